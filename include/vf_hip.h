@@ -1,0 +1,160 @@
+/* vf_hip.h — C ABI of the MI355X (gfx950) backend for the context-encoder GAN hot path.
+ *
+ * The reference (MKimiSH/video-filler, Lua/Torch7) has no FFI of its own: its compute boundary is
+ * Torch7's nn.Module / nn.Criterion object protocol plus ONE backend-swap hook, util.cudnn(net)
+ * (util.lua:108-131, called at train.lua:245-258 / train_vid_weighted.lua:330-347).  Each entry point
+ * below is what a Torch7-side module class bound through LuaJIT ffi.cdef would call in place of the
+ * THNN / THCUNN / cudnn native it replaces; the replaced native and the reference call site are cited
+ * per function.  INTEGRATION.md shows the ffi.cdef + nn.Module stubs.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; vf_last_error() gives the message
+ *    (Torch7 natives raise THError -> Lua error(); the binding turns non-zero into error()).
+ *  - all tensor pointers are DEVICE pointers to fp32 unless stated; nothing is allocated or freed
+ *    by the library except through vf_malloc / vf_free; the caller owns every buffer.
+ *  - all work is enqueued on the context's stream; no call synchronises the host except
+ *    vf_stream_synchronize and vf_memcpy_d2h.
+ *  - activations are NHWC ("channels-last": logical B x C x H x W as the reference indexes it,
+ *    physical [B][H][W][C]).  Convolution weights are the reference tensors in channels-last too:
+ *      nn.SpatialConvolution      logical [Cout][Cin][kH][kW]  physical [Cout][kH][kW][Cin]
+ *      nn.SpatialFullConvolution  logical [Cin][Cout][kH][kW]  physical [Cin][kH][kW][Cout]
+ *    vf_nchw_to_nhwc / vf_nhwc_to_nchw convert reference-layout buffers at the boundary.
+ *  - kernels: k = 4 only, (stride, pad) in {(2,1), (1,0)} — the only shapes the reference builds
+ *    (train.lua:89-146,183-196).  Spatial sizes must be powers of two (fineSize = 128).
+ */
+#ifndef VF_HIP_H
+#define VF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vf_ctx vf_ctx;
+
+/* activation codes for fused epilogues and vf_act_* */
+enum { VF_ACT_NONE = 0, VF_ACT_LRELU = 1, VF_ACT_RELU = 2, VF_ACT_TANH = 3, VF_ACT_SIGMOID = 4 };
+
+/* ---- context / memory / errors ------------------------------------------------------------ */
+const char* vf_last_error(void);
+int vf_version(void);
+/* cutorch.setDevice(opt.gpu) (train.lua:249).  stream = hipStream_t or NULL for the null stream. */
+int vf_ctx_create(vf_ctx** out, int device, void* stream);
+int vf_ctx_destroy(vf_ctx* ctx);
+int vf_ctx_set_stream(vf_ctx* ctx, void* stream);
+/* scratch for split-K slabs and reduction partials; caller-owned, >= vf_workspace_bytes_hint(). */
+int vf_ctx_set_workspace(vf_ctx* ctx, void* ptr, size_t bytes);
+size_t vf_workspace_bytes_hint(void);
+int vf_stream_synchronize(vf_ctx* ctx);
+int vf_malloc(void** out, size_t bytes);
+int vf_free(void* ptr);
+int vf_memcpy_h2d(vf_ctx* ctx, void* dst, const void* src, size_t bytes);
+int vf_memcpy_d2h(vf_ctx* ctx, void* dst, const void* src, size_t bytes); /* synchronises */
+int vf_zero(vf_ctx* ctx, void* ptr, size_t bytes);                       /* Tensor:zero() */
+/* bias zeroing sweep `m.bias:zero()` over every *Convolution* module (train.lua:279-280):
+ * zero nseg segments base[offs[i] .. offs[i]+lens[i]) ; offs/lens are DEVICE int64 arrays. */
+int vf_zero_segments(vf_ctx* ctx, float* base, const int64_t* offs, const int64_t* lens, int nseg);
+int vf_nchw_to_nhwc(vf_ctx* ctx, const float* src, float* dst, int B, int C, int H, int W);
+int vf_nhwc_to_nchw(vf_ctx* ctx, const float* src, float* dst, int B, int C, int H, int W);
+
+/* ---- nn.SpatialConvolution (THNN SpatialConvolutionMM / cudnn.SpatialConvolution) ---------- */
+/* updateOutput.  y[B][Ho][Wo][Cout] = act(conv(x[B][H][W][Cin], w) + bias).  bias may be NULL.
+ * act/slope fuse a following in-place nn.LeakyReLU / nn.ReLU / nn.Tanh / nn.Sigmoid (train.lua:90,196). */
+int vf_conv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H,
+                  int W, int Cin, int Cout, int k, int stride, int pad, int act, float slope);
+/* updateGradInput.  gx[B][H][W][Cin] from gy[B][Ho][Wo][Cout]. */
+int vf_conv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx, int B, int H, int W,
+                       int Cin, int Cout, int k, int stride, int pad);
+/* accGradParameters(scale = 1).  gw = beta*gw + dW ; gb = beta*gb + db (gb may be NULL).
+ * beta = 1 is Torch's accumulate; beta = 0 overwrites (saves the gradParameters:zero() pass). */
+int vf_conv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H,
+                         int W, int Cin, int Cout, int k, int stride, int pad, float beta);
+
+/* ---- nn.SpatialFullConvolution (THNN SpatialFullConvolution; train.lua:134-146) ------------- */
+/* x[B][H][W][Cin] -> y[B][Ho][Wo][Cout], Ho = (H-1)*stride - 2*pad + k. */
+int vf_deconv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H,
+                    int W, int Cin, int Cout, int k, int stride, int pad, int act, float slope);
+int vf_deconv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx, int B, int H, int W,
+                         int Cin, int Cout, int k, int stride, int pad);
+int vf_deconv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H,
+                           int W, int Cin, int Cout, int k, int stride, int pad, float beta);
+
+/* ---- nn.SpatialBatchNormalization (THNN/THCUNN BatchNormalization; train.lua:92) ------------ */
+/* Training forward in two phases so a data-parallel caller can all-reduce `sums` in between:
+ *   vf_bn_stats     : sums[0..C) = sum(x - shift), sums[C..2C) = sum((x - shift)^2)  (DOUBLE), shift = running_mean
+ *   vf_bn_finalize  : mean/invstd from sums over n_total rows; updates running stats (momentum, unbiased var)
+ *   vf_bn_apply     : y = act((x - mean) * invstd * gamma + beta)     (y may alias x)
+ * vf_bn_train_fwd runs the three back to back.  npix = B*H*W rows of C channels. */
+int vf_bn_stats(vf_ctx* ctx, const float* x, const float* shift, double* sums, int64_t npix, int C);
+int vf_bn_finalize(vf_ctx* ctx, const double* sums, float* running_mean, float* running_var, float* save_mean,
+                   float* save_invstd, int64_t n_total, int C, float momentum, float eps);
+int vf_bn_apply(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                const float* invstd, int64_t npix, int C, int act, float slope);
+int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
+                    int64_t npix, int C, float momentum, float eps, int act, float slope);
+/* evaluate() mode (test_vid.lua:48): running statistics. */
+int vf_bn_eval_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                   const float* running_mean, const float* running_var, int64_t npix, int C, float eps, int act,
+                   float slope);
+/* Backward, also two-phase: vf_bn_bwd_stats gives sums[0..C) = sum(g), sums[C..2C) = sum(g*(x-mean)) with
+ * g = gy masked by the fused activation's derivative (y_act = the activated output; NULL when act = NONE);
+ * vf_bn_bwd_apply writes gx (may be NULL) and ggamma/gbeta (may be NULL) = pbeta*old + new. */
+int vf_bn_bwd_stats(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, const float* save_mean,
+                    double* sums, int64_t npix, int C, int act, float slope);
+int vf_bn_bwd_apply(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                    float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
+                    const double* sums, int64_t npix, int64_t n_total, int C, int act, float slope, float pbeta);
+int vf_bn_bwd(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+              float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
+              int64_t npix, int C, int act, float slope, float pbeta);
+
+/* ---- pointwise modules (nn.LeakyReLU / ReLU / Tanh / Sigmoid; train.lua:90,146,196) --------- */
+int vf_act_fwd(vf_ctx* ctx, const float* x, float* y, int64_t n, int act, float slope); /* y may alias x */
+/* gx = gy * act'(.) evaluated from the ACTIVATED output y (in-place semantics); gx may alias gy */
+int vf_act_bwd(vf_ctx* ctx, const float* y, const float* gy, float* gx, int64_t n, int act, float slope);
+/* y = a*x + b*y  (Tensor:mul / :add(alpha, src), train.lua:382) */
+int vf_axpby(vf_ctx* ctx, float a, const float* x, float b, float* y, int64_t n);
+/* y = y .* x  (Tensor:cmul, train_vid_weighted.lua:497) */
+int vf_cmul(vf_ctx* ctx, const float* x, float* y, int64_t n);
+/* y = a*y + b   (input_mask:mul(1-lambda):add(lambda), train_vid_weighted.lua:494) */
+int vf_scale_shift(vf_ctx* ctx, float* y, float a, float b, int64_t n);
+/* out = mask != 0 ? fake : real   (maskedSelect + maskedCopy, train_vid_weighted.lua:430-432) */
+int vf_masked_compose(vf_ctx* ctx, float* out, const float* real, const float* fake, const float* mask,
+                      int64_t n);
+
+/* ---- criteria: loss scalars are written to DEVICE doubles (no host sync) -------------------- */
+/* nn.BCECriterion (eps 1e-12, sizeAverage; train.lua:204).  target = constant label (label:fill). */
+int vf_bce_fwd(vf_ctx* ctx, const float* x, float label, int n, double* loss);
+int vf_bce_bwd(vf_ctx* ctx, const float* x, float label, float* gx, int n);
+/* nn.MSECriterion (train.lua:207).  loss = mean((x-t)^2); gx = (2/n)(x-t). */
+int vf_mse_fwd(vf_ctx* ctx, const float* x, const float* t, int64_t n, double* loss);
+int vf_mse_bwd(vf_ctx* ctx, const float* x, const float* t, float* gx, int64_t n);
+/* Fused generator reconstruction gradient (train_vid_weighted.lua:489-503,523-528 / train.lua:377-399):
+ *   loss  = mean((x-t)^2)
+ *   df_dg = alpha*df_dg + (2/n)(x-t) * wgt,   wgt = c0 + c1*mask[i]            (mask != NULL)
+ *                                             wgt = inside band ? c0 : c0 + c1  (mask == NULL, band > 0:
+ *                                                   rows/cols [band, HW-band) of an HW x HW image are "inside")
+ * n = B*HW*HW*C elements, NHWC. */
+int vf_recon_grad_mix(vf_ctx* ctx, float* df_dg, const float* x, const float* t, const float* mask, float alpha,
+                      float c0, float c1, int band, int HW, int C, int64_t n, double* loss);
+/* nn.GDLCriterion(1):forward (gdl_criterion.lua:38-45) incl. the flattened-pairing quirk. */
+int vf_gdl_fwd(vf_ctx* ctx, const float* yhat, const float* y, int B, int H, int W, int C, double* loss);
+/* nn.MaskedMSECriterion(w) (MaskedMSECriterion.lua:29-41); mask is uint8 0/1. */
+int vf_masked_mse_fwd(vf_ctx* ctx, const float* x, const float* xhat, const uint8_t* mask, float w, int64_t n,
+                      double* loss);
+int vf_masked_mse_bwd(vf_ctx* ctx, const float* x, const float* xhat, const uint8_t* mask, float w, float* gx,
+                      int64_t n);
+
+/* ---- optim.adam (train.lua:421-424) -------------------------------------------------------- */
+/* One fused pass over the flat parameter vector (28 B/param).  t_dev points to TWO DEVICE int32 words:
+ * t_dev[0] = state.t (the call increments it first), t_dev[1] = scratch for the fp32 step size
+ * lr*sqrt(1-beta2^t)/(1-beta1^t), computed on the device in double so a captured graph replays correctly.
+ * Hyper-parameters are doubles, as Lua numbers are. */
+int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                 double beta2, double eps, int32_t* t_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VF_HIP_H */

@@ -1,0 +1,305 @@
+"""GPU parity: every C-ABI op of the HIP path against the CPU oracle on the same seeded inputs.
+
+fp32 tolerance (stated): 2e-5 of the tensor's max-norm for single ops whose contraction is <= 8192 long
+(the f32 MFMA is an fmaf chain; the oracle sums in a different order), 1e-6 for pointwise ops.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+# (B, Cin, H, Cout, stride, pad)
+CONV_CASES = [
+    (2, 3, 16, 64, 2, 1),      # first layer of train.lua nets: Cin = 3 (scalar gather path)
+    (2, 12, 16, 32, 2, 1),     # first netD layer of the video nets, predLen = 4
+    (3, 16, 8, 32, 2, 1),      # smallest vectorised path
+    (2, 64, 16, 64, 2, 1),
+    (2, 32, 8, 128, 2, 1),
+    (5, 64, 4, 128, 2, 1),     # ragged M (B = 5), 4x4 -> 2x2
+    (2, 128, 4, 100, 1, 0),    # bottleneck conv 4x4 -> 1x1, nBottleneck = 100 (train.lua default)
+    (3, 64, 4, 260, 1, 0),     # bottleneck with N not a multiple of the tile
+    (4, 512, 4, 1, 1, 0),      # netD's last conv + sigmoid
+    (1, 48, 8, 64, 2, 1),      # B = 1, 16-frame clips (nc = 48)
+]
+
+
+def _rand(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, oracle, hipb):
+    B, Cin, H, Cout, s, p = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    ref = oracle.SpatialConvolution(Cin, Cout, 4, 4, s, s, p, p)
+    ref.weight[...] = _rand(rng, *ref.weight.shape) * 0.05
+    ref.bias[...] = _rand(rng, Cout)
+    x = _rand(rng, B, Cin, H, H)
+    y = ref.forward(x)
+    gy = _rand(rng, *y.shape)
+    ref.gradWeight[...] = _rand(rng, *ref.weight.shape)     # accumulate onto a non-zero buffer
+    ref.gradBias[...] = _rand(rng, Cout)
+    gw0, gb0 = ref.gradWeight.copy(), ref.gradBias.copy()
+    ref.backward(x, gy)
+
+    dx, dw, db = to_dev(x, hipb), to_dev(ref.weight, hipb), to_dev(ref.bias, hipb)
+    dy = hipb.empty_act(*y.shape)
+    hipb.conv2d_fwd(dx, dw, db, dy, 4, s, p)
+    assert_close(to_np(dy), y, TOL, "conv fwd %s" % (case,))
+    dgy = to_dev(gy, hipb)
+    dgx = hipb.empty_act(*x.shape)
+    hipb.conv2d_bwd_data(dgy, dw, dgx, 4, s, p)
+    assert_close(to_np(dgx), ref.gradInput, TOL, "conv bwd_data %s" % (case,))
+    dgw, dgb = to_dev(gw0, hipb), to_dev(gb0, hipb)
+    hipb.conv2d_bwd_weight(dx, dgy, dgw, dgb, 4, s, p, 1.0)
+    assert_close(to_np(dgw), ref.gradWeight, TOL, "conv bwd_weight(beta=1) %s" % (case,))
+    assert_close(to_np(dgb), ref.gradBias, TOL, "conv bias grad %s" % (case,))
+    hipb.conv2d_bwd_weight(dx, dgy, dgw, dgb, 4, s, p, 0.0)
+    assert_close(to_np(dgw), ref.gradWeight - gw0, TOL * 2, "conv bwd_weight(beta=0) %s" % (case,))
+
+
+def test_conv_fused_activation(oracle, hipb):
+    rng = np.random.default_rng(7)
+    ref = oracle.SpatialConvolution(16, 32, 4, 4, 2, 2, 1, 1)
+    ref.weight[...] = _rand(rng, *ref.weight.shape) * 0.1
+    x = _rand(rng, 2, 16, 8, 8)
+    y = ref.forward(x).copy()
+    dx, dw, db = to_dev(x, hipb), to_dev(ref.weight, hipb), to_dev(ref.bias, hipb)
+    for act, fn in (("lrelu", lambda v: np.where(v > 0, v, 0.2 * v)), ("relu", lambda v: np.maximum(v, 0)),
+                    ("tanh", np.tanh), ("sigmoid", lambda v: 1 / (1 + np.exp(-v)))):
+        dy = hipb.empty_act(*y.shape)
+        hipb.conv2d_fwd(dx, dw, db, dy, 4, 2, 1, act, 0.2)
+        assert_close(to_np(dy), fn(y), TOL, "fused " + act)
+
+
+# (B, Cin, H, Cout, stride, pad)
+DECONV_CASES = [
+    (2, 100, 1, 128, 1, 0),    # decoder's first full-conv: 1x1 -> 4x4 (plain GEMM)
+    (3, 260, 1, 64, 1, 0),
+    (2, 128, 4, 64, 2, 1),
+    (2, 64, 8, 3, 2, 1),       # last layer of train.lua's netG: Cout = 3
+    (2, 64, 8, 12, 2, 1),      # last layer of the video netG, predLen = 4
+    (5, 16, 2, 16, 2, 1),      # ragged M
+    (1, 32, 16, 48, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_deconv_fwd_bwd(case, oracle, hipb):
+    B, Cin, H, Cout, s, p = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    ref = oracle.SpatialFullConvolution(Cin, Cout, 4, 4, s, s, p, p)
+    ref.weight[...] = _rand(rng, *ref.weight.shape) * 0.05
+    ref.bias[...] = _rand(rng, Cout)
+    x = _rand(rng, B, Cin, H, H)
+    y = ref.forward(x)
+    gy = _rand(rng, *y.shape)
+    ref.gradWeight[...] = _rand(rng, *ref.weight.shape)
+    ref.gradBias[...] = _rand(rng, Cout)
+    gw0, gb0 = ref.gradWeight.copy(), ref.gradBias.copy()
+    ref.backward(x, gy)
+
+    dx, dw, db = to_dev(x, hipb), to_dev(ref.weight, hipb), to_dev(ref.bias, hipb)
+    dy = hipb.empty_act(*y.shape)
+    hipb.deconv2d_fwd(dx, dw, db, dy, 4, s, p)
+    assert_close(to_np(dy), y, TOL, "deconv fwd %s" % (case,))
+    hipb.deconv2d_fwd(dx, dw, db, dy, 4, s, p, "relu")
+    assert_close(to_np(dy), np.maximum(y, 0), TOL, "deconv fwd+relu %s" % (case,))
+    dgy = to_dev(gy, hipb)
+    dgx = hipb.empty_act(*x.shape)
+    hipb.deconv2d_bwd_data(dgy, dw, dgx, 4, s, p)
+    assert_close(to_np(dgx), ref.gradInput, TOL, "deconv bwd_data %s" % (case,))
+    dgw, dgb = to_dev(gw0, hipb), to_dev(gb0, hipb)
+    hipb.deconv2d_bwd_weight(dx, dgy, dgw, dgb, 4, s, p, 1.0)
+    assert_close(to_np(dgw), ref.gradWeight, TOL, "deconv bwd_weight %s" % (case,))
+    assert_close(to_np(dgb), ref.gradBias, TOL, "deconv bias grad %s" % (case,))
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 8, 8), (2, 128, 16, 16), (8, 100, 1, 1), (3, 260, 4, 4), (16, 4000, 1, 1)])
+@pytest.mark.parametrize("act", ["none", "lrelu", "relu"])
+def test_batchnorm(shape, act, oracle, hipb):
+    B, C, H, W = shape
+    rng = np.random.default_rng(C * 7 + H)
+    ref = oracle.SpatialBatchNormalization(C)
+    ref.weight[...] = 1 + 0.1 * _rand(rng, C)
+    ref.bias[...] = 0.1 * _rand(rng, C)
+    ref.running_mean[...] = 0.3 * _rand(rng, C)
+    ref.running_var[...] = 1 + 0.2 * np.abs(_rand(rng, C))
+    rm0, rv0 = ref.running_mean.copy(), ref.running_var.copy()
+    x = (_rand(rng, *shape) * 1.7 + 0.8).astype(np.float32)
+    y = ref.forward(x).copy()
+    slope = 0.2
+    if act == "lrelu":
+        ya = np.where(y > 0, y, slope * y).astype(np.float32)
+    elif act == "relu":
+        ya = np.maximum(y, 0)
+    else:
+        ya = y
+    gy = _rand(rng, *shape)
+    g_eff = gy.copy()
+    if act == "lrelu":
+        g_eff = np.where(ya > 0, gy, slope * gy).astype(np.float32)
+    elif act == "relu":
+        g_eff = np.where(ya > 0, gy, 0).astype(np.float32)
+    ref.gradWeight[...] = _rand(rng, C)
+    ref.gradBias[...] = _rand(rng, C)
+    gw0, gb0 = ref.gradWeight.copy(), ref.gradBias.copy()
+    ref.backward(x, g_eff)
+
+    dx = to_dev(x, hipb)
+    dy = hipb.empty_act(*shape)
+    gamma, beta = to_dev(ref.weight, hipb), to_dev(ref.bias, hipb)
+    rm, rv = to_dev(rm0, hipb), to_dev(rv0, hipb)
+    sm, si = hipb.zeros(C), hipb.zeros(C)
+    sums = hipb.zeros(2 * C, dtype=torch.float64)
+    hipb.bn_stats(dx, rm, sums)
+    hipb.bn_finalize(sums, rm, rv, sm, si, B * H * W, 0.1, 1e-5)
+    hipb.bn_apply(dx, dy, gamma, beta, sm, si, act, slope)
+    assert_close(to_np(dy), ya, 1e-5, "bn fwd")
+    assert_close(to_np(sm), ref.save_mean, 1e-5, "save_mean")
+    assert_close(to_np(si), ref.save_std, 1e-5, "save_invstd")
+    assert_close(to_np(rm), ref.running_mean, 1e-5, "running_mean")
+    if B * H * W > 1:
+        assert_close(to_np(rv), ref.running_var, 1e-5, "running_var")
+    dgy = to_dev(gy, hipb)
+    dgx = hipb.empty_act(*shape)
+    ggam, gbet = to_dev(gw0, hipb), to_dev(gb0, hipb)
+    hipb.bn_bwd_stats(dx, dy if act != "none" else None, dgy, sm, sums, act, slope)
+    hipb.bn_bwd_apply(dx, dy if act != "none" else None, dgy, dgx, ggam, gbet, gamma, sm, si, sums, B * H * W, act, slope, 1.0)
+    assert_close(to_np(dgx), ref.gradInput, 5e-5, "bn gradInput")
+    assert_close(to_np(ggam), ref.gradWeight, 2e-5, "bn gradWeight")
+    assert_close(to_np(gbet), ref.gradBias, 2e-5, "bn gradBias")
+    # evaluate mode
+    ref.train = False
+    ye = ref.forward(x)
+    hipb.bn_eval_fwd(dx, dy, gamma, beta, rm, rv, 1e-5)
+    assert_close(to_np(dy), ye, 1e-5, "bn eval")
+
+
+def test_pointwise_and_layout(oracle, hipb):
+    rng = np.random.default_rng(3)
+    x = _rand(rng, 3, 5, 8, 8)
+    d = torch.from_numpy(x).to(hipb.device)             # NCHW contiguous on device
+    out = hipb.empty(3, 8, 8, 5)
+    hipb._c("vf_nchw_to_nhwc", d.data_ptr(), out.data_ptr(), 3, 5, 8, 8)
+    np.testing.assert_array_equal(to_np(out), x.transpose(0, 2, 3, 1))
+    back = hipb.empty(3, 5, 8, 8)
+    hipb._c("vf_nhwc_to_nchw", out.data_ptr(), back.data_ptr(), 3, 5, 8, 8)
+    np.testing.assert_array_equal(to_np(back), x)
+    a, b = to_dev(x, hipb), to_dev(_rand(rng, 3, 5, 8, 8), hipb)
+    an, bn = to_np(a), to_np(b)
+    y = b.clone()
+    hipb.axpby(0.25, a, -1.5, y)
+    assert_close(to_np(y), 0.25 * an - 1.5 * bn, 1e-6, "axpby")
+    y = b.clone()
+    hipb.cmul(a, y)
+    assert_close(to_np(y), an * bn, 1e-6, "cmul")
+    y = b.clone()
+    hipb.scale_shift(y, 0.95, 0.05)
+    assert_close(to_np(y), bn * np.float32(0.95) + np.float32(0.05), 1e-6, "scale_shift")
+    mask = (rng.random((3, 5, 8, 8)) > 0.5).astype(np.float32)
+    o = hipb.empty_act(3, 5, 8, 8)
+    hipb.masked_compose(o, a, b, to_dev(mask, hipb))
+    np.testing.assert_array_equal(to_np(o), np.where(mask != 0, bn, an))
+    for act in ("lrelu", "relu", "tanh", "sigmoid"):
+        yv = torch.empty_like(a)
+        hipb.act_fwd(a, yv, act, 0.2)
+        g = torch.empty_like(a)
+        hipb.act_bwd(yv, b, g, act, 0.2)
+        ynp = to_np(yv)
+        if act == "lrelu":
+            ey, eg = np.where(an > 0, an, 0.2 * an), np.where(ynp > 0, bn, 0.2 * bn)
+        elif act == "relu":
+            ey, eg = np.maximum(an, 0), np.where(ynp > 0, bn, 0)
+        elif act == "tanh":
+            ey, eg = np.tanh(an), bn * (1 - ynp * ynp)
+        else:
+            ey = 1 / (1 + np.exp(-an))
+            eg = bn * (1 - ynp) * ynp
+        assert_close(ynp, ey, 2e-6, act + " fwd")
+        assert_close(to_np(g), eg, 2e-6, act + " bwd")
+    # zero_segments
+    base = hipb.zeros(100) + 1
+    offs = torch.tensor([3, 50], dtype=torch.int64, device=hipb.device)
+    lens = torch.tensor([5, 10], dtype=torch.int64, device=hipb.device)
+    hipb.zero_segments(base, offs, lens)
+    e = np.ones(100, np.float32)
+    e[3:8] = 0
+    e[50:60] = 0
+    np.testing.assert_array_equal(to_np(base), e)
+
+
+def test_criteria(oracle, hipb):
+    rng = np.random.default_rng(5)
+    loss = hipb.zeros(1, dtype=torch.float64)
+    # BCE incl. saturated inputs (eps = 1e-12 semantics differ from torch's clamp)
+    p = np.concatenate([rng.random(30), [0.0, 1.0, 1e-9, 1 - 1e-7]]).astype(np.float32)
+    for label in (0.0, 1.0):
+        t = np.full(p.shape, label, np.float32)
+        hipb.bce_fwd(to_dev(p, hipb), label, loss)
+        assert abs(loss.item() - oracle.lib().vfo_bce_fwd(oracle._p(p), oracle._p(t), p.size)) <= 1e-9 * max(1, abs(loss.item()))
+        g = hipb.zeros(p.size)
+        hipb.bce_bwd(to_dev(p, hipb), label, g)
+        assert_close(to_np(g), oracle.BCECriterion().backward(p, t), 1e-6, "bce bwd")
+    x, t = _rand(rng, 2, 6, 16, 16), _rand(rng, 2, 6, 16, 16)
+    dx, dt = to_dev(x, hipb), to_dev(t, hipb)
+    hipb.mse_fwd(dx, dt, loss)
+    assert abs(loss.item() - oracle.MSECriterion().forward(x, t)) < 1e-6
+    g = torch.empty_like(dx)
+    hipb.mse_bwd(dx, dt, g)
+    assert_close(to_np(g), oracle.MSECriterion().backward(x, t), 1e-6, "mse bwd")
+    hipb.gdl_fwd(dx, dt, loss)
+    assert abs(loss.item() - oracle.GDLCriterion(1).forward(x, t)) < 1e-6
+    m = (rng.random(x.shape) > 0.6).astype(np.uint8)
+    crit = oracle.MaskedMSECriterion(0.05)
+    crit.setMask(m)
+    dm = to_dev(m, hipb)
+    hipb.masked_mse_fwd(dx, dt, dm, 0.05, loss)
+    assert abs(loss.item() - crit.forward(x, t)) < 1e-6
+    hipb.masked_mse_bwd(dx, dt, dm, 0.05, g)
+    assert_close(to_np(g), crit.backward(x, t), 1e-6, "masked mse bwd")
+    # fused recon gradient: mask form and band form against the reference op sequence
+    dfdg0 = _rand(rng, *x.shape)
+    wt, lam, wtgdl = 0.999, 0.05, 0.5
+    gl2 = oracle.MSECriterion().backward(x, t)
+    w = m.astype(np.float32) * np.float32(1 - lam) + np.float32(lam)
+    exp = dfdg0 * np.float32(1 - wt) + np.float32(wt) * (gl2 * w) + np.float32(wtgdl) * gl2
+    d = to_dev(dfdg0, hipb)
+    hipb.recon_grad_mix(d, dx, dt, to_dev(m.astype(np.float32), hipb), 1 - wt, wt * lam + wtgdl, wt * (1 - lam), 0, loss)
+    assert_close(to_np(d), exp, 2e-6, "recon_grad_mix(mask)")
+    assert abs(loss.item() - oracle.MSECriterion().forward(x, t)) < 1e-6
+    ov = 3
+    W = np.full(x.shape, np.float32(10 * wt), np.float32)
+    W[:, :, ov:16 - ov, ov:16 - ov] = np.float32(wt)
+    exp = dfdg0 * np.float32(1 - wt) + W * gl2
+    d = to_dev(dfdg0, hipb)
+    hipb.recon_grad_mix(d, dx, dt, None, 1 - wt, wt, 9 * wt, ov, loss)
+    assert_close(to_np(d), exp, 2e-6, "recon_grad_mix(band)")
+
+
+def test_adam(oracle, hipb):
+    rng = np.random.default_rng(11)
+    n = 10007
+    x, g = _rand(rng, n), _rand(rng, n) * 1e-3
+    g[:50] = 0.0
+    g[50:100] *= 1e-6
+    xr = x.copy()
+    state = {"learningRate": 0.002, "beta1": 0.5}
+    npad = (n + 3) // 4 * 4
+    dx, dg = hipb.zeros(npad), hipb.zeros(npad)
+    dx[:n] = torch.from_numpy(x).to(hipb.device)
+    dg[:n] = torch.from_numpy(g).to(hipb.device)
+    m, v = hipb.zeros(npad), hipb.zeros(npad)
+    t_dev = hipb.zeros(2, dtype=torch.int32)
+    for it in range(3):
+        oracle.adam(lambda _x: (0.0, g), xr, state)
+        hipb.adam_step(dx[:n], dg[:n], m[:n], v[:n], 0.002, 0.5, 0.999, 1e-8, t_dev)
+        np.testing.assert_allclose(to_np(dx[:n]), xr, rtol=0, atol=2e-7 * (it + 1))
+    assert int(t_dev[0].item()) == 3
+    np.testing.assert_allclose(to_np(m[:n]), state["m"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(to_np(v[:n]), state["v"], rtol=1e-6, atol=1e-15)

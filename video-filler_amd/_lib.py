@@ -1,0 +1,103 @@
+"""ctypes binding of include/vf_hip.h (the C-ABI of the gfx950 backend).
+
+The library is built in-tree by build.py (hipcc, --offload-arch=gfx950).  There is NO fallback:
+if the shared object is missing or no GPU is visible, loading / context creation raises.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_HEADER = os.path.join(_HERE, "..", "include", "vf_hip.h")
+
+vp, f32, i32, i64, f64, sz = C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vf_hip.h one to one
+SIGNATURES = {
+    "vf_last_error": (C.c_char_p, []),
+    "vf_version": (i32, []),
+    "vf_ctx_create": (i32, [C.POINTER(vp), i32, vp]),
+    "vf_ctx_destroy": (i32, [vp]),
+    "vf_ctx_set_stream": (i32, [vp, vp]),
+    "vf_ctx_set_workspace": (i32, [vp, vp, sz]),
+    "vf_workspace_bytes_hint": (sz, []),
+    "vf_stream_synchronize": (i32, [vp]),
+    "vf_malloc": (i32, [C.POINTER(vp), sz]),
+    "vf_free": (i32, [vp]),
+    "vf_memcpy_h2d": (i32, [vp, vp, vp, sz]),
+    "vf_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+    "vf_zero": (i32, [vp, vp, sz]),
+    "vf_zero_segments": (i32, [vp, vp, vp, vp, i32]),
+    "vf_nchw_to_nhwc": (i32, [vp, vp, vp, i32, i32, i32, i32]),
+    "vf_nhwc_to_nchw": (i32, [vp, vp, vp, i32, i32, i32, i32]),
+    "vf_conv2d_fwd": (i32, [vp, vp, vp, vp, vp] + [i32] * 8 + [i32, f32]),
+    "vf_conv2d_bwd_data": (i32, [vp, vp, vp, vp] + [i32] * 8),
+    "vf_conv2d_bwd_weight": (i32, [vp, vp, vp, vp, vp] + [i32] * 8 + [f32]),
+    "vf_deconv2d_fwd": (i32, [vp, vp, vp, vp, vp] + [i32] * 8 + [i32, f32]),
+    "vf_deconv2d_bwd_data": (i32, [vp, vp, vp, vp] + [i32] * 8),
+    "vf_deconv2d_bwd_weight": (i32, [vp, vp, vp, vp, vp] + [i32] * 8 + [f32]),
+    "vf_bn_stats": (i32, [vp, vp, vp, vp, i64, i32]),
+    "vf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32]),
+    "vf_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32]),
+    "vf_bn_train_fwd": (i32, [vp] * 10 + [i64, i32, f32, f32, i32, f32]),
+    "vf_bn_eval_fwd": (i32, [vp] * 7 + [i64, i32, f32, i32, f32]),
+    "vf_bn_bwd_stats": (i32, [vp] * 6 + [i64, i32, i32, f32]),
+    "vf_bn_bwd_apply": (i32, [vp] * 11 + [i64, i64, i32, i32, f32, f32]),
+    "vf_bn_bwd": (i32, [vp] * 11 + [i64, i32, i32, f32, f32]),
+    "vf_act_fwd": (i32, [vp, vp, vp, i64, i32, f32]),
+    "vf_act_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32]),
+    "vf_axpby": (i32, [vp, f32, vp, f32, vp, i64]),
+    "vf_cmul": (i32, [vp, vp, vp, i64]),
+    "vf_scale_shift": (i32, [vp, vp, f32, f32, i64]),
+    "vf_masked_compose": (i32, [vp, vp, vp, vp, vp, i64]),
+    "vf_bce_fwd": (i32, [vp, vp, f32, i32, vp]),
+    "vf_bce_bwd": (i32, [vp, vp, f32, vp, i32]),
+    "vf_mse_fwd": (i32, [vp, vp, vp, i64, vp]),
+    "vf_mse_bwd": (i32, [vp, vp, vp, vp, i64]),
+    "vf_recon_grad_mix": (i32, [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i64, vp]),
+    "vf_gdl_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "vf_masked_mse_fwd": (i32, [vp, vp, vp, vp, f32, i64, vp]),
+    "vf_masked_mse_bwd": (i32, [vp, vp, vp, vp, f32, vp, i64]),
+    "vf_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, vp]),
+}
+
+
+def header_symbols():
+    """Every function name declared in include/vf_hip.h."""
+    with open(_HEADER) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(vf_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libvf_hip.so")
+
+
+_LIB = None
+
+
+def load():
+    """dlopen the HIP library and attach signatures.  Raises if it is not built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "video-filler_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+class VfError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise VfError(load().vf_last_error().decode())

@@ -1,0 +1,213 @@
+"""Tensor-level backend used by the nn mirror: torch tensors in, raw device pointers out to the C-ABI.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); every FLOP of the hot path runs in
+libvf_hip.so.  `HipBackend` is the only backend the package ships.  Tests may install another object with
+the same methods through `set_backend` to exercise host logic on CPU (tests/oracle_backend.py); the package
+itself never constructs anything else and never falls back.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def is_nhwc(t):
+    """True if a logical B x C x H x W tensor is physically [B][H][W][C] and dense."""
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def nhwc_empty(B, Cc, H, W, device, dtype=torch.float32):
+    return torch.empty((B, H, W, Cc), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def to_nhwc(t):
+    return t if is_nhwc(t) else t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+class HipBackend:
+    name = "hip-gfx950"
+
+    def __init__(self, device=None, workspace_bytes=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("video-filler_amd: no MI355X visible (torch.cuda.is_available() is False); "
+                               "the HIP backend has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        ctx = C.c_void_p()
+        _lib.check(self.lib.vf_ctx_create(C.byref(ctx), self.device.index, None))
+        self.ctx = ctx
+        nbytes = workspace_bytes or self.lib.vf_workspace_bytes_hint()
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.vf_ctx_set_workspace(self.ctx, _ptr(self.workspace), nbytes))
+        self.use_current_stream()
+
+    # ---- plumbing
+    def use_current_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.vf_ctx_set_stream(self.ctx, C.c_void_p(s)))
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def empty_act(self, B, Cc, H, W):
+        return nhwc_empty(B, Cc, H, W, self.device)
+
+    def from_host(self, t):
+        return t.to(self.device)
+
+    def all_reduce(self, t, group=None):
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+
+    def _c(self, name, *args):
+        _lib.check(getattr(self.lib, name)(self.ctx, *args))
+
+    # ---- convolution family.  x/y logical BxCxHxW (NHWC physical); w logical as the reference (channels-last)
+    def conv2d_fwd(self, x, w, bias, y, k, stride, pad, act="none", slope=0.0):
+        B, Cin, H, W = x.shape
+        self._c("vf_conv2d_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, w.shape[0], k, stride, pad,
+                ACT[act], slope)
+
+    def conv2d_bwd_data(self, gy, w, gx, k, stride, pad):
+        B, Cin, H, W = gx.shape
+        self._c("vf_conv2d_bwd_data", _ptr(gy), _ptr(w), _ptr(gx), B, H, W, Cin, w.shape[0], k, stride, pad)
+
+    def conv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta):
+        B, Cin, H, W = x.shape
+        self._c("vf_conv2d_bwd_weight", _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), B, H, W, Cin, gw.shape[0], k, stride,
+                pad, beta)
+
+    def deconv2d_fwd(self, x, w, bias, y, k, stride, pad, act="none", slope=0.0):
+        B, Cin, H, W = x.shape
+        self._c("vf_deconv2d_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, w.shape[1], k, stride, pad,
+                ACT[act], slope)
+
+    def deconv2d_bwd_data(self, gy, w, gx, k, stride, pad):
+        B, Cin, H, W = gx.shape
+        self._c("vf_deconv2d_bwd_data", _ptr(gy), _ptr(w), _ptr(gx), B, H, W, Cin, w.shape[1], k, stride, pad)
+
+    def deconv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta):
+        B, Cin, H, W = x.shape
+        self._c("vf_deconv2d_bwd_weight", _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), B, H, W, Cin, gw.shape[1], k, stride,
+                pad, beta)
+
+    # ---- batch norm
+    def bn_stats(self, x, shift, sums):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_stats", _ptr(x), _ptr(shift), _ptr(sums), B * H * W, Cc)
+
+    def bn_finalize(self, sums, rm, rv, save_mean, save_invstd, n_total, momentum, eps):
+        self._c("vf_bn_finalize", _ptr(sums), _ptr(rm), _ptr(rv), _ptr(save_mean), _ptr(save_invstd), n_total,
+                rm.numel(), momentum, eps)
+
+    def bn_apply(self, x, y, gamma, beta, mean, invstd, act="none", slope=0.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_apply", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), B * H * W, Cc,
+                ACT[act], slope)
+
+    def bn_eval_fwd(self, x, y, gamma, beta, rm, rv, eps, act="none", slope=0.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_eval_fwd", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), B * H * W, Cc, eps,
+                ACT[act], slope)
+
+    def bn_bwd_stats(self, x, y_act, gy, save_mean, sums, act="none", slope=0.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_bwd_stats", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(save_mean), _ptr(sums), B * H * W, Cc,
+                ACT[act], slope)
+
+    def bn_bwd_apply(self, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, n_total, act="none",
+                     slope=0.0, pbeta=1.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_bwd_apply", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
+                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), B * H * W, n_total, Cc, ACT[act], slope, pbeta)
+
+    # ---- pointwise
+    def act_fwd(self, x, y, act, slope=0.0):
+        self._c("vf_act_fwd", _ptr(x), _ptr(y), x.numel(), ACT[act], slope)
+
+    def act_bwd(self, y, gy, gx, act, slope=0.0):
+        self._c("vf_act_bwd", _ptr(y), _ptr(gy), _ptr(gx), y.numel(), ACT[act], slope)
+
+    def axpby(self, a, x, b, y):
+        self._c("vf_axpby", a, _ptr(x), b, _ptr(y), y.numel())
+
+    def cmul(self, x, y):
+        self._c("vf_cmul", _ptr(x), _ptr(y), y.numel())
+
+    def scale_shift(self, y, a, b):
+        self._c("vf_scale_shift", _ptr(y), a, b, y.numel())
+
+    def masked_compose(self, out, real, fake, mask):
+        self._c("vf_masked_compose", _ptr(out), _ptr(real), _ptr(fake), _ptr(mask), out.numel())
+
+    def zero(self, t):
+        self._c("vf_zero", _ptr(t), t.numel() * t.element_size())
+
+    def zero_segments(self, base, offs, lens):
+        self._c("vf_zero_segments", _ptr(base), _ptr(offs), _ptr(lens), offs.numel())
+
+    def copy(self, dst, src):
+        dst.copy_(src)  # cudaMemcpyAsync D2D on the current stream — plumbing
+
+    # ---- criteria (loss: 1-element float64 device tensor)
+    def bce_fwd(self, x, label, loss):
+        self._c("vf_bce_fwd", _ptr(x), float(label), x.numel(), _ptr(loss))
+
+    def bce_bwd(self, x, label, gx):
+        self._c("vf_bce_bwd", _ptr(x), float(label), _ptr(gx), x.numel())
+
+    def mse_fwd(self, x, t, loss):
+        self._c("vf_mse_fwd", _ptr(x), _ptr(t), x.numel(), _ptr(loss))
+
+    def mse_bwd(self, x, t, gx):
+        self._c("vf_mse_bwd", _ptr(x), _ptr(t), _ptr(gx), x.numel())
+
+    def recon_grad_mix(self, df_dg, x, t, mask, alpha, c0, c1, band, loss):
+        B, Cc, H, W = x.shape
+        self._c("vf_recon_grad_mix", _ptr(df_dg), _ptr(x), _ptr(t), _ptr(mask), alpha, c0, c1, band, H, Cc, x.numel(),
+                _ptr(loss))
+
+    def gdl_fwd(self, yhat, y, loss):
+        B, Cc, H, W = y.shape
+        self._c("vf_gdl_fwd", _ptr(yhat), _ptr(y), B, H, W, Cc, _ptr(loss))
+
+    def masked_mse_fwd(self, x, xhat, mask_u8, w, loss):
+        self._c("vf_masked_mse_fwd", _ptr(x), _ptr(xhat), _ptr(mask_u8), w, x.numel(), _ptr(loss))
+
+    def masked_mse_bwd(self, x, xhat, mask_u8, w, gx):
+        self._c("vf_masked_mse_bwd", _ptr(x), _ptr(xhat), _ptr(mask_u8), w, _ptr(gx), x.numel())
+
+    # ---- adam
+    def adam_step(self, x, g, m, v, lr, beta1, beta2, eps, t_dev):
+        self._c("vf_adam_step", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), lr, beta1, beta2, eps, _ptr(t_dev))
+
+    def synchronize(self):
+        _lib.check(self.lib.vf_stream_synchronize(self.ctx))
+
+
+_BACKEND = None
+
+
+def get_backend():
+    """The process-wide backend; created on first use.  Raises without a GPU — no CPU fallback exists."""
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+def set_backend(b):
+    """Install a backend object (tests only: host-logic checks on CPU)."""
+    global _BACKEND
+    _BACKEND = b
+    return b

@@ -1,0 +1,49 @@
+"""Build the gfx950 HIP library in-tree: video-filler_amd/lib/libvf_hip.so (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = ["vf_core.hip", "vf_bn.hip", "vf_conv.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libvf_hip.so")
+
+
+def build(force=False, verbose=False):
+    csrc = os.path.join(HERE, "csrc")
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(csrc, "vf_common.h"), os.path.join(HERE, "..", "include", "vf_hip.h")]
+    hdr_m = max(os.path.getmtime(h) for h in hdrs)
+    objs, rebuilt = [], False
+    procs = []
+    for s in SRC:
+        src = os.path.join(csrc, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+            cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            rebuilt = True
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on " + s)
+        if verbose and out:
+            print(out.decode())
+    so = lib_path()
+    if rebuilt or not os.path.exists(so):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs])
+    return so
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

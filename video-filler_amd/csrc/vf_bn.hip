@@ -1,0 +1,315 @@
+// vf_bn.hip — nn.SpatialBatchNormalization (train forward, backward, eval forward) on NHWC rows [npix][C].
+//
+// Reference: THNN BatchNormalization.c (double accumulators) / THCUNN BatchNormalization.cu, reached from
+// train.lua:92-101,125,135-144,189-193.  HBM-bound: every kernel walks rows with the channel axis on the
+// lanes (16-byte loads, fully coalesced), per-thread fp32 partial sums over <= 64 rows, then DOUBLE partials
+// combined in a fixed order (deterministic).  Statistics are shifted by the running mean so that
+// var = E[(x-s)^2] - E[x-s]^2 does not cancel catastrophically; the two-phase split (stats | finalize+apply)
+// is the hook where a data-parallel caller all-reduces the per-channel sums (SyncBN).
+#include <algorithm>
+
+#include "vf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct BnGeom {
+  int cq;              // float4 columns per block (power of two <= 64)
+  int rp;              // row lanes per block = 256 / cq
+  int gy;              // column chunks
+  int gx;              // row slabs
+  int rows_per_block;
+};
+
+static BnGeom bn_geom(int64_t npix, int C) {
+  BnGeom g;
+  const int C4 = C / 4;
+  int cq = 1;
+  while (cq < C4 && cq < 64) cq <<= 1;
+  g.cq = cq;
+  g.rp = 256 / cq;
+  g.gy = (int)vf_cdiv(C4, cq);
+  // <= 64 rows per thread, and no more than ~2048 blocks in total
+  int64_t rpb = (int64_t)g.rp * 64;
+  while (vf_cdiv(npix, rpb) * g.gy > 2048) rpb *= 2;
+  g.rows_per_block = (int)std::min<int64_t>(rpb, std::max<int64_t>(npix, 1));
+  g.gx = (int)vf_cdiv(npix, g.rows_per_block);
+  return g;
+}
+
+// ---- forward statistics: partial[slab][2][C] (double)
+__global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, const float* __restrict__ shift,
+                                                  double* __restrict__ part, int64_t npix, int C, int cq, int rows_per_block) {
+  const int rp = 256 / cq;
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
+  const int c4 = blockIdx.y * cq + tx;
+  const int C4 = C >> 2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(npix, r0 + rows_per_block);
+  f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+  if (c4 < C4) {
+    const f32x4 sh = shift ? *(const f32x4*)(shift + 4 * c4) : f32x4{0, 0, 0, 0};
+    for (int64_t r = r0 + ty; r < r1; r += rp) {
+      const f32x4 v = *(const f32x4*)(x + r * C + 4 * c4) - sh;
+      s += v;
+      ss += v * v;
+    }
+  }
+  __shared__ f32x4 red[2][256];
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (ty == 0 && c4 < C4) {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    for (int j = 0; j < rp; ++j) {
+      const f32x4 u = red[0][j * cq + tx], w = red[1][j * cq + tx];
+      for (int e = 0; e < 4; ++e) {
+        a[e] += (double)u[e];
+        b[e] += (double)w[e];
+      }
+    }
+    double* o = part + (int64_t)blockIdx.x * 2 * C;
+    for (int e = 0; e < 4; ++e) {
+      o[4 * c4 + e] = a[e];
+      o[C + 4 * c4 + e] = b[e];
+    }
+  }
+}
+
+__global__ void k_sum_partials(const double* __restrict__ part, double* __restrict__ sums, int nslab, int twoC) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= twoC) return;
+  double s = 0;
+  for (int k = 0; k < nslab; ++k) s += part[(int64_t)k * twoC + i];
+  sums[i] = s;
+}
+
+// mean/invstd + running statistics (THNN BatchNormalization_updateOutput, train branch)
+__global__ void k_bn_finalize(const double* __restrict__ sums, float* __restrict__ running_mean,
+                              float* __restrict__ running_var, float* __restrict__ save_mean,
+                              float* __restrict__ save_invstd, double n, int C, float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double shift = running_mean[c];
+  const double s1 = sums[c], s2 = sums[C + c];
+  const double mean = shift + s1 / n;
+  double m2 = s2 - s1 * s1 / n;  // = sum (x - mean)^2
+  if (m2 < 0) m2 = 0;
+  float invstd;
+  if (m2 == 0 && eps == 0.f)
+    invstd = 0.f;
+  else
+    invstd = (float)(1.0 / sqrt(m2 / n + (double)eps));
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  running_mean[c] = (float)(momentum * mean + (1.0 - momentum) * running_mean[c]);
+  const double unbiased = m2 / (n - 1.0);  // n == 1 -> inf/NaN, as the reference
+  running_var[c] = (float)(momentum * unbiased + (1.0 - momentum) * running_var[c]);
+}
+
+// y = act(((x - mean) * invstd) * gamma + beta)
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, float* __restrict__ y,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                  int64_t npix, int C, int cq, int rows_per_block, int act, float slope) {
+  const int rp = 256 / cq;
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
+  const int c4 = blockIdx.y * cq + tx;
+  if (c4 >= (C >> 2)) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(npix, r0 + rows_per_block);
+  const f32x4 mu = *(const f32x4*)(mean + 4 * c4), is = *(const f32x4*)(invstd + 4 * c4);
+  const f32x4 ga = gamma ? *(const f32x4*)(gamma + 4 * c4) : f32x4{1, 1, 1, 1};
+  const f32x4 be = beta ? *(const f32x4*)(beta + 4 * c4) : f32x4{0, 0, 0, 0};
+  for (int64_t r = r0 + ty; r < r1; r += rp) {
+    f32x4 v = *(const f32x4*)(x + r * C + 4 * c4);
+    v = ((v - mu) * is) * ga + be;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = vf_act_apply(v[e], act, slope);
+    *(f32x4*)(y + r * C + 4 * c4) = v;
+  }
+}
+
+__global__ void k_bn_eval_coeff(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                float* __restrict__ mean, float* __restrict__ invstd, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  invstd[c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+}
+
+// ---- backward statistics: sum(g), sum(g * (x - mean)), g = gy masked by the fused activation
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ x, const float* __restrict__ yact,
+                                                      const float* __restrict__ gy, const float* __restrict__ mean,
+                                                      double* __restrict__ part, int64_t npix, int C, int cq,
+                                                      int rows_per_block, int act, float slope) {
+  const int rp = 256 / cq;
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
+  const int c4 = blockIdx.y * cq + tx;
+  const int C4 = C >> 2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(npix, r0 + rows_per_block);
+  f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+  if (c4 < C4) {
+    const f32x4 mu = *(const f32x4*)(mean + 4 * c4);
+    for (int64_t r = r0 + ty; r < r1; r += rp) {
+      const int64_t o = r * C + 4 * c4;
+      f32x4 g = *(const f32x4*)(gy + o);
+      if (act != VF_ACT_NONE) {
+        const f32x4 ya = *(const f32x4*)(yact + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = vf_act_grad(ya[e], g[e], act, slope);
+      }
+      const f32x4 xv = *(const f32x4*)(x + o);
+      s += g;
+      dp += g * (xv - mu);
+    }
+  }
+  __shared__ f32x4 red[2][256];
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = dp;
+  __syncthreads();
+  if (ty == 0 && c4 < C4) {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    for (int j = 0; j < rp; ++j) {
+      const f32x4 u = red[0][j * cq + tx], w = red[1][j * cq + tx];
+      for (int e = 0; e < 4; ++e) {
+        a[e] += (double)u[e];
+        b[e] += (double)w[e];
+      }
+    }
+    double* o = part + (int64_t)blockIdx.x * 2 * C;
+    for (int e = 0; e < 4; ++e) {
+      o[4 * c4 + e] = a[e];
+      o[C + 4 * c4 + e] = b[e];
+    }
+  }
+}
+
+// gx = (g - sum/n - (x-mean)*k) * invstd * gamma,  k = dotp*invstd^2/n   (THNN BatchNormalization_backward)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ yact,
+                                                      const float* __restrict__ gy, float* __restrict__ gx,
+                                                      float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const double* __restrict__ sums,
+                                                      int64_t npix, double n, int C, int cq, int rows_per_block, int act,
+                                                      float slope, float pbeta) {
+  const int rp = 256 / cq;
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
+  const int c4 = blockIdx.y * cq + tx;
+  if (c4 >= (C >> 2)) return;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(npix, r0 + rows_per_block);
+  const f32x4 mu = *(const f32x4*)(mean + 4 * c4), is = *(const f32x4*)(invstd + 4 * c4);
+  const f32x4 ga = gamma ? *(const f32x4*)(gamma + 4 * c4) : f32x4{1, 1, 1, 1};
+  f32x4 kk, gm;
+  double sum[4], dotp[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sum[e] = sums[4 * c4 + e];
+    dotp[e] = sums[C + 4 * c4 + e];
+    kk[e] = (float)(dotp[e] * is[e] * is[e] / n);
+    gm[e] = (float)(sum[e] / n);
+  }
+  if (blockIdx.x == 0 && ty == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (ggamma) ggamma[4 * c4 + e] = (pbeta != 0.f ? pbeta * ggamma[4 * c4 + e] : 0.f) + (float)(dotp[e] * is[e]);
+      if (gbeta) gbeta[4 * c4 + e] = (pbeta != 0.f ? pbeta * gbeta[4 * c4 + e] : 0.f) + (float)sum[e];
+    }
+  }
+  if (!gx) return;
+  for (int64_t r = r0 + ty; r < r1; r += rp) {
+    const int64_t o = r * C + 4 * c4;
+    f32x4 g = *(const f32x4*)(gy + o);
+    if (act != VF_ACT_NONE) {
+      const f32x4 ya = *(const f32x4*)(yact + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = vf_act_grad(ya[e], g[e], act, slope);
+    }
+    const f32x4 xv = *(const f32x4*)(x + o);
+    *(f32x4*)(gx + o) = (g - gm - (xv - mu) * kk) * is * ga;
+  }
+}
+
+// ================================================================================================ host
+static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C) {
+  hipLaunchKernelGGL(k_sum_partials, dim3((int)vf_cdiv(2 * C, 256)), dim3(256), 0, ctx->stream, (const double*)ctx->ws,
+                     sums, g.gx, 2 * C);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+VF_API int vf_bn_stats(vf_ctx* ctx, const float* x, const float* shift, double* sums, int64_t npix, int C) {
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  const BnGeom g = bn_geom(npix, C);
+  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, shift, (double*)ctx->ws, npix, C, g.cq,
+                     g.rows_per_block);
+  VF_LAUNCH_CHECK();
+  return run_stats(ctx, g, sums, C);
+}
+
+VF_API int vf_bn_finalize(vf_ctx* ctx, const double* sums, float* running_mean, float* running_var, float* save_mean,
+                          float* save_invstd, int64_t n_total, int C, float momentum, float eps) {
+  hipLaunchKernelGGL(k_bn_finalize, dim3((int)vf_cdiv(C, 256)), dim3(256), 0, ctx->stream, sums, running_mean, running_var,
+                     save_mean, save_invstd, (double)n_total, C, momentum, eps);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+VF_API int vf_bn_apply(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                       const float* invstd, int64_t npix, int C, int act, float slope) {
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  const BnGeom g = bn_geom(npix, C);
+  hipLaunchKernelGGL(k_bn_apply, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y, gamma, beta, mean, invstd, npix, C, g.cq,
+                     g.rows_per_block, act, slope);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
+                           int64_t npix, int C, float momentum, float eps, int act, float slope) {
+  if (int rc = vf_bn_stats(ctx, x, running_mean, sums, npix, C)) return rc;
+  if (int rc = vf_bn_finalize(ctx, sums, running_mean, running_var, save_mean, save_invstd, npix, C, momentum, eps)) return rc;
+  return vf_bn_apply(ctx, x, y, gamma, beta, save_mean, save_invstd, npix, C, act, slope);
+}
+
+VF_API int vf_bn_eval_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                          const float* running_mean, const float* running_var, int64_t npix, int C, float eps, int act,
+                          float slope) {
+  VF_REQUIRE((size_t)2 * C * sizeof(float) <= ctx->ws_bytes, "workspace too small");
+  float* mean = (float*)ctx->ws;
+  float* invstd = mean + C;
+  hipLaunchKernelGGL(k_bn_eval_coeff, dim3((int)vf_cdiv(C, 256)), dim3(256), 0, ctx->stream, running_mean, running_var, mean,
+                     invstd, C, eps);
+  VF_LAUNCH_CHECK();
+  return vf_bn_apply(ctx, x, y, gamma, beta, mean, invstd, npix, C, act, slope);
+}
+
+VF_API int vf_bn_bwd_stats(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, const float* save_mean,
+                           double* sums, int64_t npix, int C, int act, float slope) {
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "fused activation backward needs the activated output");
+  const BnGeom g = bn_geom(npix, C);
+  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  hipLaunchKernelGGL(k_bn_bwd_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, save_mean, (double*)ctx->ws,
+                     npix, C, g.cq, g.rows_per_block, act, slope);
+  VF_LAUNCH_CHECK();
+  return run_stats(ctx, g, sums, C);
+}
+
+VF_API int vf_bn_bwd_apply(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                           float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
+                           const double* sums, int64_t npix, int64_t n_total, int C, int act, float slope, float pbeta) {
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  const BnGeom g = bn_geom(npix, C);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, gx, ggamma, gbeta, gamma,
+                     save_mean, save_invstd, sums, npix, (double)n_total, C, g.cq, g.rows_per_block, act, slope, pbeta);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+VF_API int vf_bn_bwd(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                     float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
+                     int64_t npix, int C, int act, float slope, float pbeta) {
+  if (int rc = vf_bn_bwd_stats(ctx, x, y_act, gy, save_mean, sums, npix, C, act, slope)) return rc;
+  return vf_bn_bwd_apply(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix, npix, C, act, slope,
+                         pbeta);
+}

@@ -1,0 +1,69 @@
+// vf_common.h — shared host-side plumbing for the gfx950 backend (context, error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/vf_hip.h"
+
+#define VF_API extern "C" __attribute__((visibility("default")))
+
+struct vf_ctx {
+  int device;
+  hipStream_t stream;
+  void* ws;         // caller-owned scratch (split-K slabs, reduction partials)
+  size_t ws_bytes;
+};
+
+void vf_set_error(const char* fmt, ...);
+
+#define VF_CHECK_HIP(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      vf_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return 1;                                                                         \
+    }                                                                                   \
+  } while (0)
+
+#define VF_REQUIRE(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      vf_set_error(__VA_ARGS__);   \
+      return 2;                    \
+    }                              \
+  } while (0)
+
+#define VF_LAUNCH_CHECK() VF_CHECK_HIP(hipGetLastError())
+
+static inline int vf_ilog2(int v) {  // v must be a power of two
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static inline bool vf_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int64_t vf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// fused activation
+__device__ __forceinline__ float vf_act_apply(float v, int act, float slope) {
+  switch (act) {
+    case VF_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case VF_ACT_RELU: return v > 0.f ? v : 0.f;
+    case VF_ACT_TANH: return tanhf(v);
+    case VF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+// derivative factor evaluated from the ACTIVATED value y
+__device__ __forceinline__ float vf_act_grad(float y, float g, int act, float slope) {
+  switch (act) {
+    case VF_ACT_LRELU: return y > 0.f ? g : g * slope;
+    case VF_ACT_RELU: return y > 0.f ? g : 0.f;
+    case VF_ACT_TANH: return g * (1.f - y * y);
+    case VF_ACT_SIGMOID: return g * (1.f - y) * y;
+    default: return g;
+  }
+}

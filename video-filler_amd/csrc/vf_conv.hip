@@ -1,0 +1,817 @@
+// vf_conv.hip — 4x4 convolution / transposed convolution, forward + data-grad + weight-grad, for gfx950.
+//
+// Every pass is an implicit GEMM on the f32-input matrix core (v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-for-bit a k-ordered fmaf chain, so the parity mode and the fast mode are the same code).
+// Activations are NHWC, weights are the reference tensors in channels-last (see include/vf_hip.h), which
+// makes a layer's three passes need only two kernels:
+//
+//   k_igemm  C[m][n] = sum_{tap,c} A(m,tap,c) * Wt(n,tap,c)
+//            - conv forward            (reference: THNN SpatialConvolutionMM_updateOutput, train.lua:89)
+//            - conv data-grad          (transposed conv, 4 output-parity classes, each a 2x2-tap GEMM)
+//            - full-conv forward       (= conv data-grad; THNN SpatialFullConvolution_updateOutput, train.lua:134)
+//            - full-conv data-grad     (= conv forward without bias)
+//            - the 4x4 -> 1x1 bottleneck conv and 1x1 -> 4x4 full-conv (plain GEMMs, weight-bandwidth bound)
+//   k_wgrad  dW[n][tap][c] = sum_p U(p,n) * V(p,tap,c), split over pixels p
+//            - conv / full-conv accGradParameters (the two differ only in which tensor is x and which is gy)
+//
+// Tiles: 256 threads = 4 waves, each wave 64 x {64,32} of 32x32 MFMA tiles, BK = 16, LDS double-buffered,
+// register-staged global->LDS copies (the f32 matrix core needs 64 cycles per 32x32x2, so the MFMA pipe is the
+// bottleneck, not staging).  Grid.z carries output parity and split-K; split-K partial slabs are combined by
+// k_slab_reduce in a fixed order (deterministic; no float atomics).
+#include <algorithm>
+
+#include "vf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+struct IGemm {
+  const float* A;     // gathered activations [B][Hi][Wi][C]
+  const float* Wt;    // weights
+  const float* bias;  // [N] or null
+  float* Y;           // output [B][outH][outW][N]
+  float* slab;        // split-K partials, ksplit x (output-sized) ; null when ksplit == 1
+  int64_t out_elems;  // B*outH*outW*N
+  int M, lgMh, lgMw;  // GEMM rows = B << (lgMh+lgMw), decoded as (b, my, mx)
+  int Hi, Wi, C;
+  int N;
+  int TH, TW;                      // taps walked by the K loop
+  int sy, ty, oy0, sx, tx, ox0;    // iy = my*sy + th*ty + oy0 (+ph in parity mode)
+  int kh0, khs, kw0, kws;          // filter tap (kh, kw) = (kh0 + th*khs, kw0 + tw*kws)
+  int64_t wsN, wsC, wsTap;         // weight offset = n*wsN + (kh*4+kw)*wsTap + c*wsC
+  int outH, outW, osy, ooy0, osx, oox0;  // output pixel = (my*osy + ooy0, mx*osx + oox0)
+  int parity;                      // 1: z&3 = (ph<<1)|pw shifts oy0/ox0/ooy0/oox0 and selects kh0/kw0
+  int ksplit, nk;                  // K steps total and number of splits
+  int vecA, vecB;                  // 16-byte load paths legal
+  int act;
+  float slope;
+};
+
+template <int BM, int BN, int WN, bool BKM>
+__global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
+  constexpr int BK = 16, LDA = 20;
+  constexpr int LDB = BKM ? (BN + 4) : 20;
+  constexpr int NT = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int A_CH = BM / 64;
+  constexpr int B_CH = (BN * 4 + 255) / 256;
+  constexpr int A_SZ = BM * LDA;
+  constexpr int B_SZ = BKM ? BK * LDB : BN * LDB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int z = blockIdx.z;
+  int ph = 0, pw = 0;
+  if (p.parity) {
+    ph = (z >> 1) & 1;
+    pw = z & 1;
+    z >>= 2;
+  }
+  const int ks = z;
+  const int steps = (p.nk + p.ksplit - 1) / p.ksplit;
+  const int kt0 = ks * steps;
+  const int kt1 = min(p.nk, kt0 + steps);
+  const int oy0 = p.oy0 + ph, ox0 = p.ox0 + pw;
+  const int kh0 = p.parity ? (1 - ph) : p.kh0, kw0 = p.parity ? (1 - pw) : p.kw0;
+  const int ooy0 = p.ooy0 + ph, oox0 = p.oox0 + pw;
+  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
+  const int ntaps = p.TH * p.TW;
+  const int Ktot = ntaps * p.C;
+  const int spt = p.vecA ? (p.C >> 4) : 1;  // K steps per tap on the chunked path
+
+  // ---- per-thread A rows (fixed for the whole K loop)
+  int a_iy0[A_CH], a_ix0[A_CH];
+  int64_t a_boff[A_CH];
+  bool a_ok[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int row = (tid + 256 * i) >> 2;
+    const int m = m0 + row;
+    a_ok[i] = m < p.M;
+    const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+    a_iy0[i] = my * p.sy + oy0;
+    a_ix0[i] = mx * p.sx + ox0;
+    a_boff[i] = (int64_t)b * p.Hi * p.Wi * p.C;
+  }
+  const int kq = tid & 3;
+
+  f32x4 ra[A_CH], rb[B_CH];
+
+  auto load_tile = [&](int kt) {
+    // ---------------- A
+    if (p.vecA) {
+      const int tap = kt / spt, c0 = (kt - tap * spt) << 4;
+      const int th = tap / p.TW, tw = tap - th * p.TW;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
+        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *(const f32x4*)(p.A + a_boff[i] + ((int64_t)iy * p.Wi + ix) * p.C + c0 + 4 * kq);
+        ra[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = kt * BK + 4 * kq + j;
+          if (a_ok[i] && k < Ktot) {
+            const int tap = k / p.C, c = k - tap * p.C;
+            const int th = tap / p.TW, tw = tap - th * p.TW;
+            const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
+            if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+              v[j] = p.A[a_boff[i] + ((int64_t)iy * p.Wi + ix) * p.C + c];
+          }
+        }
+        ra[i] = v;
+      }
+    }
+    // ---------------- B
+    if constexpr (!BKM) {
+      // rows n, k contiguous (wsC == 1)
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) {
+        const int id = tid + 256 * i;
+        const int n = n0 + (id >> 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (id < BN * 4 && n < p.N) {
+          if (p.vecA && p.vecB) {
+            const int tap = kt / spt, c0 = (kt - tap * spt) << 4;
+            const int th = tap / p.TW, tw = tap - th * p.TW;
+            const int tapidx = (kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws);
+            v = *(const f32x4*)(p.Wt + (int64_t)n * p.wsN + (int64_t)tapidx * p.wsTap + c0 + 4 * kq);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int k = kt * BK + 4 * kq + j;
+              if (k < Ktot) {
+                const int tap = k / p.C, c = k - tap * p.C;
+                const int th = tap / p.TW, tw = tap - th * p.TW;
+                const int tapidx = (kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws);
+                v[j] = p.Wt[(int64_t)n * p.wsN + (int64_t)tapidx * p.wsTap + (int64_t)c * p.wsC];
+              }
+            }
+          }
+        }
+        rb[i] = v;
+      }
+    } else {
+      // n contiguous (wsN == 1): one float4 covers 4 consecutive n at one k
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) {
+        const int id = tid + 256 * i;
+        const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
+        const int n = n0 + 4 * nq;
+        const int k = kt * BK + kk;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (id < BN * 4 && k < Ktot && n < p.N) {
+          int tap, c;
+          if (p.vecA) {
+            tap = kt / spt;
+            c = ((kt - tap * spt) << 4) + kk;
+          } else {
+            tap = k / p.C;
+            c = k - tap * p.C;
+          }
+          const int th = tap / p.TW, tw = tap - th * p.TW;
+          const int tapidx = (kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws);
+          const float* src = p.Wt + (int64_t)tapidx * p.wsTap + (int64_t)c * p.wsC + n;
+          if (p.vecB) {
+            v = *(const f32x4*)src;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (n + j < p.N) v[j] = src[j];
+          }
+        }
+        rb[i] = v;
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    float* As = smem + buf * (A_SZ + B_SZ);
+    float* Bs = As + A_SZ;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int row = (tid + 256 * i) >> 2;
+      *(f32x4*)(As + row * LDA + 4 * kq) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int id = tid + 256 * i;
+      if (id < BN * 4) {
+        if constexpr (!BKM) {
+          *(f32x4*)(Bs + (id >> 2) * LDB + 4 * kq) = rb[i];
+        } else {
+          const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
+          *(f32x4*)(Bs + kk * LDB + 4 * nq) = rb[i];
+        }
+      }
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tile(kt + 1);
+    const float* As = smem + buf * (A_SZ + B_SZ);
+    const float* Bs = As + A_SZ;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x4 a[2], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(As + (wm + mt * 32 + lr) * LDA + 8 * s + 4 * lh);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (!BKM) {
+          b[nt] = *(const f32x4*)(Bs + (wn + nt * 32 + lr) * LDB + 8 * s + 4 * lh);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[nt][j] = Bs[(8 * s + 4 * lh + j) * LDB + wn + nt * 32 + lr];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
+  const bool fin = p.ksplit == 1;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + row;
+      if (m >= p.M) continue;
+      const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+      const int64_t pix = ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn + nt * 32 + lr;
+        if (n < p.N) {
+          float v = acc[mt][nt][r];
+          if (fin) {
+            if (p.bias) v += p.bias[n];
+            v = vf_act_apply(v, p.act, p.slope);
+          }
+          out[pix * p.N + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// y = act(sum_s slab[s] + bias)  or  dst = beta*dst + sum_s slab[s]  (wgrad)
+__global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ dst, const float* __restrict__ bias,
+                              int64_t total, int N, int ksplit, int act, float slope, float beta) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += slab[(int64_t)k * total + i];
+    if (bias) s += bias[i % N];
+    if (beta != 0.f) s += beta * dst[i];
+    dst[i] = vf_act_apply(s, act, slope);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WGrad {
+  const float* U;   // plain operand at the LOW-res pixel grid: [P][Nu]
+  const float* V;   // gathered operand on the HIGH-res grid: [B][Hv][Wv][Cv]
+  float* dW;        // [Nu][16][Cv]
+  float* slab;
+  int P, lgMh, lgMw;
+  int Nu, Cv, Hv, Wv;
+  int stride, pad;  // iy = my*stride - pad + kh
+  int ksplit, nk;   // nk = ceil(P/16)
+  int vecU, vecV;
+  float beta;
+};
+
+template <int BM>  // BM over n (64 or 128); BN = 128 columns (tap,c)
+__global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
+  constexpr int BN = 128, BK = 16;
+  constexpr int LDU = BM + 4, LDV = BN + 4;
+  constexpr int WN = BM == 128 ? 64 : 32;
+  constexpr int NT = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int U_CH = (BK * BM / 4) / 256;  // 2 (BM=128) or 1 (BM=64)
+  constexpr int V_CH = (BK * BN / 4) / 256;  // 2
+  constexpr int U_SZ = BK * LDU, V_SZ = BK * LDV;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (U_SZ + V_SZ)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
+  const int n0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+  const int ks = blockIdx.z;
+  const int steps = (p.nk + p.ksplit - 1) / p.ksplit;
+  const int kt0 = ks * steps, kt1 = min(p.nk, kt0 + steps);
+  const int Ncols = 16 * p.Cv;
+  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
+
+  // V columns owned by this thread: 4 consecutive columns starting at j0 + 4*cq
+  const int cq = tid & 31;
+  int v_dy[4], v_dx[4], v_c[4];
+  bool v_okc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = j0 + 4 * cq + j;
+    v_okc[j] = col < Ncols;
+    const int tap = v_okc[j] ? col / p.Cv : 0;
+    v_c[j] = v_okc[j] ? col - tap * p.Cv : 0;
+    v_dy[j] = (tap >> 2) - p.pad;
+    v_dx[j] = (tap & 3) - p.pad;
+  }
+  const int uq = tid % (BM / 4), ukk = tid / (BM / 4);  // U: 4 consecutive n at pixel row ukk (+ 256/(BM/4) per chunk)
+
+  f32x4 ru[U_CH], rv[V_CH];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < U_CH; ++i) {
+      const int kk = ukk + i * (1024 / BM);
+      const int pp = kt * BK + kk;
+      const int n = n0 + 4 * uq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pp < p.P && n < p.Nu) {
+        const float* src = p.U + (int64_t)pp * p.Nu + n;
+        if (p.vecU) {
+          v = *(const f32x4*)src;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j < p.Nu) v[j] = src[j];
+        }
+      }
+      ru[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < V_CH; ++i) {
+      const int kk = (tid >> 5) + 8 * i;
+      const int pp = kt * BK + kk;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pp < p.P) {
+        const int mx = pp & (Mw - 1), my = (pp >> p.lgMw) & (Mh - 1), b = pp >> (p.lgMw + p.lgMh);
+        const int64_t boff = (int64_t)b * p.Hv * p.Wv * p.Cv;
+        if (p.vecV) {
+          const int iy = my * p.stride + v_dy[0], ix = mx * p.stride + v_dx[0];
+          if (v_okc[0] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv)
+            v = *(const f32x4*)(p.V + boff + ((int64_t)iy * p.Wv + ix) * p.Cv + v_c[0]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int iy = my * p.stride + v_dy[j], ix = mx * p.stride + v_dx[j];
+            if (v_okc[j] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv)
+              v[j] = p.V[boff + ((int64_t)iy * p.Wv + ix) * p.Cv + v_c[j]];
+          }
+        }
+      }
+      rv[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Us = smem + buf * (U_SZ + V_SZ);
+    float* Vs = Us + U_SZ;
+#pragma unroll
+    for (int i = 0; i < U_CH; ++i) *(f32x4*)(Us + (ukk + i * (1024 / BM)) * LDU + 4 * uq) = ru[i];
+#pragma unroll
+    for (int i = 0; i < V_CH; ++i) *(f32x4*)(Vs + ((tid >> 5) + 8 * i) * LDV + 4 * cq) = rv[i];
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  const int lr = lane & 31, lh = lane >> 5;
+  constexpr int MT_VALID = BM == 128 ? 2 : 2;  // BM=64: waves are 1x4, each wave still 64 rows
+
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tile(kt + 1);
+    const float* Us = smem + buf * (U_SZ + V_SZ);
+    const float* Vs = Us + U_SZ;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float a[2][4], b[NT][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 8 * s + 4 * lh + j;
+#pragma unroll
+        for (int mt = 0; mt < MT_VALID; ++mt) a[mt][j] = Us[k * LDU + wm + mt * 32 + lr];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt][j] = Vs[k * LDV + wn + nt * 32 + lr];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT_VALID; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int64_t total = (int64_t)p.Nu * Ncols;
+  float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * total : p.dW;
+#pragma unroll
+  for (int mt = 0; mt < MT_VALID; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n >= p.Nu) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = j0 + wn + nt * 32 + lr;
+        if (col < Ncols) {
+          const int64_t idx = (int64_t)n * Ncols + col;
+          float v = acc[mt][nt][r];
+          if (p.ksplit == 1 && p.beta != 0.f) v += p.beta * out[idx];
+          out[idx] = v;
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cout == 1, 4x4 stride-1 conv on a 4x4 map (netD's last layer, train.lua:195): dot products.
+__global__ __launch_bounds__(256) void k_dot_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, float* __restrict__ y, int K, int act,
+                                                 float slope) {
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += x[(int64_t)b * K + k] * w[k];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) y[b] = vf_act_apply(red[0] + (bias ? bias[0] : 0.f), act, slope);
+}
+__global__ void k_dot_bwd_data(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int B,
+                               int K) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < (int64_t)B * K) gx[i] = gy[i / K] * w[i % K];
+}
+__global__ void k_dot_bwd_weight(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gw,
+                                 float* __restrict__ gb, int B, int K, float beta) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += gy[b] * x[(int64_t)b * K + k];
+    gw[k] = (beta != 0.f ? beta * gw[k] : 0.f) + s;
+  }
+  if (gb && k == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += gy[b];
+    gb[0] = (beta != 0.f ? beta * gb[0] : 0.f) + s;
+  }
+}
+
+// bias gradient: gb[c] = beta*gb[c] + sum_p g[p][c]   (THNN accGradParameters' gradBias; fp32 like THNN)
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ g, double* __restrict__ part, int64_t P,
+                                                        int C, int rows_per_block) {
+  // grid.x = row slabs, grid.y = column chunks of 64; thread (tx = col, ty = row lane)
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(P, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < C)
+    for (int64_t r = r0 + ty; r < r1; r += 4) s += g[r * C + c];
+  __shared__ float red[4][64];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C)
+    part[(int64_t)blockIdx.x * C + c] = (double)red[0][tx] + (double)red[1][tx] + (double)red[2][tx] + (double)red[3][tx];
+}
+__global__ void k_colsum_final(const double* __restrict__ part, float* __restrict__ gb, int nslab, int C, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * C + c];
+  gb[c] = (beta != 0.f ? beta * gb[c] : 0.f) + (float)s;
+}
+
+// ================================================================================================ host
+static int launch_igemm(vf_ctx* ctx, IGemm& g) {
+  const int zpar = g.parity ? 4 : 1;
+  // tile selection
+  int BM, BN;
+  if (g.N <= 32) {
+    BM = 256;
+    BN = 32;
+  } else if (g.N <= 64) {
+    BM = 128;
+    BN = 64;
+  } else if (g.M <= 64) {
+    BM = 64;
+    BN = 128;
+  } else {
+    BM = 128;
+    BN = 128;
+  }
+  const int gm = (int)vf_cdiv(g.M, BM), gn = (int)vf_cdiv(g.N, BN);
+  const int Ktot = g.TH * g.TW * g.C;
+  g.nk = g.vecA ? g.TH * g.TW * (g.C / 16) : (int)vf_cdiv(Ktot, 16);
+  // split-K: fill >= 2 blocks per CU when the K loop is long enough to share
+  int64_t blocks = (int64_t)gm * gn * zpar;
+  int ksplit = 1;
+  if (blocks < 512 && g.nk >= 16) {
+    ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(512, blocks));
+    const size_t slab_bytes = (size_t)g.out_elems * sizeof(float);
+    while (ksplit > 1 && (size_t)ksplit * slab_bytes > ctx->ws_bytes) --ksplit;
+    if (ksplit < 1) ksplit = 1;
+    // avoid empty trailing splits
+    const int steps = (int)vf_cdiv(g.nk, ksplit);
+    ksplit = (int)vf_cdiv(g.nk, steps);
+  }
+  g.ksplit = ksplit;
+  g.slab = ksplit > 1 ? (float*)ctx->ws : nullptr;
+  dim3 grid(gm, gn, zpar * ksplit), block(256);
+  const bool bkm = g.wsN == 1 && g.wsC != 1;
+#define VF_IGEMM(BM_, BN_, WN_)                                                             \
+  do {                                                                                      \
+    if (bkm)                                                                                \
+      hipLaunchKernelGGL((k_igemm<BM_, BN_, WN_, true>), grid, block, 0, ctx->stream, g);   \
+    else                                                                                    \
+      hipLaunchKernelGGL((k_igemm<BM_, BN_, WN_, false>), grid, block, 0, ctx->stream, g);  \
+  } while (0)
+  if (BM == 256)
+    VF_IGEMM(256, 32, 32);
+  else if (BM == 128 && BN == 64)
+    VF_IGEMM(128, 64, 32);
+  else if (BM == 64)
+    VF_IGEMM(64, 128, 32);
+  else
+    VF_IGEMM(128, 128, 64);
+#undef VF_IGEMM
+  VF_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    const int64_t total = g.out_elems;
+    const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, g.slab, g.Y, g.bias, total, g.N, ksplit,
+                       g.act, g.slope, 0.f);
+    VF_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int check_conv_args(int B, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+  VF_REQUIRE(k == 4, "only 4x4 kernels are built by the reference (got k=%d)", k);
+  VF_REQUIRE((stride == 2 && pad == 1) || (stride == 1 && pad == 0), "unsupported stride/pad %d/%d", stride, pad);
+  VF_REQUIRE(B > 0 && Cin > 0 && Cout > 0, "bad sizes B=%d Cin=%d Cout=%d", B, Cin, Cout);
+  VF_REQUIRE(vf_is_pow2(H) && vf_is_pow2(W), "spatial sizes must be powers of two (got %dx%d)", H, W);
+  if (stride == 1) VF_REQUIRE(H >= 4 && W >= 4, "4x4 stride-1 conv needs H,W >= 4");
+  if (stride == 2) VF_REQUIRE(H >= 2 && W >= 2, "stride-2 conv needs H,W >= 2");
+  return 0;
+}
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Generic "conv-like" pass: Y[b,oy,ox,n] = sum_{kh,kw,c} A[b, oy*s-pad+kh, ox*s-pad+kw, c] * Wt(n,kh,kw,c)
+// (conv forward: A = x, n = Cout, weights [n][kh][kw][c];  full-conv data-grad: A = gy, n = Cin_full,
+//  weights [n][kh][kw][c] as well — same physical layout by construction.)
+static int conv_like_fwd(vf_ctx* ctx, const float* A, const float* w, const float* bias, float* Y, int B, int Hi, int Wi,
+                         int C, int N, int stride, int pad, int act, float slope) {
+  const int Ho = (Hi + 2 * pad - 4) / stride + 1, Wo = (Wi + 2 * pad - 4) / stride + 1;
+  VF_REQUIRE(vf_is_pow2(Ho) && vf_is_pow2(Wo), "output spatial sizes must be powers of two");
+  if (N == 1 && stride == 1 && Hi == 4 && Wi == 4) {
+    hipLaunchKernelGGL(k_dot_fwd, dim3(B), dim3(256), 0, ctx->stream, A, w, bias, Y, 16 * C, act, slope);
+    VF_LAUNCH_CHECK();
+    return 0;
+  }
+  IGemm g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.Wt = w; g.bias = bias; g.Y = Y;
+  g.lgMh = vf_ilog2(Ho); g.lgMw = vf_ilog2(Wo);
+  g.M = B * Ho * Wo;
+  g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
+  g.TH = 4; g.TW = 4;
+  g.sy = stride; g.ty = 1; g.oy0 = -pad; g.sx = stride; g.tx = 1; g.ox0 = -pad;
+  g.kh0 = 0; g.khs = 1; g.kw0 = 0; g.kws = 1;
+  g.wsN = 16 * (int64_t)C; g.wsC = 1; g.wsTap = C;
+  g.outH = Ho; g.outW = Wo; g.osy = 1; g.osx = 1;
+  g.out_elems = (int64_t)g.M * N;
+  g.vecA = (C % 16 == 0) && aligned16(A);
+  g.vecB = (C % 16 == 0) && aligned16(w);
+  g.act = act; g.slope = slope;
+  return launch_igemm(ctx, g);
+}
+
+// Generic "transposed" pass: Y[b,oh,ow,n] = sum_{kh,kw,c : oh = 2i-1+kh ...} A[b,i,j,c] * Wt[c][kh][kw][n]
+// (conv data-grad: A = gy, c = Cout, n = Cin;  full-conv forward: A = x, c = Cin_full, n = Cout_full.)
+static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const float* bias, float* Y, int B, int Hi, int Wi,
+                         int C, int N, int stride, int pad, int act, float slope) {
+  IGemm g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.Wt = w; g.bias = bias; g.Y = Y;
+  g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
+  g.wsN = 1; g.wsC = 16 * (int64_t)N; g.wsTap = N;
+  g.act = act; g.slope = slope;
+  g.vecA = (C % 16 == 0) && aligned16(A);
+  g.vecB = (N % 4 == 0) && aligned16(w);
+  if (stride == 2) {
+    // output (2*Hi) x (2*Wi); per parity class a 2x2-tap GEMM over the low-res grid
+    g.lgMh = vf_ilog2(Hi); g.lgMw = vf_ilog2(Wi);
+    g.M = B * Hi * Wi;
+    g.TH = 2; g.TW = 2;
+    g.sy = 1; g.ty = -1; g.oy0 = 0; g.sx = 1; g.tx = -1; g.ox0 = 0;  // iy = my + ph - th
+    g.khs = 2; g.kws = 2;                                            // kh = (1-ph) + 2*th
+    g.outH = 2 * Hi; g.outW = 2 * Wi; g.osy = 2; g.osx = 2;
+    g.parity = 1;
+    g.out_elems = (int64_t)B * g.outH * g.outW * N;
+  } else {
+    // stride 1, pad 0, low-res 1x1 -> 4x4: plain GEMM with N' = (kh,kw,n)
+    VF_REQUIRE(Hi == 1 && Wi == 1, "stride-1 transposed pass is built for the 1x1 bottleneck only (got %dx%d)", Hi, Wi);
+    g.lgMh = 0; g.lgMw = 0;
+    g.M = B;
+    g.TH = 1; g.TW = 1;
+    g.sy = 1; g.ty = 1; g.sx = 1; g.tx = 1;
+    g.N = 16 * N;                 // columns (kh,kw,n) are contiguous in [c][kh][kw][n]
+    g.wsC = 16 * (int64_t)N; g.wsTap = 0;
+    g.outH = 1; g.outW = 1; g.osy = 1; g.osx = 1;
+    g.out_elems = (int64_t)B * 16 * N;
+    g.vecB = ((16 * N) % 4 == 0) && aligned16(w);
+    if (bias) {
+      // bias is per n, columns are (tap,n): handled by the reduce/epilogue through i % N only when N' == N.
+      // The reference always runs with zero conv biases (train.lua:279-280); add it in a second pass.
+    }
+  }
+  const float* real_bias = bias;
+  int real_act = act;
+  if (stride == 1 && bias) {  // defer bias+act to a pointwise pass (bias index = col % N)
+    g.bias = nullptr;
+    g.act = VF_ACT_NONE;
+  }
+  int rc = launch_igemm(ctx, g);
+  if (rc) return rc;
+  if (stride == 1 && real_bias) {
+    const int64_t total = (int64_t)B * 16 * N;
+    const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, Y, Y, real_bias, total, N, 0, real_act, slope,
+                       1.f);
+    VF_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// dW[n][kh][kw][c] = beta*dW + sum_p U[p][n] * V[b, my*s-pad+kh, mx*s-pad+kw, c]
+static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, int Hl, int Wl, int Nu, int Hv, int Wv,
+                 int Cv, int stride, int pad, float beta) {
+  WGrad g;
+  memset(&g, 0, sizeof(g));
+  g.U = U; g.V = V; g.dW = dW;
+  g.P = B * Hl * Wl;
+  g.lgMh = vf_ilog2(Hl); g.lgMw = vf_ilog2(Wl);
+  g.Nu = Nu; g.Cv = Cv; g.Hv = Hv; g.Wv = Wv;
+  g.stride = stride; g.pad = pad;
+  g.nk = (int)vf_cdiv(g.P, 16);
+  g.vecU = (Nu % 4 == 0) && aligned16(U);
+  g.vecV = (Cv % 4 == 0) && aligned16(V);
+  g.beta = beta;
+  const int BM = Nu > 64 ? 128 : 64;
+  const int gy = (int)vf_cdiv(Nu, BM), gx = (int)vf_cdiv(16 * (int64_t)Cv, 128);
+  const int64_t blocks = (int64_t)gx * gy;
+  const int64_t total = (int64_t)Nu * 16 * Cv;
+  int ksplit = 1;
+  if (blocks < 512 && g.nk >= 16) {
+    ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(512, blocks));
+    while (ksplit > 1 && (size_t)ksplit * total * sizeof(float) > ctx->ws_bytes) --ksplit;
+    if (ksplit < 1) ksplit = 1;
+    const int steps = (int)vf_cdiv(g.nk, ksplit);
+    ksplit = (int)vf_cdiv(g.nk, steps);
+  }
+  g.ksplit = ksplit;
+  g.slab = ksplit > 1 ? (float*)ctx->ws : nullptr;
+  dim3 grid(gx, gy, ksplit), block(256);
+  if (BM == 128)
+    hipLaunchKernelGGL((k_wgrad<128>), grid, block, 0, ctx->stream, g);
+  else
+    hipLaunchKernelGGL((k_wgrad<64>), grid, block, 0, ctx->stream, g);
+  VF_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, g.slab, dW, (const float*)nullptr, total, 1,
+                       ksplit, (int)VF_ACT_NONE, 0.f, beta);
+    VF_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int bias_grad(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C, float beta) {
+  const int rows_per_block = 256;
+  int nslab = (int)vf_cdiv(P, rows_per_block);
+  VF_REQUIRE((size_t)nslab * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for bias-grad partials");
+  double* part = (double*)ctx->ws;
+  hipLaunchKernelGGL(k_colsum_partial, dim3(nslab, (int)vf_cdiv(C, 64)), dim3(256), 0, ctx->stream, g, part, P, C,
+                     rows_per_block);
+  VF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_final, dim3((int)vf_cdiv(C, 256)), dim3(256), 0, ctx->stream, (const double*)part, gb, nslab,
+                     C, beta);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+VF_API int vf_conv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                         int Cin, int Cout, int k, int stride, int pad, int act, float slope) {
+  if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
+  return conv_like_fwd(ctx, x, w, bias, y, B, H, W, Cin, Cout, stride, pad, act, slope);
+}
+
+VF_API int vf_conv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx, int B, int H, int W, int Cin,
+                              int Cout, int k, int stride, int pad) {
+  if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
+  const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
+  if (stride == 1) {
+    VF_REQUIRE(H == 4 && W == 4, "stride-1 conv data-grad is built for the 4x4 bottleneck input only");
+    if (Cout == 1) {
+      const int64_t n = (int64_t)B * 16 * Cin;
+      hipLaunchKernelGGL(k_dot_bwd_data, dim3((int)vf_cdiv(n, 256)), dim3(256), 0, ctx->stream, gy, w, gx, B, 16 * Cin);
+      VF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  return conv_like_bwd(ctx, gy, w, nullptr, gx, B, Ho, Wo, Cout, Cin, stride, pad, VF_ACT_NONE, 0.f);
+}
+
+VF_API int vf_conv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W,
+                                int Cin, int Cout, int k, int stride, int pad, float beta) {
+  if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
+  const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
+  if (Cout == 1 && stride == 1 && H == 4 && W == 4) {
+    hipLaunchKernelGGL(k_dot_bwd_weight, dim3((int)vf_cdiv(16 * Cin, 256)), dim3(256), 0, ctx->stream, x, gy, gw, gb, B,
+                       16 * Cin, beta);
+    VF_LAUNCH_CHECK();
+    return 0;
+  }
+  if (int rc = wgrad(ctx, gy, x, gw, B, Ho, Wo, Cout, H, W, Cin, stride, pad, beta)) return rc;
+  if (gb) return bias_grad(ctx, gy, gb, (int64_t)B * Ho * Wo, Cout, beta);
+  return 0;
+}
+
+VF_API int vf_deconv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                           int Cin, int Cout, int k, int stride, int pad, int act, float slope) {
+  VF_REQUIRE(k == 4 && ((stride == 2 && pad == 1) || (stride == 1 && pad == 0)), "unsupported full-conv shape");
+  VF_REQUIRE(vf_is_pow2(H) && vf_is_pow2(W), "spatial sizes must be powers of two");
+  return conv_like_bwd(ctx, x, w, bias, y, B, H, W, Cin, Cout, stride, pad, act, slope);
+}
+
+VF_API int vf_deconv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx, int B, int H, int W, int Cin,
+                                int Cout, int k, int stride, int pad) {
+  VF_REQUIRE(k == 4 && ((stride == 2 && pad == 1) || (stride == 1 && pad == 0)), "unsupported full-conv shape");
+  const int Ho = (H - 1) * stride - 2 * pad + 4, Wo = (W - 1) * stride - 2 * pad + 4;
+  VF_REQUIRE(vf_is_pow2(H) && vf_is_pow2(W), "spatial sizes must be powers of two");
+  // conv of gy (Ho x Wo, Cout channels) with weights [Cin][kh][kw][Cout] -> gx (H x W, Cin channels)
+  return conv_like_fwd(ctx, gy, w, nullptr, gx, B, Ho, Wo, Cout, Cin, stride, pad, VF_ACT_NONE, 0.f);
+}
+
+VF_API int vf_deconv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W,
+                                  int Cin, int Cout, int k, int stride, int pad, float beta) {
+  VF_REQUIRE(k == 4 && ((stride == 2 && pad == 1) || (stride == 1 && pad == 0)), "unsupported full-conv shape");
+  VF_REQUIRE(vf_is_pow2(H) && vf_is_pow2(W), "spatial sizes must be powers of two");
+  const int Ho = (H - 1) * stride - 2 * pad + 4, Wo = (W - 1) * stride - 2 * pad + 4;
+  // gw[ci][kh][kw][co] = sum_{b,i,j} x[b,i,j,ci] * gy[b, i*s-pad+kh, j*s-pad+kw, co]
+  if (int rc = wgrad(ctx, x, gy, gw, B, H, W, Cin, Ho, Wo, Cout, stride, pad, beta)) return rc;
+  if (gb) return bias_grad(ctx, gy, gb, (int64_t)B * Ho * Wo, Cout, beta);
+  return 0;
+}

@@ -1,0 +1,417 @@
+// vf_core.hip — context, memory, layout conversion, pointwise modules, criteria and the fused Adam step.
+// Everything here is HBM-bound byte work: 16-byte accesses, grid-stride loops capped at ~2048 blocks.
+#include <algorithm>
+#include <cmath>
+
+#include "vf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ errors / ctx
+static thread_local char g_err[1024] = "";
+
+void vf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+VF_API const char* vf_last_error(void) { return g_err; }
+VF_API int vf_version(void) { return 100; }
+
+VF_API int vf_ctx_create(vf_ctx** out, int device, void* stream) {
+  VF_REQUIRE(out != nullptr, "vf_ctx_create: out is NULL");
+  int ndev = 0;
+  VF_CHECK_HIP(hipGetDeviceCount(&ndev));
+  VF_REQUIRE(ndev > 0, "no HIP device visible: the gfx950 backend has no CPU fallback");
+  VF_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+  VF_CHECK_HIP(hipSetDevice(device));
+  vf_ctx* c = new vf_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  c->ws = nullptr;
+  c->ws_bytes = 0;
+  *out = c;
+  return 0;
+}
+VF_API int vf_ctx_destroy(vf_ctx* ctx) {
+  delete ctx;
+  return 0;
+}
+VF_API int vf_ctx_set_stream(vf_ctx* ctx, void* stream) {
+  ctx->stream = (hipStream_t)stream;
+  return 0;
+}
+VF_API int vf_ctx_set_workspace(vf_ctx* ctx, void* ptr, size_t bytes) {
+  ctx->ws = ptr;
+  ctx->ws_bytes = bytes;
+  return 0;
+}
+VF_API size_t vf_workspace_bytes_hint(void) { return (size_t)256 << 20; }
+VF_API int vf_stream_synchronize(vf_ctx* ctx) {
+  VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+VF_API int vf_malloc(void** out, size_t bytes) {
+  VF_CHECK_HIP(hipMalloc(out, bytes));
+  return 0;
+}
+VF_API int vf_free(void* ptr) {
+  VF_CHECK_HIP(hipFree(ptr));
+  return 0;
+}
+VF_API int vf_memcpy_h2d(vf_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  VF_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+VF_API int vf_memcpy_d2h(vf_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  VF_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+VF_API int vf_zero(vf_ctx* ctx, void* ptr, size_t bytes) {
+  VF_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, ctx->stream));
+  return 0;
+}
+
+static inline int grid_for(int64_t n, int per_thread = 4) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(vf_cdiv(n, 256 * (int64_t)per_thread), 2048));
+}
+
+__global__ void k_zero_segments(float* __restrict__ base, const int64_t* __restrict__ offs, const int64_t* __restrict__ lens) {
+  const int64_t off = offs[blockIdx.x], len = lens[blockIdx.x];
+  for (int64_t i = threadIdx.x; i < len; i += blockDim.x) base[off + i] = 0.f;
+}
+VF_API int vf_zero_segments(vf_ctx* ctx, float* base, const int64_t* offs, const int64_t* lens, int nseg) {
+  if (nseg <= 0) return 0;
+  hipLaunchKernelGGL(k_zero_segments, dim3(nseg), dim3(256), 0, ctx->stream, base, offs, lens);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ layout
+// per image: src [R][S] -> dst [S][R]   (NCHW->NHWC: R = C, S = H*W ; NHWC->NCHW: R = H*W, S = C)
+__global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int R, int S) {
+  __shared__ float tile[32][33];
+  const int64_t img = (int64_t)blockIdx.z * R * S;
+  const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = r0 + j, s = s0 + threadIdx.x;
+    if (r < R && s < S) tile[j][threadIdx.x] = src[img + (int64_t)r * S + s];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int s = s0 + j, r = r0 + threadIdx.x;
+    if (r < R && s < S) dst[img + (int64_t)s * R + r] = tile[threadIdx.x][j];
+  }
+}
+VF_API int vf_nchw_to_nhwc(vf_ctx* ctx, const float* src, float* dst, int B, int C, int H, int W) {
+  const int S = H * W;
+  hipLaunchKernelGGL(k_transpose, dim3((int)vf_cdiv(S, 32), (int)vf_cdiv(C, 32), B), dim3(32, 8), 0, ctx->stream, src, dst, C, S);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+VF_API int vf_nhwc_to_nchw(vf_ctx* ctx, const float* src, float* dst, int B, int C, int H, int W) {
+  const int S = H * W;
+  hipLaunchKernelGGL(k_transpose, dim3((int)vf_cdiv(C, 32), (int)vf_cdiv(S, 32), B), dim3(32, 8), 0, ctx->stream, src, dst, S, C);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise
+enum { OP_ACT_FWD, OP_ACT_BWD, OP_AXPBY, OP_CMUL, OP_SCALE_SHIFT, OP_COMPOSE, OP_MSE_BWD };
+
+template <int OP>
+__global__ void k_pointwise(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                            float* __restrict__ out, int64_t n, float f0, float f1, int act) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  auto op = [&](float av, float bv, float cv, float ov) -> float {
+    if constexpr (OP == OP_ACT_FWD) return vf_act_apply(av, act, f0);
+    if constexpr (OP == OP_ACT_BWD) return vf_act_grad(av, bv, act, f0);        // a = y, b = gy
+    if constexpr (OP == OP_AXPBY) return f0 * av + f1 * ov;                       // out = f0*a + f1*out
+    if constexpr (OP == OP_CMUL) return ov * av;
+    if constexpr (OP == OP_SCALE_SHIFT) return ov * f0 + f1;
+    if constexpr (OP == OP_COMPOSE) return cv != 0.f ? bv : av;                   // a = real, b = fake, c = mask
+    if constexpr (OP == OP_MSE_BWD) return f0 * (av - bv);
+    return 0.f;
+  };
+  constexpr bool RA = OP != OP_SCALE_SHIFT;
+  constexpr bool RB = OP == OP_ACT_BWD || OP == OP_COMPOSE || OP == OP_MSE_BWD;
+  constexpr bool RC = OP == OP_COMPOSE;
+  constexpr bool RO = OP == OP_AXPBY || OP == OP_CMUL || OP == OP_SCALE_SHIFT;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 av = {0, 0, 0, 0}, bv = av, cv = av, ov = av;
+    if (RA) av = ((const f32x4*)a)[i];
+    if (RB) bv = ((const f32x4*)b)[i];
+    if (RC) cv = ((const f32x4*)c)[i];
+    if (RO) ov = ((const f32x4*)out)[i];
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = op(av[e], bv[e], cv[e], ov[e]);
+    ((f32x4*)out)[i] = r;
+  }
+  // tail
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = op(RA ? a[i] : 0.f, RB ? b[i] : 0.f, RC ? c[i] : 0.f, RO ? out[i] : 0.f);
+}
+
+template <int OP>
+static int launch_pw(vf_ctx* ctx, const float* a, const float* b, const float* c, float* out, int64_t n, float f0, float f1,
+                     int act) {
+  if (n <= 0) return 0;
+  VF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0,
+             "pointwise operands must be 16-byte aligned");
+  hipLaunchKernelGGL((k_pointwise<OP>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, a, b, c, out, n, f0, f1, act);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+VF_API int vf_act_fwd(vf_ctx* ctx, const float* x, float* y, int64_t n, int act, float slope) {
+  return launch_pw<OP_ACT_FWD>(ctx, x, nullptr, nullptr, y, n, slope, 0.f, act);
+}
+VF_API int vf_act_bwd(vf_ctx* ctx, const float* y, const float* gy, float* gx, int64_t n, int act, float slope) {
+  return launch_pw<OP_ACT_BWD>(ctx, y, gy, nullptr, gx, n, slope, 0.f, act);
+}
+VF_API int vf_axpby(vf_ctx* ctx, float a, const float* x, float b, float* y, int64_t n) {
+  return launch_pw<OP_AXPBY>(ctx, x, nullptr, nullptr, y, n, a, b, 0);
+}
+VF_API int vf_cmul(vf_ctx* ctx, const float* x, float* y, int64_t n) {
+  return launch_pw<OP_CMUL>(ctx, x, nullptr, nullptr, y, n, 0.f, 0.f, 0);
+}
+VF_API int vf_scale_shift(vf_ctx* ctx, float* y, float a, float b, int64_t n) {
+  return launch_pw<OP_SCALE_SHIFT>(ctx, nullptr, nullptr, nullptr, y, n, a, b, 0);
+}
+VF_API int vf_masked_compose(vf_ctx* ctx, float* out, const float* real, const float* fake, const float* mask, int64_t n) {
+  return launch_pw<OP_COMPOSE>(ctx, real, fake, mask, out, n, 0.f, 0.f, 0);
+}
+VF_API int vf_mse_bwd(vf_ctx* ctx, const float* x, const float* t, float* gx, int64_t n) {
+  return launch_pw<OP_MSE_BWD>(ctx, x, t, nullptr, gx, n, 2.f / (float)n, 0.f, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ criteria
+__device__ __forceinline__ void block_add_double(double v, double* dst) {
+  __shared__ double red[256];
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(dst, red[0]);
+}
+
+// nn.BCECriterion: single block (n = batch size)
+__global__ __launch_bounds__(256) void k_bce_fwd(const float* __restrict__ x, float label, int n, double* __restrict__ loss) {
+  const double EPS = 1e-12;
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double xv = x[i], t = label;
+    s -= log(xv + EPS) * t + log(1. - xv + EPS) * (1. - t);
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = red[0] / (double)n;
+}
+__global__ void k_bce_bwd(const float* __restrict__ x, float label, float* __restrict__ gx, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double EPS = 1e-12, xv = x[i], t = label;
+  gx[i] = (float)(-(1.0 / (double)n) * (t - xv) / ((1. - xv + EPS) * (xv + EPS)));
+}
+VF_API int vf_bce_fwd(vf_ctx* ctx, const float* x, float label, int n, double* loss) {
+  hipLaunchKernelGGL(k_bce_fwd, dim3(1), dim3(256), 0, ctx->stream, x, label, n, loss);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+VF_API int vf_bce_bwd(vf_ctx* ctx, const float* x, float label, float* gx, int n) {
+  hipLaunchKernelGGL(k_bce_bwd, dim3((int)vf_cdiv(n, 256)), dim3(256), 0, ctx->stream, x, label, gx, n);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// sum((x-t)^2)/n -> loss (double atomics across blocks; order only perturbs the 16th digit)
+__global__ __launch_bounds__(256) void k_mse_fwd(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
+                                                 double inv_n, double* __restrict__ loss) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, n4 = n >> 2;
+  float s = 0.f;
+  double sd = 0;
+  int cnt = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 d = ((const f32x4*)x)[i] - ((const f32x4*)t)[i];
+    s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    if (++cnt == 16) {
+      sd += (double)s;
+      s = 0.f;
+      cnt = 0;
+    }
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = x[i] - t[i];
+    s += d * d;
+  }
+  sd += (double)s;
+  block_add_double(sd * inv_n, loss);
+}
+VF_API int vf_mse_fwd(vf_ctx* ctx, const float* x, const float* t, int64_t n, double* loss) {
+  VF_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_mse_fwd, dim3(grid_for(n, 16)), dim3(256), 0, ctx->stream, x, t, n, 1.0 / (double)n, loss);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// fused: loss = mean((x-t)^2) ; df_dg = alpha*df_dg + (2/n)(x-t)*wgt
+__global__ __launch_bounds__(256) void k_recon_grad_mix(float* __restrict__ dfdg, const float* __restrict__ x,
+                                                        const float* __restrict__ t, const float* __restrict__ mask,
+                                                        float alpha, float c0, float c1, int band, int HW, int C, int64_t n,
+                                                        float two_over_n, double inv_n, double* __restrict__ loss) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double sd = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = x[i] - t[i];
+    sd += (double)(d * d);
+    float w;
+    if (mask) {
+      w = c0 + c1 * mask[i];
+    } else if (band > 0) {
+      const int64_t pix = i / C;
+      const int wcol = (int)(pix % HW), hrow = (int)((pix / HW) % HW);
+      const bool inside = hrow >= band && hrow < HW - band && wcol >= band && wcol < HW - band;
+      w = inside ? c0 : c0 + c1;
+    } else {
+      w = c0;
+    }
+    dfdg[i] = alpha * dfdg[i] + (two_over_n * d) * w;
+  }
+  block_add_double(sd * inv_n, loss);
+}
+VF_API int vf_recon_grad_mix(vf_ctx* ctx, float* df_dg, const float* x, const float* t, const float* mask, float alpha,
+                             float c0, float c1, int band, int HW, int C, int64_t n, double* loss) {
+  VF_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_recon_grad_mix, dim3(grid_for(n, 8)), dim3(256), 0, ctx->stream, df_dg, x, t, mask, alpha, c0, c1, band,
+                     HW, C, n, 2.f / (float)n, 1.0 / (double)n, loss);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// nn.GDLCriterion(1) forward on NHWC, with the reference's flattened pairing:
+// per (b,c) plane, element k of the H x (W-1) crops pairs with element k of the (H-1) x W crops.
+__global__ __launch_bounds__(256) void k_gdl_fwd(const float* __restrict__ yh, const float* __restrict__ y, int B, int H, int W,
+                                                 int C, double inv_cnt, double* __restrict__ loss) {
+  const int64_t m = (int64_t)(H - 1) * W;
+  const int64_t total = (int64_t)B * m * C;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double sd = 0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int c = (int)(e % C);
+    const int64_t k = (e / C) % m;
+    const int64_t b = e / (C * m);
+    const int64_t base = b * H * W;
+    const int64_t r = k / (W - 1), cc = k % (W - 1);
+    const int64_t i2 = (base + r * W + cc) * C + c;       // X[.., :, 0:W-1] flattened
+    const int64_t j2 = i2 + C;                             // X[.., :, 1:W]
+    const int64_t i1 = (base + k) * C + c;                 // X[.., 0:H-1, :] flattened
+    const int64_t j1 = (base + W + k) * C + c;             // X[.., 1:H, :]
+    const float t1 = fabsf(y[i2] - y[i1]), t2 = fabsf(yh[i2] - yh[i1]);
+    const float t3 = fabsf(y[j2] - y[j1]), t4 = fabsf(yh[j2] - yh[j1]);
+    sd += (double)fabsf(t1 - t2) + (double)fabsf(t3 - t4);
+  }
+  block_add_double(sd * inv_cnt, loss);
+}
+VF_API int vf_gdl_fwd(vf_ctx* ctx, const float* yhat, const float* y, int B, int H, int W, int C, double* loss) {
+  VF_REQUIRE(H == W, "GDLCriterion needs square maps (the reference's CSubTable pairs H x (W-1) with (H-1) x W)");
+  VF_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+  const int64_t cnt = (int64_t)B * C * (H - 1) * W;
+  hipLaunchKernelGGL(k_gdl_fwd, dim3(grid_for(cnt, 8)), dim3(256), 0, ctx->stream, yhat, y, B, H, W, C, 1.0 / (double)cnt, loss);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void k_masked_mse(const float* __restrict__ x, const float* __restrict__ xh,
+                                                    const uint8_t* __restrict__ mask, float w, float* __restrict__ gx,
+                                                    int64_t n, double inv_n, double* __restrict__ loss) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double sd = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double wm = (1.0 - (double)w) * mask[i] + (double)w;
+    const double d = (double)x[i] - (double)xh[i];
+    const double v = wm * d * d;
+    if (gx) gx[i] = (float)((v >= 0 ? 1.0 : -1.0) * inv_n * wm * 2.0 * d);
+    sd += fabs(v);
+  }
+  if (loss) block_add_double(sd * inv_n, loss);
+}
+VF_API int vf_masked_mse_fwd(vf_ctx* ctx, const float* x, const float* xhat, const uint8_t* mask, float w, int64_t n,
+                             double* loss) {
+  VF_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_masked_mse, dim3(grid_for(n, 8)), dim3(256), 0, ctx->stream, x, xhat, mask, w, (float*)nullptr, n,
+                     1.0 / (double)n, loss);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+VF_API int vf_masked_mse_bwd(vf_ctx* ctx, const float* x, const float* xhat, const uint8_t* mask, float w, float* gx,
+                             int64_t n) {
+  hipLaunchKernelGGL(k_masked_mse, dim3(grid_for(n, 8)), dim3(256), 0, ctx->stream, x, xhat, mask, w, gx, n, 1.0 / (double)n,
+                     (double*)nullptr);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ optim.adam
+// state[0] = t (int32), state[1] = bit pattern of the fp32 step size lr*sqrt(1-b2^t)/(1-b1^t)
+__global__ void k_adam_prep(int32_t* state, double lr, double b1, double b2) {
+  const int t = state[0] + 1;
+  state[0] = t;
+  const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+  state[1] = __float_as_int((float)(lr * sqrt(bc2) / bc1));
+}
+// One pass: read x,g,m,v (16 B) ; write x,m,v (12 B) = 28 B/param.  fp32 op order follows optim/adam.lua.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float b1, float omb1, float b2, float omb2,
+                                              float eps, const int32_t* __restrict__ state) {
+  const float step = __int_as_float(state[1]);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, n4 = n >> 2;
+  auto upd = [&](float& xv, float gv, float& mv, float& vv) {
+    float mi = mv * b1;
+    mi = mi + omb1 * gv;
+    float vi = vv * b2;
+    vi = vi + (omb2 * gv) * gv;
+    float d = sqrtf(vi);
+    d = d + eps;
+    mv = mi;
+    vv = vi;
+    xv = xv - (step * mi) / d;
+  };
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 xv = ((f32x4*)x)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+    const f32x4 gv = ((const f32x4*)g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xe = xv[e], me = mv[e], ve = vv[e];
+      upd(xe, gv[e], me, ve);
+      xv[e] = xe;
+      mv[e] = me;
+      vv[e] = ve;
+    }
+    ((f32x4*)x)[i] = xv;
+    ((f32x4*)m)[i] = mv;
+    ((f32x4*)v)[i] = vv;
+  }
+  for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) upd(x[i], g[i], m[i], v[i]);
+}
+VF_API int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                        double beta2, double eps, int32_t* t_dev) {
+  VF_REQUIRE((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam operands must be 16-byte aligned");
+  hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, ctx->stream, t_dev, lr, beta1, beta2);
+  VF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 4)), dim3(256), 0, ctx->stream, x, g, m, v, n, (float)beta1, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
+  VF_LAUNCH_CHECK();
+  return 0;
+}

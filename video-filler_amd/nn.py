@@ -1,0 +1,593 @@
+"""Host-side mirror of the Torch7 `nn` surface the reference drivers use, backed by the gfx950 C-ABI.
+
+Same class names, constructor arguments, method names and field names as Torch7 (`forward`, `backward`,
+`updateGradInput`, `accGradParameters`, `apply`, `getParameters`, `evaluate`, `.output`, `.gradInput`,
+`.weight .bias .gradWeight .gradBias`, `.running_mean .running_var`, `.modules`, `.nInputPlane .nOutputPlane
+.kW .kH .dW .dH .padW .padH`) — the protocol listed in SURVEY.md 8(b) — so a driver written against it reads
+like train.lua / train_vid_weighted.lua.  Tensors are torch tensors used purely as device memory: logical
+B x C x H x W exactly as the reference indexes them, physical channels-last (NHWC); parameters likewise
+(see include/vf_hip.h).  All arithmetic happens in libvf_hip.so; there is no CPU path in this package.
+
+Differences from Torch7 that are deliberate and documented in DESIGN.md:
+  * `nn.Sequential` fuses an in-place LeakyReLU/ReLU (and a Tanh/Sigmoid that directly follows a convolution)
+    into its producer's kernel.  The activated tensor is then the producer's `.output` — for in-place
+    activations that is what Torch7 holds as well; for Tanh/Sigmoid the pre-activation tensor is not kept.
+    `Sequential(fuse=False)` runs module by module like Torch7.
+  * `zeroGradParameters()` is lazy by default: the next accGradParameters overwrites (beta = 0) instead of
+    memset + accumulate.  `lazy_zero=False` restores the memset.
+  * criteria return a lazy device scalar (`float(x)` synchronises) instead of a Lua number.
+"""
+import torch
+
+from .backend import get_backend, is_nhwc, to_nhwc
+
+
+# ---------------------------------------------------------------------------------------------- scalars
+class DeviceScalar:
+    """A loss value that lives on the device until float() is called."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    @staticmethod
+    def of(t):
+        return DeviceScalar(lambda: float(t.item()))
+
+    def __float__(self):
+        return float(self._fn())
+
+    def _bin(self, other, op):
+        a, b = self, other
+        return DeviceScalar(lambda: op(float(a), float(b)))
+
+    def __add__(self, o):
+        return self._bin(o, lambda x, y: x + y)
+
+    __radd__ = __add__
+
+    def __mul__(self, o):
+        return self._bin(o, lambda x, y: x * y)
+
+    __rmul__ = __mul__
+
+    def __repr__(self):
+        return "DeviceScalar(%r)" % float(self)
+
+
+# ---------------------------------------------------------------------------------------------- base
+class Module:
+    _type = "nn.Module"
+
+    def __init__(self):
+        self.output = None
+        self.gradInput = None
+        self.train = True
+
+    def type_name(self):            # torch.type(m)
+        return self._type
+
+    def forward(self, input):
+        return self.updateOutput(input)
+
+    def backward(self, input, gradOutput, scale=1):
+        self.updateGradInput(input, gradOutput)
+        self.accGradParameters(input, gradOutput, scale)
+        return self.gradInput
+
+    def updateGradInput(self, input, gradOutput):
+        raise NotImplementedError
+
+    def accGradParameters(self, input, gradOutput, scale=1):
+        pass
+
+    def parameters(self):
+        return None
+
+    def apply(self, fn):
+        fn(self)
+        return self
+
+    def training(self):
+        return self.apply(lambda m: setattr(m, "train", True))
+
+    def evaluate(self):
+        return self.apply(lambda m: setattr(m, "train", False))
+
+    def cuda(self):
+        return self
+
+    def float(self):
+        return self
+
+    def _buf(self, name, B, Cc, H, W):
+        t = getattr(self, name)
+        if t is None or tuple(t.shape) != (B, Cc, H, W):
+            t = get_backend().empty_act(B, Cc, H, W)
+            setattr(self, name, t)
+        return t
+
+
+def _chlast_param(B, d0, d1, kH, kW):
+    """logical [d0][d1][kH][kW], physical [d0][kH][kW][d1] (channels-last), zero-initialised."""
+    return B.zeros(d0, kH, kW, d1).permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------- convolutions
+class SpatialConvolution(Module):
+    """nn.SpatialConvolution(nInputPlane, nOutputPlane, kW, kH, dW, dH, padW, padH) — train.lua:89."""
+    _type = "nn.SpatialConvolution"
+    _is_full = False
+
+    def __init__(self, nInputPlane, nOutputPlane, kW, kH, dW=1, dH=1, padW=0, padH=0):
+        super().__init__()
+        assert kW == kH and dW == dH and padW == padH, "the reference only builds square kernels/strides"
+        self.nInputPlane, self.nOutputPlane = nInputPlane, nOutputPlane
+        self.kW, self.kH, self.dW, self.dH, self.padW, self.padH = kW, kH, dW, dH, padW, padH
+        B = get_backend()
+        d0, d1 = (nInputPlane, nOutputPlane) if self._is_full else (nOutputPlane, nInputPlane)
+        self.weight = _chlast_param(B, d0, d1, kH, kW)
+        self.gradWeight = _chlast_param(B, d0, d1, kH, kW)
+        self.bias = B.zeros(nOutputPlane)
+        self.gradBias = B.zeros(nOutputPlane)
+        self._fresh = False           # lazy zeroGradParameters: next accumulate overwrites
+
+    def out_hw(self, H, W):
+        if self._is_full:
+            return ((H - 1) * self.dH - 2 * self.padH + self.kH, (W - 1) * self.dW - 2 * self.padW + self.kW)
+        return ((H + 2 * self.padH - self.kH) // self.dH + 1, (W + 2 * self.padW - self.kW) // self.dW + 1)
+
+    def updateOutput(self, input, act="none", slope=0.0):
+        input = to_nhwc(input)
+        Bn, Cin, H, W = input.shape
+        assert Cin == self.nInputPlane, "expected %d input planes, got %d" % (self.nInputPlane, Cin)
+        Ho, Wo = self.out_hw(H, W)
+        y = self._buf("output", Bn, self.nOutputPlane, Ho, Wo)
+        fn = get_backend().deconv2d_fwd if self._is_full else get_backend().conv2d_fwd
+        fn(input, self.weight, self.bias, y, self.kH, self.dH, self.padH, act, slope)
+        return y
+
+    def updateGradInput(self, input, gradOutput):
+        gx = self._buf("gradInput", *input.shape)
+        fn = get_backend().deconv2d_bwd_data if self._is_full else get_backend().conv2d_bwd_data
+        fn(to_nhwc(gradOutput), self.weight, gx, self.kH, self.dH, self.padH)
+        return gx
+
+    def accGradParameters(self, input, gradOutput, scale=1):
+        assert scale == 1, "the reference always uses scale = 1"
+        beta = 0.0 if self._fresh else 1.0
+        self._fresh = False
+        fn = get_backend().deconv2d_bwd_weight if self._is_full else get_backend().conv2d_bwd_weight
+        fn(to_nhwc(input), to_nhwc(gradOutput), self.gradWeight, self.gradBias, self.kH, self.dH, self.padH, beta)
+
+    def parameters(self):
+        return [self.weight, self.bias], [self.gradWeight, self.gradBias]
+
+
+class SpatialFullConvolution(SpatialConvolution):
+    """nn.SpatialFullConvolution(nInputPlane, nOutputPlane, kW, kH, dW, dH, padW, padH) — train.lua:134."""
+    _type = "nn.SpatialFullConvolution"
+    _is_full = True
+
+
+# ---------------------------------------------------------------------------------------------- batch norm
+class SpatialBatchNormalization(Module):
+    """nn.SpatialBatchNormalization(nOutput, eps=1e-5, momentum=0.1, affine=true) — train.lua:92."""
+    _type = "nn.SpatialBatchNormalization"
+
+    def __init__(self, nOutput, eps=1e-5, momentum=0.1, affine=True):
+        super().__init__()
+        assert affine, "the reference builds affine BN only"
+        B = get_backend()
+        self.nOutputPlane = nOutput
+        self.eps, self.momentum = eps, momentum
+        self.weight = B.zeros(nOutput) + 1.0
+        self.bias = B.zeros(nOutput)
+        self.gradWeight = B.zeros(nOutput)
+        self.gradBias = B.zeros(nOutput)
+        self.running_mean = B.zeros(nOutput)
+        self.running_var = B.zeros(nOutput) + 1.0
+        self.save_mean = B.zeros(nOutput)
+        self.save_std = B.zeros(nOutput)          # holds 1/sqrt(var+eps), as THNN's save_std does
+        self._sums = B.zeros(2 * nOutput, dtype=torch.float64)
+        self._fresh = False
+        self.sync_world = 1                       # >1: SyncBN — all-reduce the per-channel sums
+        self.sync_group = None
+
+    def updateOutput(self, input, act="none", slope=0.0):
+        B = get_backend()
+        input = to_nhwc(input)
+        Bn, Cc, H, W = input.shape
+        assert Cc == self.nOutputPlane
+        y = self._buf("output", Bn, Cc, H, W)
+        if self.train:
+            B.bn_stats(input, self.running_mean, self._sums)
+            if self.sync_world > 1:
+                B.all_reduce(self._sums, self.sync_group)
+            B.bn_finalize(self._sums, self.running_mean, self.running_var, self.save_mean, self.save_std,
+                          Bn * H * W * self.sync_world, self.momentum, self.eps)
+            B.bn_apply(input, y, self.weight, self.bias, self.save_mean, self.save_std, act, slope)
+        else:
+            B.bn_eval_fwd(input, y, self.weight, self.bias, self.running_mean, self.running_var, self.eps, act, slope)
+        return y
+
+    def _bwd(self, input, gradOutput, want_gx, want_gp, act="none", slope=0.0, y_act=None):
+        assert self.train, "the reference never back-propagates through BN in evaluate mode"
+        B = get_backend()
+        input, gradOutput = to_nhwc(input), to_nhwc(gradOutput)
+        Bn, Cc, H, W = input.shape
+        gx = self._buf("gradInput", Bn, Cc, H, W) if want_gx else None
+        B.bn_bwd_stats(input, y_act, gradOutput, self.save_mean, self._sums, act, slope)
+        if self.sync_world > 1:
+            B.all_reduce(self._sums, self.sync_group)
+        pbeta = 1.0
+        if want_gp:
+            pbeta = 0.0 if self._fresh else 1.0
+            self._fresh = False
+        B.bn_bwd_apply(input, y_act, gradOutput, gx, self.gradWeight if want_gp else None,
+                       self.gradBias if want_gp else None, self.weight, self.save_mean, self.save_std, self._sums,
+                       Bn * H * W * self.sync_world, act, slope, pbeta)
+        return gx
+
+    def updateGradInput(self, input, gradOutput):
+        return self._bwd(input, gradOutput, True, False)
+
+    def accGradParameters(self, input, gradOutput, scale=1):
+        assert scale == 1
+        self._bwd(input, gradOutput, False, True)
+
+    def backward(self, input, gradOutput, scale=1):
+        assert scale == 1
+        return self._bwd(input, gradOutput, True, True)
+
+    def parameters(self):
+        return [self.weight, self.bias], [self.gradWeight, self.gradBias]
+
+
+# ---------------------------------------------------------------------------------------------- pointwise
+class _Act(Module):
+    act = "none"
+    slope = 0.0
+    inplace = False
+
+    def updateOutput(self, input):
+        if self.inplace:
+            self.output = input
+        elif self.output is None or self.output.shape != input.shape:
+            self.output = torch.empty_like(input)
+        get_backend().act_fwd(input, self.output, self.act, self.slope)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        # the derivative is evaluated from the ACTIVATED values; for in-place modules `input`
+        # already holds them (the producer's .output was overwritten).
+        y = input if self.inplace else self.output
+        if self.inplace:
+            self.gradInput = gradOutput
+        else:
+            self.gradInput = torch.empty_like(gradOutput) if (
+                self.gradInput is None or self.gradInput.shape != gradOutput.shape) else self.gradInput
+        get_backend().act_bwd(y, gradOutput, self.gradInput, self.act, self.slope)
+        return self.gradInput
+
+
+class LeakyReLU(_Act):
+    _type = "nn.LeakyReLU"
+    act = "lrelu"
+
+    def __init__(self, negval=0.01, inplace=False):
+        super().__init__()
+        self.slope, self.inplace = negval, inplace
+        self.negval = negval
+
+
+class ReLU(_Act):
+    _type = "nn.ReLU"
+    act = "relu"
+
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+
+class Tanh(_Act):
+    _type = "nn.Tanh"
+    act = "tanh"
+
+
+class Sigmoid(_Act):
+    _type = "nn.Sigmoid"
+    act = "sigmoid"
+
+
+class View(Module):
+    """nn.View(1):setNumInputDims(3) — B x 1 x 1 x 1 -> B x 1 (train.lua:198)."""
+    _type = "nn.View"
+
+    def __init__(self, *sizes):
+        super().__init__()
+        self.sizes = sizes
+        self.numInputDims = None
+
+    def setNumInputDims(self, n):
+        self.numInputDims = n
+        return self
+
+    def updateOutput(self, input):
+        self.output = input.reshape(input.shape[0], *self.sizes)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        self.gradInput = gradOutput.reshape(input.shape)
+        return self.gradInput
+
+
+# ---------------------------------------------------------------------------------------------- container
+class Sequential(Module):
+    _type = "nn.Sequential"
+
+    def __init__(self, fuse=True, lazy_zero=True):
+        super().__init__()
+        self.modules = []
+        self.fuse = fuse
+        self.lazy_zero = lazy_zero
+        self._plan = None
+        self._flat = None
+
+    def add(self, m):
+        self.modules.append(m)
+        self._plan = None
+        return self
+
+    def apply(self, fn):
+        fn(self)
+        for m in self.modules:
+            m.apply(fn)
+        return self
+
+    def leaves(self):
+        out = []
+        for m in self.modules:
+            out += m.leaves() if isinstance(m, Sequential) else [m]
+        return out
+
+    # -- execution plan: [(main, act_or_None)] over the flattened leaf list
+    def _build_plan(self):
+        leaves = self.leaves()
+        plan, i = [], 0
+        while i < len(leaves):
+            m = leaves[i]
+            nxt = leaves[i + 1] if i + 1 < len(leaves) else None
+            fusable = False
+            if self.fuse and nxt is not None and isinstance(nxt, _Act):
+                if isinstance(m, (SpatialConvolution, SpatialBatchNormalization)) and nxt.inplace:
+                    fusable = True
+                elif isinstance(m, SpatialConvolution) and isinstance(nxt, (Tanh, Sigmoid)):
+                    fusable = True
+            if fusable:
+                plan.append((m, nxt))
+                i += 2
+            else:
+                plan.append((m, None))
+                i += 1
+        self._plan = plan
+        return plan
+
+    def updateOutput(self, input):
+        plan = self._plan or self._build_plan()
+        cur = input
+        for m, a in plan:
+            if a is None:
+                cur = m.updateOutput(cur)
+            else:
+                cur = m.updateOutput(cur, a.act, a.slope)
+                a.output = cur
+        self.output = cur
+        return cur
+
+    def _walk(self, input, gradOutput, want_gp, need_input_grad=True):
+        plan = self._plan or self._build_plan()
+        B = get_backend()
+        g = gradOutput
+        for idx in range(len(plan) - 1, -1, -1):
+            m, a = plan[idx]
+            x = input if idx == 0 else plan[idx - 1][0].output
+            want_gx = need_input_grad or idx > 0
+            if isinstance(m, SpatialBatchNormalization):
+                if a is None:
+                    g = m._bwd(x, g, want_gx, want_gp)
+                else:
+                    a.gradInput = g
+                    g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, m.output)
+            else:
+                if a is not None:
+                    B.act_bwd(m.output, g, g, a.act, a.slope)   # in place on the incoming gradient
+                    a.gradInput = g
+                gin = m.updateGradInput(x, g) if want_gx else None
+                if want_gp:
+                    m.accGradParameters(x, g, 1)
+                g = gin
+        self.gradInput = g
+        return g
+
+    def updateGradInput(self, input, gradOutput):
+        return self._walk(input, gradOutput, False)
+
+    def backward(self, input, gradOutput, scale=1, need_input_grad=True):
+        """need_input_grad=False skips the first layer's gradInput — Torch7 always computes it, the reference
+        drivers never read it for netD's two full backward passes nor for netG (train.lua:318,348,403)."""
+        assert scale == 1
+        return self._walk(input, gradOutput, True, need_input_grad)
+
+    def parameters(self):
+        ws, gs = [], []
+        for m in self.leaves():
+            p = m.parameters()
+            if p:
+                ws += p[0]
+                gs += p[1]
+        return ws, gs
+
+    # -- net:getParameters()  
+    def getParameters(self, align=64):
+        """Flatten {weight, bias} of every module, depth first, into ONE fp32 storage (+ one for grads) and make
+        the module tensors views of it.  Inside a tensor the order is the physical channels-last order; segment
+        starts are padded to `align` floats so every tensor stays 16-byte aligned.  `reference_flat()` gives
+        the exact A.11 vector."""
+        B = get_backend()
+        owners = [m for m in self.leaves() if m.parameters()]
+        segs, off = [], 0
+        for m in owners:
+            for name, gname in (("weight", "gradWeight"), ("bias", "gradBias")):
+                t = getattr(m, name)
+                off = (off + align - 1) // align * align
+                segs.append((m, name, gname, off, t.numel()))
+                off += t.numel()
+        total = (off + align - 1) // align * align
+        flat, gflat = B.zeros(total), B.zeros(total)
+        bias_offs, bias_lens = [], []
+        for m, name, gname, o, n in segs:
+            t, g = getattr(m, name), getattr(m, gname)
+            if t.dim() == 4:
+                d0, d1, kH, kW = t.shape
+                pv = flat[o:o + n].view(d0, kH, kW, d1)
+                pv.copy_(t.permute(0, 2, 3, 1))
+                gv = gflat[o:o + n].view(d0, kH, kW, d1)
+                gv.copy_(g.permute(0, 2, 3, 1))
+                setattr(m, name, pv.permute(0, 3, 1, 2))
+                setattr(m, gname, gv.permute(0, 3, 1, 2))
+            else:
+                flat[o:o + n].copy_(t)
+                gflat[o:o + n].copy_(g)
+                setattr(m, name, flat[o:o + n])
+                setattr(m, gname, gflat[o:o + n])
+            if name == "bias" and "Convolution" in m.type_name():
+                bias_offs.append(o)
+                bias_lens.append(n)
+        self._flat = (flat, gflat, segs)
+        self._bias_offs = B.from_host(torch.tensor(bias_offs, dtype=torch.int64))
+        self._bias_lens = B.from_host(torch.tensor(bias_lens, dtype=torch.int64))
+        return flat, gflat
+
+    def reference_flat(self, grads=False):
+        """The flat vector exactly as Torch7's getParameters() lays it out (A.11): logical row-major tensors,
+        no padding."""
+        parts = []
+        for m, name, gname, o, n in self._flat[2]:
+            t = getattr(m, gname if grads else name)
+            parts.append(t.contiguous().reshape(-1))
+        return torch.cat(parts)
+
+    def load_reference_flat(self, vec):
+        off = 0
+        for m, name, gname, o, n in self._flat[2]:
+            t = getattr(m, name)
+            t.copy_(vec[off:off + n].reshape(t.shape))
+            off += n
+        assert off == vec.numel()
+
+    def n_parameters(self):
+        return sum(n for *_, n in self._flat[2])
+
+    def zeroConvBiases(self):
+        """netX:apply(function(m) if torch.type(m):find('Convolution') then m.bias:zero() end end) — train.lua:279."""
+        if self._flat is not None:
+            get_backend().zero_segments(self._flat[0], self._bias_offs, self._bias_lens)
+        else:
+            for m in self.leaves():
+                if "Convolution" in m.type_name():
+                    get_backend().zero(m.bias)
+
+    def zeroGradParameters(self):
+        """gradParameters:zero() — train.lua:282."""
+        if self.lazy_zero:
+            for m in self.leaves():
+                if m.parameters():
+                    m._fresh = True
+        elif self._flat is not None:
+            get_backend().zero(self._flat[1])
+        else:
+            for m in self.leaves():
+                p = m.parameters()
+                if p:
+                    for g in p[1]:
+                        get_backend().zero(g)
+
+
+# ---------------------------------------------------------------------------------------------- criteria
+class _Criterion:
+    def __init__(self):
+        self._loss = get_backend().zeros(1, dtype=torch.float64)
+        self.gradInput = None
+        self.output = None
+
+    def cuda(self):
+        return self
+
+    def _g(self, like):
+        if self.gradInput is None or self.gradInput.shape != like.shape:
+            self.gradInput = torch.empty_like(to_nhwc(like) if like.dim() == 4 else like)
+        return self.gradInput
+
+
+class BCECriterion(_Criterion):
+    """nn.BCECriterion() — train.lua:204.  `target` is the constant the reference fills `label` with."""
+
+    def forward(self, input, target):
+        get_backend().bce_fwd(input, float(target), self._loss)
+        self.output = DeviceScalar.of(self._loss)
+        return self.output
+
+    def backward(self, input, target):
+        g = self._g(input)
+        get_backend().bce_bwd(input, float(target), g)
+        return g
+
+
+class MSECriterion(_Criterion):
+    """nn.MSECriterion() — train.lua:207."""
+
+    def forward(self, input, target):
+        get_backend().mse_fwd(to_nhwc(input), to_nhwc(target), self._loss)
+        self.output = DeviceScalar.of(self._loss)
+        return self.output
+
+    def backward(self, input, target):
+        g = self._g(input)
+        get_backend().mse_bwd(to_nhwc(input), to_nhwc(target), g)
+        return g
+
+
+class GDLCriterion(_Criterion):
+    """nn.GDLCriterion(alpha) — gdl_criterion.lua:6; only :forward is consumed (train_vid_weighted.lua:524)."""
+
+    def __init__(self, alpha=1):
+        super().__init__()
+        assert alpha == 1  # gdl_criterion.lua:9
+
+    def forward(self, input, target):
+        get_backend().gdl_fwd(to_nhwc(input), to_nhwc(target), self._loss)
+        self.output = DeviceScalar.of(self._loss)
+        return self.output
+
+
+class MaskedMSECriterion(_Criterion):
+    """nn.MaskedMSECriterion(mWeight) — MaskedMSECriterion.lua:7."""
+
+    def __init__(self, mWeight=1.0):
+        super().__init__()
+        self.mWeight = mWeight
+        self.mask = None
+
+    def setMask(self, m):
+        assert m.dtype == torch.uint8, "setMask wants a ByteTensor (MaskedMSECriterion.lua:25)"
+        self.mask = m if m.dim() != 4 else to_nhwc(m)
+
+    def forward(self, input, target):
+        get_backend().masked_mse_fwd(to_nhwc(input), to_nhwc(target), self.mask, self.mWeight, self._loss)
+        self.output = DeviceScalar.of(self._loss)
+        return self.output
+
+    def backward(self, input, target):
+        g = self._g(input)
+        get_backend().masked_mse_bwd(to_nhwc(input), to_nhwc(target), self.mask, self.mWeight, g)
+        return g

@@ -1,0 +1,26 @@
+"""optim.adam with the reference's call shape: optim.adam(opfunc, x, state) (train.lua:421-424).
+
+`x` is the flat parameter tensor from net:getParameters(); `opfunc(x)` returns (f(x), df/dx) where df/dx is the
+flat gradient tensor.  State (`m`, `v`, device step counter) lives in `state`, as in optim/adam.lua; the update
+itself is ONE fused kernel pass (vf_adam_step).  Defaults as optim.adam: beta1 0.9, beta2 0.999, epsilon 1e-8.
+"""
+import torch
+
+from .backend import get_backend
+
+
+def adam(opfunc, x, state):
+    B = get_backend()
+    lr = state.get("learningRate", 0.001)
+    beta1 = state.get("beta1", 0.9)
+    beta2 = state.get("beta2", 0.999)
+    eps = state.get("epsilon", 1e-8)
+    fx, dfdx = opfunc(x)
+    if "m" not in state:
+        state["t"] = 0
+        state["m"] = torch.zeros_like(x)
+        state["v"] = torch.zeros_like(x)
+        state["t_dev"] = B.zeros(2, dtype=torch.int32)
+    state["t"] += 1          # host mirror of the device counter (informational)
+    B.adam_step(x, dfdx, state["m"], state["v"], lr, beta1, beta2, eps, state["t_dev"])
+    return x, [fx]

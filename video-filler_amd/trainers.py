@@ -1,0 +1,350 @@
+"""The reference drivers' hot loop — net construction, the fDx / fGx closures and the two optim.adam calls —
+restated over the nn mirror so it reads like the Lua it replaces.
+
+  CenterTrainer  <- train.lua                  (net: :87-199, closures: :278-410, loop body: :421-424)
+  VidTrainer     <- train_vid_weighted.lua     (net: :112-236, closures: :373-537, loop body: :548-551)
+                    train_wholeim_input.lua    (same closures; nc_in/nc_out/widths differ, :116-119,137-260)
+
+Option names are the reference's (`opt` table / environment variables).  Data loading, display and checkpoint
+cadence are outside the hot path; `set_batch` takes tensors with the loaders' contract.
+
+Data parallelism (new capability; the reference is single-device): one process per GPU, each with a
+full replica and an equal shard of the batch; flat gradients are all-reduce-averaged over RCCL at the end of
+each closure, which reproduces the single-device big-batch gradient because every criterion is a batch mean.
+`sync_bn=True` additionally all-reduces the BatchNorm sums so statistics equal the big batch's.
+"""
+import os
+
+import torch
+
+from . import nn, optim
+from .backend import get_backend, to_nhwc
+
+DEFAULT_OPT_TRAIN = dict(batchSize=64, fineSize=128, nBottleneck=100, nef=64, ngf=64, ndf=64, nc=3, wtl2=0.0,
+                         overlapPred=0, lr=0.0002, beta1=0.5)
+DEFAULT_OPT_VID = dict(batchSize=16, fineSize=128, nBottleneck=4000, nef=64, ngf=64, ndf=64, nc=3, predLen=4,
+                       wtl2=0.999, weight_nomask=0.05, wtgdl=0.0, overlapPred=0, lr=0.0002, beta1=0.5,
+                       nc_in=None, nc_out=None)
+
+
+def opt_from_env(defaults):
+    """`for k,v in pairs(opt) do opt[k] = tonumber(os.getenv(k)) or os.getenv(k) or opt[k] end` (train.lua:36)."""
+    opt = dict(defaults)
+    for k in opt:
+        v = os.getenv(k)
+        if v is not None:
+            try:
+                opt[k] = float(v) if ("." in v or "e" in v.lower()) else int(v)
+            except ValueError:
+                opt[k] = v
+    return opt
+
+
+def _conv(nIn, nOut, s2=True):
+    return nn.SpatialConvolution(nIn, nOut, 4, 4, 2, 2, 1, 1) if s2 else nn.SpatialConvolution(nIn, nOut, 4, 4)
+
+
+def _full(nIn, nOut, s2=True):
+    return nn.SpatialFullConvolution(nIn, nOut, 4, 4, 2, 2, 1, 1) if s2 else nn.SpatialFullConvolution(nIn, nOut, 4, 4)
+
+
+def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=True, lazy_zero=True):
+    """train.lua:87-148 (64x64 output) / train_vid_weighted.lua:112-176 (extra ngf->ngf layer, 128x128 output)."""
+    BN, LReLU, ReLU = nn.SpatialBatchNormalization, nn.LeakyReLU, nn.ReLU
+    netE = nn.Sequential(fuse, lazy_zero)
+    netE.add(_conv(nc_in, nef)).add(LReLU(0.2, True))
+    netE.add(_conv(nef, nef)).add(BN(nef)).add(LReLU(0.2, True))
+    netE.add(_conv(nef, nef * 2)).add(BN(nef * 2)).add(LReLU(0.2, True))
+    netE.add(_conv(nef * 2, nef * 4)).add(BN(nef * 4)).add(LReLU(0.2, True))
+    netE.add(_conv(nef * 4, nef * 8)).add(BN(nef * 8)).add(LReLU(0.2, True))
+    netE.add(_conv(nef * 8, nBottleneck, s2=False))
+    netG = nn.Sequential(fuse, lazy_zero)
+    netG.add(netE)
+    netG.add(BN(nBottleneck)).add(LReLU(0.2, True))
+    netG.add(_full(nBottleneck, ngf * 8, s2=False)).add(BN(ngf * 8)).add(ReLU(True))
+    netG.add(_full(ngf * 8, ngf * 4)).add(BN(ngf * 4)).add(ReLU(True))
+    netG.add(_full(ngf * 4, ngf * 2)).add(BN(ngf * 2)).add(ReLU(True))
+    netG.add(_full(ngf * 2, ngf)).add(BN(ngf)).add(ReLU(True))
+    if extra_decoder_layer:
+        netG.add(_full(ngf, ngf)).add(BN(ngf)).add(ReLU(True))
+    netG.add(_full(ngf, nc_out)).add(nn.Tanh())
+    return netG
+
+
+def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True):
+    """train.lua:157-199 (64x64 input) / train_vid_weighted.lua:213-236 (extra floor(ndf/2) layer, 128x128 input)."""
+    BN, LReLU = nn.SpatialBatchNormalization, nn.LeakyReLU
+    netD = nn.Sequential(fuse, lazy_zero)
+    if extra_first_layer:
+        mylayer = ndf // 2
+        netD.add(_conv(nc, mylayer)).add(LReLU(0.2, True))
+        netD.add(_conv(mylayer, ndf)).add(LReLU(0.2, True))
+    else:
+        netD.add(_conv(nc, ndf)).add(LReLU(0.2, True))
+    netD.add(_conv(ndf, ndf * 2)).add(BN(ndf * 2)).add(LReLU(0.2, True))
+    netD.add(_conv(ndf * 2, ndf * 4)).add(BN(ndf * 4)).add(LReLU(0.2, True))
+    netD.add(_conv(ndf * 4, ndf * 8)).add(BN(ndf * 8)).add(LReLU(0.2, True))
+    netD.add(_conv(ndf * 8, 1, s2=False)).add(nn.Sigmoid())
+    netD.add(nn.View(1).setNumInputDims(3))
+    return netD
+
+
+def weights_init(net, gen):
+    """train.lua:58-67.  `gen` is a torch.Generator on CPU (Torch7's MT19937 stream cannot be reproduced;
+    parity tests load explicit weights instead)."""
+    B = get_backend()
+
+    def init(m):
+        name = m.type_name()
+        if "Convolution" in name:
+            w = torch.empty(m.weight.shape).normal_(0.0, 0.02, generator=gen)
+            m.weight.copy_(B.from_host(w))
+            m.bias.zero_()
+        elif "BatchNormalization" in name:
+            m.weight.copy_(B.from_host(torch.empty(m.weight.shape).normal_(1.0, 0.02, generator=gen)))
+            m.bias.zero_()
+
+    net.apply(init)
+
+
+def _solver(opt):
+    wt = opt["wtl2"]
+    lrG = opt["lr"] * 10 if (wt > 0 and wt < 1) else opt["lr"]      # train.lua:219-226
+    return ({"learningRate": lrG, "beta1": opt["beta1"]}, {"learningRate": opt["lr"], "beta1": opt["beta1"]})
+
+
+class _TrainerBase:
+    def _finish_init(self, seed, world, rank, group, sync_bn, skip_dead_grads):
+        gen = torch.Generator().manual_seed(seed)
+        weights_init(self.netG, gen)
+        weights_init(self.netD, gen)
+        self.criterion = nn.BCECriterion()
+        self.optimStateG, self.optimStateD = _solver(self.opt)
+        self.parametersD, self.gradParametersD = self.netD.getParameters()
+        self.parametersG, self.gradParametersG = self.netG.getParameters()
+        self.world, self.rank, self.group = world, rank, group
+        self.skip_dead_grads = skip_dead_grads
+        if world > 1 and sync_bn:
+            for net in (self.netG, self.netD):
+                for m in net.leaves():
+                    if isinstance(m, nn.SpatialBatchNormalization):
+                        m.sync_world, m.sync_group = world, group
+        self.errD = self.errG = self.errG_l2 = self.errG_gdl = None
+        self._graph = None
+
+    def _allreduce_avg(self, flat):
+        """RCCL all-reduce of a flat gradient vector, then 1/world."""
+        if self.world > 1:
+            B = get_backend()
+            B.all_reduce(flat, self.group)
+            B.scale_shift(flat, 1.0 / self.world, 0.0)
+
+    def step(self):
+        """The loop body: optim.adam(fDx, ...) ; optim.adam(fGx, ...)  (train.lua:421-424)."""
+        optim.adam(self.fDx, self.parametersD, self.optimStateD)
+        optim.adam(self.fGx, self.parametersG, self.optimStateG)
+
+    # -- HIP graph of one whole iteration (single-GPU): zero launch gaps, no host work per step
+    def capture(self, warmup=3):
+        assert self.world == 1, "graph capture covers the single-device iteration; DP runs eagerly"
+        B = get_backend()
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            B.use_current_stream()
+            self.step()
+        B.use_current_stream()
+        self._graph = g
+        return g
+
+    def replay(self):
+        self._graph.replay()
+
+    def losses(self):
+        out = dict(errD=self.errD, errG=self.errG, errG_l2=self.errG_l2, errG_gdl=self.errG_gdl)
+        return {k: (None if v is None else float(v)) for k, v in out.items()}
+
+
+class CenterTrainer(_TrainerBase):
+    """train.lua: centre-square inpainting; netD judges the 64x64 centre."""
+
+    def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
+                 skip_dead_grads=True):
+        o = dict(DEFAULT_OPT_TRAIN)
+        o.update(opt or {})
+        self.opt = o
+        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, fuse, lazy_zero)
+        self.netD = build_netD(o["nc"], o["ndf"], False, fuse, lazy_zero)
+        self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
+        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads)
+        self.real_label, self.fake_label = 1, 0
+        self.input_ctx = self.input_center = self.input_real_center = None
+
+    def set_batch(self, real_ctx):
+        """What train.lua:284-298 does on the loader's batch (a B x nc x fineSize x fineSize tensor in [-1,1]):
+        clone the centre crop, paint the hole (minus the overlap band) with the channel means, and copy to the
+        device buffers input_ctx / input_center / input_real_center."""
+        o, B = self.opt, get_backend()
+        fs, ov = o["fineSize"], o["overlapPred"]
+        real_ctx = B.from_host(real_ctx).clone()
+        lo, hi = fs // 4, fs // 2 + fs // 4
+        real_center = real_ctx[:, :, lo:hi, lo:hi].clone()
+        for ch, mean in enumerate((117.0, 104.0, 123.0)):
+            real_ctx[:, ch, lo + ov:hi - ov, lo + ov:hi - ov] = 2 * mean / 255.0 - 1.0
+        self.input_ctx = to_nhwc(real_ctx)
+        self._real_center = to_nhwc(real_center)
+        if self.input_center is None or self.input_center.shape != real_center.shape:
+            self.input_center = torch.empty_like(self._real_center)
+            self.input_real_center = torch.empty_like(self._real_center)
+
+    def fDx(self, x):
+        B, o = get_backend(), self.opt
+        self.netD.zeroConvBiases()
+        self.netG.zeroConvBiases()
+        self.netD.zeroGradParameters()
+        # train with real
+        B.copy(self.input_center, self._real_center)
+        if o["wtl2"] != 0:
+            B.copy(self.input_real_center, self._real_center)
+        label = self.real_label
+        output = self.netD.forward(self.input_center)
+        errD_real = self.criterion.forward(output, label)
+        df_do = self.criterion.backward(output, label)
+        self.netD.backward(self.input_center, df_do, need_input_grad=not self.skip_dead_grads)
+        # train with fake
+        fake = self.netG.forward(self.input_ctx)
+        B.copy(self.input_center, fake)
+        label = self.fake_label
+        output = self.netD.forward(self.input_center)
+        errD_fake = self.criterion.forward(output, label)
+        df_do = self.criterion.backward(output, label)
+        self.netD.backward(self.input_center, df_do, need_input_grad=not self.skip_dead_grads)
+        self.errD = errD_real + errD_fake
+        self._allreduce_avg(self.gradParametersD)
+        return self.errD, self.gradParametersD
+
+    def fGx(self, x):
+        B, o = get_backend(), self.opt
+        wt, ov = o["wtl2"], o["overlapPred"]
+        self.netD.zeroConvBiases()
+        self.netG.zeroConvBiases()
+        self.netG.zeroGradParameters()
+        label = self.real_label                      # fake labels are real for the generator cost
+        output = self.netD.output                    # reused from fDx (train.lua:363): stale w.r.t. D's Adam step
+        self.errG = self.criterion.forward(output, label)
+        df_do = self.criterion.backward(output, label)
+        df_dg = self.netD.updateGradInput(self.input_center, df_do)
+        errG_total = self.errG
+        if wt != 0:
+            # train.lua:377-399 fused into one pass: MSE forward, MSE gradient, overlap-band weighting, wtl2 mix
+            alpha = (1 - wt) if (0 < wt < 1) else 1.0
+            if ov == 0:
+                c0, c1, band = wt, 0.0, 0
+            else:
+                c0, c1, band = wt, 10 * wt - wt, ov          # inside: wtl2 ; border band: 10*wtl2
+            B.recon_grad_mix(df_dg, self.input_center, self.input_real_center, None, alpha, c0, c1, band,
+                             self.criterionMSE._loss)
+            self.errG_l2 = nn.DeviceScalar.of(self.criterionMSE._loss)
+            errG_total = (alpha if (0 < wt < 1) else 1.0) * self.errG + wt * self.errG_l2
+        self.netG.backward(self.input_ctx, df_dg, need_input_grad=not self.skip_dead_grads)
+        self._allreduce_avg(self.gradParametersG)
+        return errG_total, self.gradParametersG
+
+
+class VidTrainer(_TrainerBase):
+    """train_vid_weighted.lua / train_wholeim_input.lua: full-frame output, netD judges the whole frame."""
+
+    def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
+                 skip_dead_grads=True):
+        o = dict(DEFAULT_OPT_VID)
+        o.update(opt or {})
+        self.opt = o
+        nc = o["nc"] * o["predLen"]
+        self.nc_in = o["nc_in"] or nc
+        self.nc_out = o["nc_out"] or nc
+        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, fuse, lazy_zero)
+        self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero)
+        self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
+        self.criterionGDL = nn.GDLCriterion(1) if o["wtgdl"] != 0 else None
+        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads)
+        self.real_label, self.fake_label = 1, 0
+        self.input_inpainted = None
+
+    def set_batch(self, real_ctx, real_full, real_mask):
+        """The loader contract (datavid/dataset.lua:426): masked clip, full clip, Byte mask, all B x nc x H x W."""
+        B = get_backend()
+        self._real_ctx = to_nhwc(B.from_host(real_ctx).float())
+        self._real_full = to_nhwc(B.from_host(real_full).float())
+        self._real_mask = to_nhwc(B.from_host(real_mask).float())     # input_mask:copy(real_mask): Byte -> Float
+        if self.input_inpainted is None or self.input_inpainted.shape != self._real_full.shape:
+            self.input_ctx = torch.empty_like(self._real_ctx)
+            self.input_real = torch.empty_like(self._real_full)
+            self.input_mask = torch.empty_like(self._real_mask)
+            self.input_inpainted = torch.empty_like(self._real_full)
+
+    def fDx(self, x):
+        B, o = get_backend(), self.opt
+        self.netD.zeroConvBiases()
+        self.netG.zeroConvBiases()
+        self.netD.zeroGradParameters()
+        B.copy(self.input_ctx, self._real_ctx)
+        if o["wtl2"] != 0:
+            B.copy(self.input_real, self._real_full)
+        B.copy(self.input_mask, self._real_mask)
+        label = self.real_label
+        output = self.netD.forward(self.input_real)
+        errD_real = self.criterion.forward(output, label)
+        df_do = self.criterion.backward(output, label)
+        self.netD.backward(self.input_real, df_do, need_input_grad=not self.skip_dead_grads)
+        fake = self.netG.forward(self.input_ctx)
+        if o["weight_nomask"] == 0:                  # train_vid_weighted.lua:429-432
+            B.masked_compose(self.input_inpainted, self.input_real, fake, self.input_mask)
+        else:
+            B.copy(self.input_inpainted, fake)
+        label = self.fake_label
+        output = self.netD.forward(self.input_inpainted)
+        errD_fake = self.criterion.forward(output, label)
+        df_do = self.criterion.backward(output, label)
+        self.netD.backward(self.input_inpainted, df_do, need_input_grad=not self.skip_dead_grads)
+        self.errD = errD_real + errD_fake
+        self._allreduce_avg(self.gradParametersD)
+        return self.errD, self.gradParametersD
+
+    def fGx(self, x):
+        B, o = get_backend(), self.opt
+        wt, lam, wtgdl = o["wtl2"], o["weight_nomask"], o["wtgdl"]
+        self.netD.zeroConvBiases()
+        self.netG.zeroConvBiases()
+        self.netG.zeroGradParameters()
+        label = self.real_label
+        output = self.netD.output
+        self.errG = self.criterion.forward(output, label)
+        df_do = self.criterion.backward(output, label)
+        df_dg = self.netD.updateGradInput(self.input_real, df_do)
+        errG_total = self.errG
+        if wtgdl != 0:                               # forward value only (train_vid_weighted.lua:524)
+            self.errG_gdl = self.criterionGDL.forward(self.input_inpainted, self.input_real)
+        if wt != 0:
+            assert o["overlapPred"] == 0, "train_vid_weighted.lua:499: overlapPred must be 0 here"
+            # :489-503 (+ :525-528, which adds wtgdl * the MSE gradient — the reference's own quirk) in one pass:
+            #   g_l2 = (2/N)(x-t) .* (mask*(1-lambda)+lambda);  df_dg = alpha*df_dg + wtl2*g_l2 + wtgdl*(2/N)(x-t)
+            alpha = (1 - wt) if (0 < wt < 1) else 1.0
+            if lam == 0:
+                c0, c1, mask = wt + wtgdl, 0.0, None
+            else:
+                c0, c1, mask = wt * lam + wtgdl, wt * (1 - lam), self.input_mask
+                # the reference also rewrites input_mask in place into the weights (:494); nothing reads it
+                # again before the next fDx overwrites it, so the fused pass leaves it untouched.
+            B.recon_grad_mix(df_dg, self.input_inpainted, self.input_real, mask, alpha, c0, c1, 0,
+                             self.criterionMSE._loss)
+            self.errG_l2 = nn.DeviceScalar.of(self.criterionMSE._loss)
+            errG_total = (alpha if (0 < wt < 1) else 1.0) * self.errG + wt * self.errG_l2
+        elif wtgdl != 0:
+            raise RuntimeError("wtgdl ~= 0 with wtl2 == 0 indexes a nil criterionMSE in the reference (:525)")
+        if wtgdl != 0:
+            errG_total = errG_total + wtgdl * self.errG_gdl
+        self.netG.backward(self.input_ctx, df_dg, need_input_grad=not self.skip_dead_grads)
+        self._allreduce_avg(self.gradParametersG)
+        return errG_total, self.gradParametersG
