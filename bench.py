@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — whole-iteration throughput of the context-encoder GAN hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): train.lua nets with the README `inpaintCenter` recipe
+(nBottleneck=4000, wtl2=0.999, overlapPred=4, fineSize=128), batchSize=64 per GPU, synthetic U[-1,1] images
+resident in HBM.  A step = fDx + Adam(D) + fGx + Adam(G) (train.lua:421-424): netG 1 fwd + 1 bwd, netD 2 fwd +
+2 bwd + 1 data-grad pass, BCE/MSE criteria, two fused Adam passes.  Arithmetic is fp32 end to end (f32 MFMA).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of the step, timed with HIP
+events inside the library during an instrumented pass of the same workload; `cpu_baseline` is the CPU oracle
+(1 thread, as the reference forces torch.setnumthreads(1)) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="batchSize per GPU (train.lua:7)")
+    ap.add_argument("--nBottleneck", type=int, default=4000)
+    ap.add_argument("--workload", default="center", choices=["center", "vid16", "vid4"])
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph (N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--sync-bn", action="store_true", help="N>1: all-reduce BatchNorm sums (big-batch parity mode)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from video_filler_amd.backend import get_backend
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+
+    B = get_backend()
+    gen = torch.Generator().manual_seed(1234 + rank)
+    if args.workload == "center":
+        opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, wtl2=0.999, overlapPred=4)
+        tr = CenterTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn)
+        batch = torch.rand((args.batch, 3, 128, 128), generator=gen) * 2 - 1
+        tr.set_batch(batch)
+        wl = "train.lua inpaintCenter (nBottleneck=%d wtl2=0.999 overlapPred=4) fineSize=128 batchSize=%d/GPU" % (
+            args.nBottleneck, args.batch)
+    else:
+        predLen = 16 if args.workload == "vid16" else 4
+        nc = 3 * predLen
+        opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, predLen=predLen)
+        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn)
+        full = torch.rand((args.batch, nc, 128, 128), generator=gen) * 2 - 1
+        mask = torch.zeros((args.batch, nc, 128, 128), dtype=torch.uint8)
+        mask[:, :, 32:96, 32:96] = 1
+        ctx = full.clone()
+        ctx[mask != 0] = 2 * (110.0 / 255.0) - 1
+        tr.set_batch(ctx, full, mask)
+        wl = "train_vid_weighted.lua predLen=%d (nc=%d) nBottleneck=%d fineSize=128 batchSize=%d/GPU" % (
+            predLen, nc, args.nBottleneck, args.batch)
+
+    use_graph = world == 1 and not args.no_graph
+    if use_graph:
+        tr.capture(warmup=max(args.warmup, 2))
+        run = tr.replay
+        for _ in range(2):
+            run()
+    else:
+        run = tr.step
+        for _ in range(args.warmup):
+            run()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = tr.losses()
+
+    # ---- instrumented pass: per-kernel HIP-event timing of the same workload (eager launches)
+    kernels, roofline = {}, None
+    if rank == 0:
+        B.use_current_stream()
+        nprof = 3
+        B.prof_begin()
+        for _ in range(nprof):
+            tr.step()
+        kernels = B.prof_end()
+        tot = sum(k["ms"] for k in kernels.values())
+        name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = dom["ms"] / dom["launches"]
+        if dom["flops"] > 0:
+            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_us=round(avg_ms * 1e3, 2),
+                            launches_per_step=dom["launches"] / nprof, share_of_step=round(dom["ms"] / tot, 3))
+        else:
+            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, avg_launch_us=round(avg_ms * 1e3, 2),
+                            launches_per_step=dom["launches"] / nprof, share_of_step=round(dom["ms"] / tot, 3))
+        kernels = {k: dict(launches_per_step=v["launches"] / nprof, ms_per_step=round(v["ms"] / nprof, 4),
+                           tflops=(round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 and v["ms"] > 0 else None),
+                           gbs=(round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] > 0 and v["ms"] > 0 else None))
+                   for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+
+    # ---- CPU baseline: the oracle, 1 thread, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        from oracle import oracle as O
+        O.set_num_threads(1)
+        cb = args.cpu_batch
+        if args.workload == "center":
+            ref = O.CenterTrainer(dict(nBottleneck=args.nBottleneck, wtl2=0.999, overlapPred=4), np.random.default_rng(1234))
+            ref.set_batch(O.synth_center_batch(cb, np.random.default_rng(1235)))
+        else:
+            cb = min(cb, 2)
+            predLen = 16 if args.workload == "vid16" else 4
+            ref = O.VidTrainer(dict(nBottleneck=args.nBottleneck, predLen=predLen), np.random.default_rng(1234))
+            ref.set_batch(*O.synth_vid_batch(cb, np.random.default_rng(1235), 3 * predLen))
+        c0 = time.perf_counter()
+        ref.step()
+        cdt = time.perf_counter() - c0
+        cpu = dict(value=round(cb / cdt, 3), unit="images/s", cores=1, kind="port",
+                   sample="1 full iteration (fDx+Adam+fGx+Adam) of the same nets at batchSize=%d, %.1f s" % (cb, cdt))
+
+    if rank == 0:
+        n_img = world * args.batch * args.steps
+        out = {
+            "metric": "netG+netD fwd+bwd images/sec, 128x128 center-mask",
+            "value": round(n_img / dt, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl, "global_batch": world * args.batch, "launch": "hipGraph" if use_graph else "eager",
+                       "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "losses": losses,
+            "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

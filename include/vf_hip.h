@@ -154,6 +154,15 @@ int vf_masked_mse_bwd(vf_ctx* ctx, const float* x, const float* xhat, const uint
 int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                  double beta2, double eps, int32_t* t_dev);
 
+/* ---- per-kernel timers (the reference has three torch.Timers, train.lua:241-243; these are finer) ----
+ * Between vf_prof_begin and vf_prof_end every kernel launch of the library is bracketed by HIP events on the
+ * context's stream.  vf_prof_end synchronises and aggregates per kernel name; vf_prof_get reads entry i:
+ * launches, total milliseconds, and the ALGORITHMIC flops / bytes the launches were asked to do. */
+int vf_prof_begin(vf_ctx* ctx);
+int vf_prof_end(vf_ctx* ctx);
+int vf_prof_count(void);
+int vf_prof_get(int i, char* name, int name_cap, int64_t* launches, double* ms, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

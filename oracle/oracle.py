@@ -466,9 +466,12 @@ def _full(nIn, nOut, s2=True):
     return SpatialFullConvolution(nIn, nOut, 4, 4, 2, 2, 1, 1) if s2 else SpatialFullConvolution(nIn, nOut, 4, 4)
 
 
-def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer):
+def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth=False):
     """train.lua:87-148 (extra_decoder_layer=False, output nc x 64 x 64) and
-    train_vid_weighted.lua:112-176 / train_wholeim_input.lua:137-199 (True, output nc_out x 128 x 128)."""
+    train_vid_weighted.lua:112-176 / train_wholeim_input.lua:137-199 (True, output nc_out x 128 x 128).
+    smooth=True (tests only) replaces every LeakyReLU(0.2)/ReLU by LeakyReLU(1.0): same graph and kernels, but no
+    derivative discontinuity, so gradients can be compared at fp32 precision."""
+    LeakyReLU, ReLU = _acts(smooth)
     netE = Sequential()
     netE.add(_conv(nc_in, nef)).add(LeakyReLU(0.2, True))
     netE.add(_conv(nef, nef)).add(SpatialBatchNormalization(nef)).add(LeakyReLU(0.2, True))
@@ -489,9 +492,16 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer):
     return netG
 
 
-def build_netD(nc, ndf, extra_first_layer):
+def _acts(smooth):
+    if not smooth:
+        return globals()["LeakyReLU"], globals()["ReLU"]
+    return (lambda negval, inplace: globals()["LeakyReLU"](1.0, inplace)), (lambda inplace: globals()["LeakyReLU"](1.0, inplace))
+
+
+def build_netD(nc, ndf, extra_first_layer, smooth=False):
     """train.lua:157-199 (64x64 input) and train_vid_weighted.lua:213-236 (128x128 input,
     extra floor(ndf/2)-wide first layer)."""
+    LeakyReLU, ReLU = _acts(smooth)
     netD = Sequential()
     if extra_first_layer:
         mylayer = ndf // 2
@@ -551,8 +561,8 @@ class CenterTrainer:
         o = dict(DEFAULT_OPT_TRAIN)
         o.update(opt)
         self.opt = o
-        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False)
-        self.netD = build_netD(o["nc"], o["ndf"], False)
+        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, o.get("smooth", False))
+        self.netD = build_netD(o["nc"], o["ndf"], False, o.get("smooth", False))
         weights_init(self.netG, rng)
         weights_init(self.netD, rng)
         self.criterion = BCECriterion()
@@ -652,8 +662,8 @@ class VidTrainer:
         nc = o["nc"] * o["predLen"]
         self.nc_in = o["nc_in"] or nc
         self.nc_out = o["nc_out"] or nc
-        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True)
-        self.netD = build_netD(self.nc_out, o["ndf"], True)
+        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, o.get("smooth", False))
+        self.netD = build_netD(self.nc_out, o["ndf"], True, o.get("smooth", False))
         weights_init(self.netG, rng)
         weights_init(self.netD, rng)
         self.criterion = BCECriterion()

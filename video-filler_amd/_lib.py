@@ -59,6 +59,10 @@ SIGNATURES = {
     "vf_masked_mse_fwd": (i32, [vp, vp, vp, vp, f32, i64, vp]),
     "vf_masked_mse_bwd": (i32, [vp, vp, vp, vp, f32, vp, i64]),
     "vf_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, vp]),
+    "vf_prof_begin": (i32, [vp]),
+    "vf_prof_end": (i32, [vp]),
+    "vf_prof_count": (i32, []),
+    "vf_prof_get": (i32, [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
 }
 
 

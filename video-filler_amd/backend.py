@@ -191,6 +191,21 @@ class HipBackend:
     def adam_step(self, x, g, m, v, lr, beta1, beta2, eps, t_dev):
         self._c("vf_adam_step", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), lr, beta1, beta2, eps, _ptr(t_dev))
 
+    # ---- per-kernel timers
+    def prof_begin(self):
+        self._c("vf_prof_begin")
+
+    def prof_end(self):
+        """-> {kernel name: dict(launches, ms, flops, bytes)}"""
+        self._c("vf_prof_end")
+        out = {}
+        for i in range(self.lib.vf_prof_count()):
+            name = C.create_string_buffer(96)
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _lib.check(self.lib.vf_prof_get(i, name, 96, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return out
+
     def synchronize(self):
         _lib.check(self.lib.vf_stream_synchronize(self.ctx))
 

@@ -28,11 +28,13 @@ static BnGeom bn_geom(int64_t npix, int C) {
   g.cq = cq;
   g.rp = 256 / cq;
   g.gy = (int)vf_cdiv(C4, cq);
-  // <= 64 rows per thread, and no more than ~2048 blocks in total
-  int64_t rpb = (int64_t)g.rp * 64;
-  while (vf_cdiv(npix, rpb) * g.gy > 2048) rpb *= 2;
-  g.rows_per_block = (int)std::min<int64_t>(rpb, std::max<int64_t>(npix, 1));
-  g.gx = (int)vf_cdiv(npix, g.rows_per_block);
+  // HBM-bound: aim at ~2048 blocks (8 per CU) so enough 16-byte loads are in flight; a block walks whole
+  // multiples of its rp row lanes
+  const int64_t gx_target = std::max<int64_t>(1, 2048 / g.gy);
+  int64_t rpb = std::max<int64_t>(g.rp, vf_cdiv(npix, gx_target));
+  rpb = vf_cdiv(rpb, g.rp) * g.rp;
+  g.rows_per_block = (int)rpb;
+  g.gx = (int)vf_cdiv(npix, rpb);
   return g;
 }
 
@@ -74,12 +76,67 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, c
   }
 }
 
-__global__ void k_sum_partials(const double* __restrict__ part, double* __restrict__ sums, int nslab, int twoC) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= twoC) return;
+// second stage: 8 columns x 32 slab lanes per block, fixed combination order (deterministic)
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ part, double* __restrict__ sums, int nslab,
+                                                      int twoC) {
+  const int ci = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + ci;
   double s = 0;
-  for (int k = 0; k < nslab; ++k) s += part[(int64_t)k * twoC + i];
-  sums[i] = s;
+  if (i < twoC)
+    for (int k = lane; k < nslab; k += 32) s += part[(int64_t)k * twoC + i];
+  __shared__ double red[32][8];
+  red[lane][ci] = s;
+  __syncthreads();
+  if (lane == 0 && i < twoC) {
+    double t = 0;
+    for (int j = 0; j < 32; ++j) t += red[j][ci];
+    sums[i] = t;
+  }
+}
+
+// column sums of a row-major [P][C] fp32 matrix (conv bias gradients): gb = beta*gb + sum_p g[p][:]
+__global__ __launch_bounds__(256) void k_colsum4(const float* __restrict__ g, double* __restrict__ part, int64_t P, int C,
+                                                 int cq, int rows_per_block) {
+  const int rp = 256 / cq;
+  const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
+  const int c4 = blockIdx.y * cq + tx;
+  const int C4 = C >> 2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+  f32x4 s = {0, 0, 0, 0};
+  if (c4 < C4)
+    for (int64_t r = r0 + ty; r < r1; r += rp) s += *(const f32x4*)(g + r * C + 4 * c4);
+  __shared__ f32x4 red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ty == 0 && c4 < C4) {
+    double a[4] = {0, 0, 0, 0};
+    for (int j = 0; j < rp; ++j) {
+      const f32x4 u = red[j * cq + tx];
+      for (int e = 0; e < 4; ++e) a[e] += (double)u[e];
+    }
+    double* o = part + (int64_t)blockIdx.x * C;
+    for (int e = 0; e < 4; ++e) o[4 * c4 + e] = a[e];
+  }
+}
+// scalar variant for C % 4 != 0 (C = 3 image channels, C = 1): threads along rows, one column per blockIdx.y
+__global__ __launch_bounds__(256) void k_colsum1(const float* __restrict__ g, double* __restrict__ part, int64_t P, int C,
+                                                 int rows_per_block) {
+  const int c = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(P, r0 + rows_per_block);
+  float s = 0.f;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) s += g[r * C + c];
+  __shared__ double red[256];
+  red[threadIdx.x] = (double)s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(int64_t)blockIdx.x * C + c] = red[0];
+}
+__global__ void k_colsum_final(const double* __restrict__ sums, float* __restrict__ gb, int C, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) gb[c] = (beta != 0.f ? beta * gb[c] : 0.f) + (float)sums[c];
 }
 
 // mean/invstd + running statistics (THNN BatchNormalization_updateOutput, train branch)
@@ -229,8 +286,33 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 
 // ================================================================================================ host
 static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C) {
-  hipLaunchKernelGGL(k_sum_partials, dim3((int)vf_cdiv(2 * C, 256)), dim3(256), 0, ctx->stream, (const double*)ctx->ws,
+  hipLaunchKernelGGL(k_sum_partials, dim3((int)vf_cdiv(2 * C, 8)), dim3(256), 0, ctx->stream, (const double*)ctx->ws,
                      sums, g.gx, 2 * C);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// gb[c] = beta*gb[c] + sum_p g[p][c]  — shared with vf_conv.hip (bias gradients)
+int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C, float beta) {
+  VfProf prof(ctx, "bias_grad", 0.0, 4.0 * (double)P * C);
+  double* part = (double*)ctx->ws;
+  int nslab;
+  if (C % 4 == 0 && (((uintptr_t)g) & 15) == 0) {
+    const BnGeom ge = bn_geom(P, C);
+    nslab = ge.gx;
+    VF_REQUIRE((size_t)(nslab + 1) * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for bias-grad partials");
+    hipLaunchKernelGGL(k_colsum4, dim3(ge.gx, ge.gy), dim3(256), 0, ctx->stream, g, part, P, C, ge.cq, ge.rows_per_block);
+  } else {
+    const int64_t rpb = std::max<int64_t>(256, vf_cdiv(P, std::max(1, 1024 / C)));
+    nslab = (int)vf_cdiv(P, rpb);
+    VF_REQUIRE((size_t)(nslab + 1) * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for bias-grad partials");
+    hipLaunchKernelGGL(k_colsum1, dim3(nslab, C), dim3(256), 0, ctx->stream, g, part, P, C, (int)rpb);
+  }
+  VF_LAUNCH_CHECK();
+  double* sums = part + (int64_t)nslab * C;
+  hipLaunchKernelGGL(k_sum_partials, dim3((int)vf_cdiv(C, 8)), dim3(256), 0, ctx->stream, (const double*)part, sums, nslab, C);
+  VF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_final, dim3((int)vf_cdiv(C, 256)), dim3(256), 0, ctx->stream, (const double*)sums, gb, C, beta);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -239,6 +321,7 @@ VF_API int vf_bn_stats(vf_ctx* ctx, const float* x, const float* shift, double* 
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   const BnGeom g = bn_geom(npix, C);
   VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C);
   hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, shift, (double*)ctx->ws, npix, C, g.cq,
                      g.rows_per_block);
   VF_LAUNCH_CHECK();
@@ -257,6 +340,7 @@ VF_API int vf_bn_apply(vf_ctx* ctx, const float* x, float* y, const float* gamma
                        const float* invstd, int64_t npix, int C, int act, float slope) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   const BnGeom g = bn_geom(npix, C);
+  VfProf prof(ctx, "bn_apply", 0.0, 8.0 * (double)npix * C);
   hipLaunchKernelGGL(k_bn_apply, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y, gamma, beta, mean, invstd, npix, C, g.cq,
                      g.rows_per_block, act, slope);
   VF_LAUNCH_CHECK();
@@ -289,6 +373,7 @@ VF_API int vf_bn_bwd_stats(vf_ctx* ctx, const float* x, const float* y_act, cons
   VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "fused activation backward needs the activated output");
   const BnGeom g = bn_geom(npix, C);
   VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  VfProf prof(ctx, "bn_bwd_stats", 0.0, 4.0 * (double)npix * C * (act != VF_ACT_NONE ? 3 : 2));
   hipLaunchKernelGGL(k_bn_bwd_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, save_mean, (double*)ctx->ws,
                      npix, C, g.cq, g.rows_per_block, act, slope);
   VF_LAUNCH_CHECK();
@@ -300,6 +385,7 @@ VF_API int vf_bn_bwd_apply(vf_ctx* ctx, const float* x, const float* y_act, cons
                            const double* sums, int64_t npix, int64_t n_total, int C, int act, float slope, float pbeta) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   const BnGeom g = bn_geom(npix, C);
+  VfProf prof(ctx, "bn_bwd_apply", 0.0, gx ? 4.0 * (double)npix * C * (act != VF_ACT_NONE ? 4 : 3) : 0.0);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, gx, ggamma, gbeta, gamma,
                      save_mean, save_invstd, sums, npix, (double)n_total, C, g.cq, g.rows_per_block, act, slope, pbeta);
   VF_LAUNCH_CHECK();

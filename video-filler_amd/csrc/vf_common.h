@@ -39,6 +39,20 @@ void vf_set_error(const char* fmt, ...);
 
 #define VF_LAUNCH_CHECK() VF_CHECK_HIP(hipGetLastError())
 
+// per-launch profiling scope (active only between vf_prof_begin / vf_prof_end)
+bool vf_prof_enabled();
+void vf_prof_push(vf_ctx* ctx, const char* name, double flops, double bytes, bool begin);
+struct VfProf {
+  vf_ctx* c;
+  bool on;
+  VfProf(vf_ctx* ctx, const char* name, double flops, double bytes) : c(ctx), on(vf_prof_enabled()) {
+    if (on) vf_prof_push(c, name, flops, bytes, true);
+  }
+  ~VfProf() {
+    if (on) vf_prof_push(c, nullptr, 0, 0, false);
+  }
+};
+
 static inline int vf_ilog2(int v) {  // v must be a power of two
   int l = 0;
   while ((1 << l) < v) ++l;

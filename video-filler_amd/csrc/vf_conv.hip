@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   }
 }
 
-// y = act(sum_s slab[s] + bias)  or  dst = beta*dst + sum_s slab[s]  (wgrad)
+// y = act(sum_s slab[s] + bias)  or  dst = beta*dst + sum_s slab[s]  (wgrad).  Scalar form (any total).
 __global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ dst, const float* __restrict__ bias,
                               int64_t total, int N, int ksplit, int act, float slope, float beta) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -300,6 +300,43 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict_
     if (beta != 0.f) s += beta * dst[i];
     dst[i] = vf_act_apply(s, act, slope);
   }
+}
+// 16-byte form: 64 float4 columns x 4 split lanes per block; lanes are combined in a fixed order.
+__global__ __launch_bounds__(256) void k_slab_reduce4(const float* __restrict__ slab, float* __restrict__ dst,
+                                                      const float* __restrict__ bias, int64_t total4, int N, int ksplit,
+                                                      int act, float slope, float beta) {
+  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i4 = (int64_t)blockIdx.x * 64 + tx;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < total4)
+    for (int k = sl; k < ksplit; k += 4) s += ((const f32x4*)slab)[(int64_t)k * total4 + i4];
+  __shared__ f32x4 red[4][64];
+  red[sl][tx] = s;
+  __syncthreads();
+  if (sl == 0 && i4 < total4) {
+    f32x4 t = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+    if (beta != 0.f) t += beta * ((const f32x4*)dst)[i4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = t[e];
+      if (bias) v += bias[(i4 * 4 + e) % N];
+      t[e] = vf_act_apply(v, act, slope);
+    }
+    ((f32x4*)dst)[i4] = t;
+  }
+}
+static int launch_slab_reduce(vf_ctx* ctx, const float* slab, float* dst, const float* bias, int64_t total, int N, int ksplit,
+                              int act, float slope, float beta) {
+  if (total % 4 == 0 && ((((uintptr_t)slab) | ((uintptr_t)dst)) & 15) == 0 && ksplit > 0) {
+    const int64_t total4 = total / 4;
+    hipLaunchKernelGGL(k_slab_reduce4, dim3((int)vf_cdiv(total4, 64)), dim3(256), 0, ctx->stream, slab, dst, bias, total4, N,
+                       ksplit, act, slope, beta);
+  } else {
+    const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, slab, dst, bias, total, N, ksplit, act, slope, beta);
+  }
+  VF_LAUNCH_CHECK();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,31 +544,6 @@ __global__ void k_dot_bwd_weight(const float* __restrict__ x, const float* __res
   }
 }
 
-// bias gradient: gb[c] = beta*gb[c] + sum_p g[p][c]   (THNN accGradParameters' gradBias; fp32 like THNN)
-__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ g, double* __restrict__ part, int64_t P,
-                                                        int C, int rows_per_block) {
-  // grid.x = row slabs, grid.y = column chunks of 64; thread (tx = col, ty = row lane)
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + tx;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = min(P, r0 + rows_per_block);
-  float s = 0.f;
-  if (c < C)
-    for (int64_t r = r0 + ty; r < r1; r += 4) s += g[r * C + c];
-  __shared__ float red[4][64];
-  red[ty][tx] = s;
-  __syncthreads();
-  if (ty == 0 && c < C)
-    part[(int64_t)blockIdx.x * C + c] = (double)red[0][tx] + (double)red[1][tx] + (double)red[2][tx] + (double)red[3][tx];
-}
-__global__ void k_colsum_final(const double* __restrict__ part, float* __restrict__ gb, int nslab, int C, float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0;
-  for (int i = 0; i < nslab; ++i) s += part[(int64_t)i * C + c];
-  gb[c] = (beta != 0.f ? beta * gb[c] : 0.f) + (float)s;
-}
-
 // ================================================================================================ host
 static int launch_igemm(vf_ctx* ctx, IGemm& g) {
   const int zpar = g.parity ? 4 : 1;
@@ -569,6 +581,10 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g) {
   g.slab = ksplit > 1 ? (float*)ctx->ws : nullptr;
   dim3 grid(gm, gn, zpar * ksplit), block(256);
   const bool bkm = g.wsN == 1 && g.wsC != 1;
+  char pname[64];
+  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s%s", BM, BN, bkm ? "kmajorB" : "rowB", g.parity ? "_parity" : "");
+  {
+  VfProf prof(ctx, pname, 2.0 * (double)g.M * g.N * Ktot * zpar, 0.0);
 #define VF_IGEMM(BM_, BN_, WN_)                                                             \
   do {                                                                                      \
     if (bkm)                                                                                \
@@ -585,13 +601,11 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g) {
   else
     VF_IGEMM(128, 128, 64);
 #undef VF_IGEMM
+  }
   VF_LAUNCH_CHECK();
   if (ksplit > 1) {
-    const int64_t total = g.out_elems;
-    const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, g.slab, g.Y, g.bias, total, g.N, ksplit,
-                       g.act, g.slope, 0.f);
-    VF_LAUNCH_CHECK();
+    VfProf prof(ctx, "slab_reduce_igemm", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+    return launch_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, 0.f);
   }
   return 0;
 }
@@ -723,32 +737,24 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.ksplit = ksplit;
   g.slab = ksplit > 1 ? (float*)ctx->ws : nullptr;
   dim3 grid(gx, gy, ksplit), block(256);
-  if (BM == 128)
-    hipLaunchKernelGGL((k_wgrad<128>), grid, block, 0, ctx->stream, g);
-  else
-    hipLaunchKernelGGL((k_wgrad<64>), grid, block, 0, ctx->stream, g);
+  {
+    VfProf prof(ctx, BM == 128 ? "wgrad_128x128" : "wgrad_64x128", 2.0 * (double)g.P * Nu * 16.0 * Cv, 0.0);
+    if (BM == 128)
+      hipLaunchKernelGGL((k_wgrad<128>), grid, block, 0, ctx->stream, g);
+    else
+      hipLaunchKernelGGL((k_wgrad<64>), grid, block, 0, ctx->stream, g);
+  }
   VF_LAUNCH_CHECK();
   if (ksplit > 1) {
-    const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, g.slab, dW, (const float*)nullptr, total, 1,
-                       ksplit, (int)VF_ACT_NONE, 0.f, beta);
-    VF_LAUNCH_CHECK();
+    VfProf prof(ctx, "slab_reduce_wgrad", 0.0, 4.0 * (double)total * (ksplit + 1));
+    return launch_slab_reduce(ctx, g.slab, dW, nullptr, total, 1, ksplit, VF_ACT_NONE, 0.f, beta);
   }
   return 0;
 }
 
+int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C, float beta);  // vf_bn.hip
 static int bias_grad(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C, float beta) {
-  const int rows_per_block = 256;
-  int nslab = (int)vf_cdiv(P, rows_per_block);
-  VF_REQUIRE((size_t)nslab * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for bias-grad partials");
-  double* part = (double*)ctx->ws;
-  hipLaunchKernelGGL(k_colsum_partial, dim3(nslab, (int)vf_cdiv(C, 64)), dim3(256), 0, ctx->stream, g, part, P, C,
-                     rows_per_block);
-  VF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_colsum_final, dim3((int)vf_cdiv(C, 256)), dim3(256), 0, ctx->stream, (const double*)part, gb, nslab,
-                     C, beta);
-  VF_LAUNCH_CHECK();
-  return 0;
+  return vf_internal_colsum(ctx, g, gb, P, C, beta);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI

@@ -75,6 +75,84 @@ VF_API int vf_zero(vf_ctx* ctx, void* ptr, size_t bytes) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ profiling
+#include <map>
+#include <string>
+#include <vector>
+struct ProfRec {
+  std::string name;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
+struct ProfAgg {
+  std::string name;
+  int64_t launches;
+  double ms, flops, bytes;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<ProfAgg> g_prof_agg;
+bool vf_prof_enabled() { return g_prof_on; }
+void vf_prof_push(vf_ctx* ctx, const char* name, double flops, double bytes, bool begin) {
+  if (begin) {
+    ProfRec r;
+    r.name = name;
+    r.flops = flops;
+    r.bytes = bytes;
+    hipEventCreate(&r.e0);
+    hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, ctx->stream);
+    g_prof_recs.push_back(r);
+  } else if (!g_prof_recs.empty()) {
+    hipEventRecord(g_prof_recs.back().e1, ctx->stream);
+  }
+}
+VF_API int vf_prof_begin(vf_ctx* ctx) {
+  VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  g_prof_recs.clear();
+  g_prof_agg.clear();
+  g_prof_on = true;
+  return 0;
+}
+VF_API int vf_prof_end(vf_ctx* ctx) {
+  g_prof_on = false;
+  VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  std::map<std::string, size_t> idx;
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    auto it = idx.find(r.name);
+    if (it == idx.end()) {
+      idx[r.name] = g_prof_agg.size();
+      g_prof_agg.push_back({r.name, 0, 0.0, 0.0, 0.0});
+      it = idx.find(r.name);
+    }
+    ProfAgg& a = g_prof_agg[it->second];
+    a.launches += 1;
+    a.ms += ms;
+    a.flops += r.flops;
+    a.bytes += r.bytes;
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  g_prof_recs.clear();
+  return 0;
+}
+VF_API int vf_prof_count(void) { return (int)g_prof_agg.size(); }
+VF_API int vf_prof_get(int i, char* name, int name_cap, int64_t* launches, double* ms, double* flops, double* bytes) {
+  VF_REQUIRE(i >= 0 && i < (int)g_prof_agg.size(), "vf_prof_get: index %d out of range", i);
+  const ProfAgg& a = g_prof_agg[i];
+  if (name && name_cap > 0) {
+    strncpy(name, a.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (launches) *launches = a.launches;
+  if (ms) *ms = a.ms;
+  if (flops) *flops = a.flops;
+  if (bytes) *bytes = a.bytes;
+  return 0;
+}
+
 static inline int grid_for(int64_t n, int per_thread = 4) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(vf_cdiv(n, 256 * (int64_t)per_thread), 2048));
 }
@@ -163,6 +241,9 @@ static int launch_pw(vf_ctx* ctx, const float* a, const float* b, const float* c
   if (n <= 0) return 0;
   VF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0,
              "pointwise operands must be 16-byte aligned");
+  static const char* names[] = {"pw_act_fwd", "pw_act_bwd", "pw_axpby", "pw_cmul", "pw_scale_shift", "pw_compose", "pw_mse_bwd"};
+  const int nops = (a != nullptr) + (b != nullptr) + (c != nullptr) + 1 + ((OP == OP_AXPBY || OP == OP_CMUL || OP == OP_SCALE_SHIFT) ? 1 : 0);
+  VfProf prof(ctx, names[OP], 0.0, 4.0 * (double)n * nops);
   hipLaunchKernelGGL((k_pointwise<OP>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, a, b, c, out, n, f0, f1, act);
   VF_LAUNCH_CHECK();
   return 0;
@@ -261,6 +342,7 @@ __global__ __launch_bounds__(256) void k_mse_fwd(const float* __restrict__ x, co
 }
 VF_API int vf_mse_fwd(vf_ctx* ctx, const float* x, const float* t, int64_t n, double* loss) {
   VF_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+  VfProf prof(ctx, "mse_fwd", 0.0, 8.0 * (double)n);
   hipLaunchKernelGGL(k_mse_fwd, dim3(grid_for(n, 16)), dim3(256), 0, ctx->stream, x, t, n, 1.0 / (double)n, loss);
   VF_LAUNCH_CHECK();
   return 0;
@@ -294,6 +376,7 @@ __global__ __launch_bounds__(256) void k_recon_grad_mix(float* __restrict__ dfdg
 VF_API int vf_recon_grad_mix(vf_ctx* ctx, float* df_dg, const float* x, const float* t, const float* mask, float alpha,
                              float c0, float c1, int band, int HW, int C, int64_t n, double* loss) {
   VF_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double), ctx->stream));
+  VfProf prof(ctx, "recon_grad_mix", 0.0, 4.0 * (double)n * (mask ? 5 : 4));
   hipLaunchKernelGGL(k_recon_grad_mix, dim3(grid_for(n, 8)), dim3(256), 0, ctx->stream, df_dg, x, t, mask, alpha, c0, c1, band,
                      HW, C, n, 2.f / (float)n, 1.0 / (double)n, loss);
   VF_LAUNCH_CHECK();
@@ -410,6 +493,7 @@ VF_API int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* 
   VF_REQUIRE((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam operands must be 16-byte aligned");
   hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, ctx->stream, t_dev, lr, beta1, beta2);
   VF_LAUNCH_CHECK();
+  VfProf prof(ctx, "adam", 0.0, 28.0 * (double)n);
   hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 4)), dim3(256), 0, ctx->stream, x, g, m, v, n, (float)beta1, (float)(1.0 - beta1),
                      (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
   VF_LAUNCH_CHECK();

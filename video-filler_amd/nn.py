@@ -516,9 +516,18 @@ class Sequential(Module):
 # ---------------------------------------------------------------------------------------------- criteria
 class _Criterion:
     def __init__(self):
-        self._loss = get_backend().zeros(1, dtype=torch.float64)
+        # ring of device loss slots: each forward() writes the next one, so a value returned earlier in the
+        # iteration (errD_real) is still readable after later evaluations (errD_fake, errG); a captured graph
+        # replays into the slots it was captured with.
+        self._slots = get_backend().zeros(16, dtype=torch.float64)
+        self._i = 0
         self.gradInput = None
         self.output = None
+
+    def next_slot(self):
+        t = self._slots[self._i:self._i + 1]
+        self._i = (self._i + 1) % self._slots.numel()
+        return t
 
     def cuda(self):
         return self
@@ -533,8 +542,9 @@ class BCECriterion(_Criterion):
     """nn.BCECriterion() — train.lua:204.  `target` is the constant the reference fills `label` with."""
 
     def forward(self, input, target):
-        get_backend().bce_fwd(input, float(target), self._loss)
-        self.output = DeviceScalar.of(self._loss)
+        slot = self.next_slot()
+        get_backend().bce_fwd(input, float(target), slot)
+        self.output = DeviceScalar.of(slot)
         return self.output
 
     def backward(self, input, target):
@@ -547,8 +557,9 @@ class MSECriterion(_Criterion):
     """nn.MSECriterion() — train.lua:207."""
 
     def forward(self, input, target):
-        get_backend().mse_fwd(to_nhwc(input), to_nhwc(target), self._loss)
-        self.output = DeviceScalar.of(self._loss)
+        slot = self.next_slot()
+        get_backend().mse_fwd(to_nhwc(input), to_nhwc(target), slot)
+        self.output = DeviceScalar.of(slot)
         return self.output
 
     def backward(self, input, target):
@@ -565,8 +576,9 @@ class GDLCriterion(_Criterion):
         assert alpha == 1  # gdl_criterion.lua:9
 
     def forward(self, input, target):
-        get_backend().gdl_fwd(to_nhwc(input), to_nhwc(target), self._loss)
-        self.output = DeviceScalar.of(self._loss)
+        slot = self.next_slot()
+        get_backend().gdl_fwd(to_nhwc(input), to_nhwc(target), slot)
+        self.output = DeviceScalar.of(slot)
         return self.output
 
 
@@ -583,8 +595,9 @@ class MaskedMSECriterion(_Criterion):
         self.mask = m if m.dim() != 4 else to_nhwc(m)
 
     def forward(self, input, target):
-        get_backend().masked_mse_fwd(to_nhwc(input), to_nhwc(target), self.mask, self.mWeight, self._loss)
-        self.output = DeviceScalar.of(self._loss)
+        slot = self.next_slot()
+        get_backend().masked_mse_fwd(to_nhwc(input), to_nhwc(target), self.mask, self.mWeight, slot)
+        self.output = DeviceScalar.of(slot)
         return self.output
 
     def backward(self, input, target):

@@ -48,9 +48,18 @@ def _full(nIn, nOut, s2=True):
     return nn.SpatialFullConvolution(nIn, nOut, 4, 4, 2, 2, 1, 1) if s2 else nn.SpatialFullConvolution(nIn, nOut, 4, 4)
 
 
-def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=True, lazy_zero=True):
+def _acts(smooth):
+    """smooth=True is a parity-test aid: every LeakyReLU(0.2)/ReLU becomes LeakyReLU(1.0) — same graph, same
+    kernels, no derivative discontinuity (tests/test_gpu_trainers.py explains why)."""
+    if not smooth:
+        return nn.LeakyReLU, nn.ReLU
+    return (lambda negval, inplace: nn.LeakyReLU(1.0, inplace)), (lambda inplace: nn.LeakyReLU(1.0, inplace))
+
+
+def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=True, lazy_zero=True, smooth=False):
     """train.lua:87-148 (64x64 output) / train_vid_weighted.lua:112-176 (extra ngf->ngf layer, 128x128 output)."""
-    BN, LReLU, ReLU = nn.SpatialBatchNormalization, nn.LeakyReLU, nn.ReLU
+    BN = nn.SpatialBatchNormalization
+    LReLU, ReLU = _acts(smooth)
     netE = nn.Sequential(fuse, lazy_zero)
     netE.add(_conv(nc_in, nef)).add(LReLU(0.2, True))
     netE.add(_conv(nef, nef)).add(BN(nef)).add(LReLU(0.2, True))
@@ -71,9 +80,10 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=T
     return netG
 
 
-def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True):
+def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True, smooth=False):
     """train.lua:157-199 (64x64 input) / train_vid_weighted.lua:213-236 (extra floor(ndf/2) layer, 128x128 input)."""
-    BN, LReLU = nn.SpatialBatchNormalization, nn.LeakyReLU
+    BN = nn.SpatialBatchNormalization
+    LReLU, _ = _acts(smooth)
     netD = nn.Sequential(fuse, lazy_zero)
     if extra_first_layer:
         mylayer = ndf // 2
@@ -175,8 +185,9 @@ class CenterTrainer(_TrainerBase):
         o = dict(DEFAULT_OPT_TRAIN)
         o.update(opt or {})
         self.opt = o
-        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, fuse, lazy_zero)
-        self.netD = build_netD(o["nc"], o["ndf"], False, fuse, lazy_zero)
+        sm = bool(o.get("smooth", False))
+        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, fuse, lazy_zero, sm)
+        self.netD = build_netD(o["nc"], o["ndf"], False, fuse, lazy_zero, sm)
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads)
         self.real_label, self.fake_label = 1, 0
@@ -244,9 +255,9 @@ class CenterTrainer(_TrainerBase):
                 c0, c1, band = wt, 0.0, 0
             else:
                 c0, c1, band = wt, 10 * wt - wt, ov          # inside: wtl2 ; border band: 10*wtl2
-            B.recon_grad_mix(df_dg, self.input_center, self.input_real_center, None, alpha, c0, c1, band,
-                             self.criterionMSE._loss)
-            self.errG_l2 = nn.DeviceScalar.of(self.criterionMSE._loss)
+            slot = self.criterionMSE.next_slot()
+            B.recon_grad_mix(df_dg, self.input_center, self.input_real_center, None, alpha, c0, c1, band, slot)
+            self.errG_l2 = nn.DeviceScalar.of(slot)
             errG_total = (alpha if (0 < wt < 1) else 1.0) * self.errG + wt * self.errG_l2
         self.netG.backward(self.input_ctx, df_dg, need_input_grad=not self.skip_dead_grads)
         self._allreduce_avg(self.gradParametersG)
@@ -264,8 +275,9 @@ class VidTrainer(_TrainerBase):
         nc = o["nc"] * o["predLen"]
         self.nc_in = o["nc_in"] or nc
         self.nc_out = o["nc_out"] or nc
-        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, fuse, lazy_zero)
-        self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero)
+        sm = bool(o.get("smooth", False))
+        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, fuse, lazy_zero, sm)
+        self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero, sm)
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self.criterionGDL = nn.GDLCriterion(1) if o["wtgdl"] != 0 else None
         self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads)
@@ -337,9 +349,9 @@ class VidTrainer(_TrainerBase):
                 c0, c1, mask = wt * lam + wtgdl, wt * (1 - lam), self.input_mask
                 # the reference also rewrites input_mask in place into the weights (:494); nothing reads it
                 # again before the next fDx overwrites it, so the fused pass leaves it untouched.
-            B.recon_grad_mix(df_dg, self.input_inpainted, self.input_real, mask, alpha, c0, c1, 0,
-                             self.criterionMSE._loss)
-            self.errG_l2 = nn.DeviceScalar.of(self.criterionMSE._loss)
+            slot = self.criterionMSE.next_slot()
+            B.recon_grad_mix(df_dg, self.input_inpainted, self.input_real, mask, alpha, c0, c1, 0, slot)
+            self.errG_l2 = nn.DeviceScalar.of(slot)
             errG_total = (alpha if (0 < wt < 1) else 1.0) * self.errG + wt * self.errG_l2
         elif wtgdl != 0:
             raise RuntimeError("wtgdl ~= 0 with wtl2 == 0 indexes a nil criterionMSE in the reference (:525)")
