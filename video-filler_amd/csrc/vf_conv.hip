@@ -14,16 +14,32 @@
 //   k_wgrad  dW[n][tap][c] = sum_p U(p,n) * V(p,tap,c), split over pixels p
 //            - conv / full-conv accGradParameters (the two differ only in which tensor is x and which is gy)
 //
-// Tiles: 256 threads = 4 waves, each wave 64 x {64,32} of 32x32 MFMA tiles, BK = 16, LDS double-buffered,
-// register-staged global->LDS copies (the f32 matrix core needs 64 cycles per 32x32x2, so the MFMA pipe is the
-// bottleneck, not staging).  Grid.z carries output parity and split-K; split-K partial slabs are combined by
-// k_slab_reduce in a fixed order (deterministic; no float atomics).
+// Tiles: 256 threads = 4 waves of 32x32 MFMA tiles, BK = 16, LDS double-buffered, register-staged
+// global->LDS copies.  All global loads are UNCONDITIONAL (out-of-range lanes read element 0 and are zeroed by a
+// select) so the compiler keeps every load of tile k+1 in flight across the MFMAs of tile k and waits once,
+// before the LDS write.  Grid.z carries output parity and split-K; split-K partial slabs are combined by
+// k_slab_reduce4 in a fixed order (deterministic; no float atomics).
 #include <algorithm>
+#include <cstdlib>
 
 #include "vf_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer loads with hardware range checking: an offset past num_records returns 0, so padding taps, ragged
+// tile edges and split-K tails need neither a branch nor a select — the loads stay in flight across the MFMAs.
+#define VF_OOB 0x80000000u   // byte offset that is always out of range (operands are < 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vf_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 vf_bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float vf_bload1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
 
 // ------------------------------------------------------------------------------------------------
 struct IGemm {
@@ -33,35 +49,40 @@ struct IGemm {
   float* Y;           // output [B][outH][outW][N]
   float* slab;        // split-K partials, ksplit x (output-sized) ; null when ksplit == 1
   int64_t out_elems;  // B*outH*outW*N
+  unsigned a_bytes, w_bytes;  // operand sizes for the buffer descriptors (< 2 GiB each)
   int M, lgMh, lgMw;  // GEMM rows = B << (lgMh+lgMw), decoded as (b, my, mx)
   int Hi, Wi, C;
   int N;
   int TH, TW;                      // taps walked by the K loop
   int sy, ty, oy0, sx, tx, ox0;    // iy = my*sy + th*ty + oy0 (+ph in parity mode)
   int kh0, khs, kw0, kws;          // filter tap (kh, kw) = (kh0 + th*khs, kw0 + tw*kws)
-  int64_t wsN, wsC, wsTap;         // weight offset = n*wsN + (kh*4+kw)*wsTap + c*wsC
+  int wsN, wsC, wsTap;             // weight offset = n*wsN + (kh*4+kw)*wsTap + c*wsC   (all tensors < 2^31 elements)
   int outH, outW, osy, ooy0, osx, oox0;  // output pixel = (my*osy + ooy0, mx*osx + oox0)
   int parity;                      // 1: z&3 = (ph<<1)|pw shifts oy0/ox0/ooy0/oox0 and selects kh0/kw0
-  int ksplit, nk;                  // K steps total and number of splits
-  int vecA, vecB;                  // 16-byte load paths legal
+  int ksplit, nk, nq;              // K steps (of 32), number of splits, 16-wide chunks on the vector path
+  int dbg;                         // ablation switches (timing experiments only; wrong results): 1 no reload, 2 no LDS restage
   int act;
   float slope;
 };
 
-template <int BM, int BN, int WN, bool BKM>
+// V = 2: 16-byte loads for A and B (C % 16 == 0);  V = 1: 16-byte A, scalar B (k-major B with N % 4 != 0);
+// V = 0: scalar loads with a flattened (tap, c) K index (first/last layers: C = 3, 12, 27 ...).
+template <int BM, int BN, int WM, int WN, bool BKM, int V>
 __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
-  constexpr int BK = 16, LDA = 20;
-  constexpr int LDB = BKM ? (BN + 4) : 20;
-  constexpr int NT = WN / 32;
+  // One K step = 32 = two 16-wide chunks; each chunk has its own (tap, c0), so any C % 16 == 0 vectorises.
+  constexpr int BK = 32, LDA = BK + 4;
+  constexpr int LDB = BKM ? (BN + 4) : BK + 4;
+  constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
-  constexpr int A_CH = BM / 64;
-  constexpr int B_CH = (BN * 4 + 255) / 256;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+  constexpr int A_CH = (BM * 8 + 255) / 256;
+  constexpr int B_CH = (BN * 8 + 255) / 256;
   constexpr int A_SZ = BM * LDA;
   constexpr int B_SZ = BKM ? BK * LDB : BN * LDB;
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   int z = blockIdx.z;
   int ph = 0, pw = 0;
@@ -78,116 +99,150 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   const int kh0 = p.parity ? (1 - ph) : p.kh0, kw0 = p.parity ? (1 - pw) : p.kw0;
   const int ooy0 = p.ooy0 + ph, oox0 = p.oox0 + pw;
   const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
-  const int ntaps = p.TH * p.TW;
-  const int Ktot = ntaps * p.C;
-  const int spt = p.vecA ? (p.C >> 4) : 1;  // K steps per tap on the chunked path
+  const int Ktot = p.TH * p.TW * p.C;
+  const int spt = p.C >> 4;  // K steps per tap on the chunked (V >= 1) path
 
   // ---- per-thread A rows (fixed for the whole K loop)
-  int a_iy0[A_CH], a_ix0[A_CH];
-  int64_t a_boff[A_CH];
+  int a_iy0[A_CH], a_ix0[A_CH], a_boff[A_CH];
   bool a_ok[A_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
-    const int row = (tid + 256 * i) >> 2;
-    const int m = m0 + row;
-    a_ok[i] = m < p.M;
+    const int id = tid + 256 * i;
+    const int m = m0 + (id >> 3);
+    a_ok[i] = (id < BM * 8) && m < p.M;
     const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
     a_iy0[i] = my * p.sy + oy0;
     a_ix0[i] = mx * p.sx + ox0;
-    a_boff[i] = (int64_t)b * p.Hi * p.Wi * p.C;
+    a_boff[i] = b * p.Hi * p.Wi * p.C;
   }
-  const int kq = tid & 3;
+  const int kq = tid & 7;          // 16-byte column of the 32-wide K step
+  const int kh = kq >> 2, kl = kq & 3;  // chunk (0/1) and 16-byte column inside the chunk
 
   f32x4 ra[A_CH], rb[B_CH];
+  const __amdgpu_buffer_rsrc_t rsA = vf_rsrc(p.A, p.a_bytes), rsW = vf_rsrc(p.Wt, p.w_bytes);
+
+  auto tap_index = [&](int tap) {
+    const int th = tap / p.TW, tw = tap - th * p.TW;
+    return (kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws);
+  };
+
+  // ---- vector path (V >= 1): everything that depends on the K step is wave-uniform (SALU); a lane only adds a
+  // per-step delta to byte offsets it computed once, and tests one bit of its per-row tap-validity mask.
+  unsigned a_mask[A_CH];   // bit t: tap t of this row is inside the image
+  unsigned a_byte[A_CH];   // byte offset of (tap (0,0), c = 4*kl) for this row (wraps for padding rows; masked)
+  unsigned w_byte[B_CH];   // per-thread weight byte offset at (tap 0, c0 = 0)
+  bool w_ok[B_CH];
+  if constexpr (V >= 1) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      a_byte[i] = 4u * (unsigned)(a_boff[i] + (a_iy0[i] * p.Wi + a_ix0[i]) * p.C + 4 * kl);
+      unsigned mk = 0;
+      for (int t = 0; t < p.TH * p.TW; ++t) {
+        const int th = t / p.TW, tw = t - th * p.TW;
+        const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
+        if (a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mk |= 1u << t;
+      }
+      a_mask[i] = mk;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int id = tid + 256 * i;
+      if constexpr (!BKM) {
+        const int n = n0 + (id >> 3);
+        w_ok[i] = id < BN * 8 && n < p.N;
+        w_byte[i] = 4u * (unsigned)(n * p.wsN + 4 * kl);
+      } else {
+        const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
+        const int n = n0 + 4 * nq;
+        w_ok[i] = id < BN * 8 && n < p.N;
+        w_byte[i] = 4u * (unsigned)((kk & 15) * p.wsC + n);
+      }
+    }
+  }
+  // uniform description of one 16-wide chunk q: (tap, byte delta for A, byte delta for W, in range)
+  struct Chunk { int tap; unsigned dA, dW; bool ok; };
+  auto chunk_of = [&](int q) {
+    Chunk c;
+    const int tap = q / spt, c0 = (q - tap * spt) << 4;
+    const int th = tap / p.TW, tw = tap - th * p.TW;
+    c.tap = tap;
+    c.dA = 4u * (unsigned)((th * p.ty * p.Wi + tw * p.tx) * p.C + c0);
+    c.dW = 4u * (unsigned)(((kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws)) * p.wsTap + c0 * (BKM ? p.wsC : 1));
+    c.ok = q < p.nq;
+    return c;
+  };
 
   auto load_tile = [&](int kt) {
-    // ---------------- A
-    if (p.vecA) {
-      const int tap = kt / spt, c0 = (kt - tap * spt) << 4;
-      const int th = tap / p.TW, tw = tap - th * p.TW;
+    if constexpr (V >= 1) {
+      const Chunk c0 = chunk_of(2 * kt), c1 = chunk_of(2 * kt + 1);   // SALU
+      // ---------------- A: lanes with kh = 0 / 1 fetch chunk 0 / 1
+      const int tapv = kh ? c1.tap : c0.tap;
+      const unsigned dA = kh ? c1.dA : c0.dA;
+      const bool okq = kh ? c1.ok : c0.ok;
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
-        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = *(const f32x4*)(p.A + a_boff[i] + ((int64_t)iy * p.Wi + ix) * p.C + c0 + 4 * kq);
-        ra[i] = v;
+        const bool ok = okq && ((a_mask[i] >> tapv) & 1u);
+        ra[i] = vf_bload4(rsA, ok ? a_byte[i] + dA : VF_OOB);
+      }
+      // ---------------- B
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) {
+        bool hi;
+        if constexpr (!BKM) {
+          hi = kh;
+        } else {
+          hi = (((tid + 256 * i) / (BN / 4)) >> 4) & 1;
+        }
+        const unsigned dW = hi ? c1.dW : c0.dW;
+        const bool ok = w_ok[i] && (hi ? c1.ok : c0.ok);
+        if constexpr (V == 2) {
+          rb[i] = vf_bload4(rsW, ok ? w_byte[i] + dW : VF_OOB);
+        } else {   // V == 1: k-major B whose N is not a multiple of 4 -> four scalar loads along n
+          const int n = n0 + 4 * ((tid + 256 * i) % (BN / 4));
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = vf_bload1(rsW, (ok && n + j < p.N) ? w_byte[i] + dW + 4u * j : VF_OOB);
+          rb[i] = v;
+        }
       }
     } else {
+      // ---------------- scalar path: flattened K index, per-element (tap, c)
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int k = kt * BK + 4 * kq + j;
-          if (a_ok[i] && k < Ktot) {
-            const int tap = k / p.C, c = k - tap * p.C;
-            const int th = tap / p.TW, tw = tap - th * p.TW;
-            const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
-            if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-              v[j] = p.A[a_boff[i] + ((int64_t)iy * p.Wi + ix) * p.C + c];
-          }
+          const int tap = k / p.C, c = k - tap * p.C;
+          const int th = tap / p.TW, tw = tap - th * p.TW;
+          const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
+          const bool ok = a_ok[i] && k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+          v[j] = vf_bload1(rsA, ok ? 4u * (unsigned)(a_boff[i] + (iy * p.Wi + ix) * p.C + c) : VF_OOB);
         }
         ra[i] = v;
       }
-    }
-    // ---------------- B
-    if constexpr (!BKM) {
-      // rows n, k contiguous (wsC == 1)
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) {
         const int id = tid + 256 * i;
-        const int n = n0 + (id >> 2);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (id < BN * 4 && n < p.N) {
-          if (p.vecA && p.vecB) {
-            const int tap = kt / spt, c0 = (kt - tap * spt) << 4;
-            const int th = tap / p.TW, tw = tap - th * p.TW;
-            const int tapidx = (kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws);
-            v = *(const f32x4*)(p.Wt + (int64_t)n * p.wsN + (int64_t)tapidx * p.wsTap + c0 + 4 * kq);
-          } else {
+        f32x4 v;
+        if constexpr (!BKM) {
+          const int n = n0 + (id >> 3);
+          const bool okn = id < BN * 8 && n < p.N;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int k = kt * BK + 4 * kq + j;
-              if (k < Ktot) {
-                const int tap = k / p.C, c = k - tap * p.C;
-                const int th = tap / p.TW, tw = tap - th * p.TW;
-                const int tapidx = (kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws);
-                v[j] = p.Wt[(int64_t)n * p.wsN + (int64_t)tapidx * p.wsTap + (int64_t)c * p.wsC];
-              }
-            }
+          for (int j = 0; j < 4; ++j) {
+            const int k = kt * BK + 4 * kq + j;
+            const int tap = k / p.C, c = k - tap * p.C;
+            v[j] = vf_bload1(rsW, (okn && k < Ktot) ? 4u * (unsigned)(n * p.wsN + tap_index(tap) * p.wsTap + c * p.wsC) : VF_OOB);
           }
-        }
-        rb[i] = v;
-      }
-    } else {
-      // n contiguous (wsN == 1): one float4 covers 4 consecutive n at one k
+        } else {
+          const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
+          const int n = n0 + 4 * nq;
+          const int k = kt * BK + kk;
+          const int tap = k / p.C, c = k - tap * p.C;
+          const bool okk = id < BN * 8 && k < Ktot;
+          const int base = tap_index(tap) * p.wsTap + c * p.wsC;
 #pragma unroll
-      for (int i = 0; i < B_CH; ++i) {
-        const int id = tid + 256 * i;
-        const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
-        const int n = n0 + 4 * nq;
-        const int k = kt * BK + kk;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (id < BN * 4 && k < Ktot && n < p.N) {
-          int tap, c;
-          if (p.vecA) {
-            tap = kt / spt;
-            c = ((kt - tap * spt) << 4) + kk;
-          } else {
-            tap = k / p.C;
-            c = k - tap * p.C;
-          }
-          const int th = tap / p.TW, tw = tap - th * p.TW;
-          const int tapidx = (kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws);
-          const float* src = p.Wt + (int64_t)tapidx * p.wsTap + (int64_t)c * p.wsC + n;
-          if (p.vecB) {
-            v = *(const f32x4*)src;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (n + j < p.N) v[j] = src[j];
-          }
+          for (int j = 0; j < 4; ++j) v[j] = vf_bload1(rsW, (okk && n + j < p.N) ? 4u * (unsigned)(base + n + j) : VF_OOB);
         }
         rb[i] = v;
       }
@@ -199,15 +254,15 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     float* Bs = As + A_SZ;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      const int row = (tid + 256 * i) >> 2;
-      *(f32x4*)(As + row * LDA + 4 * kq) = ra[i];
+      const int id = tid + 256 * i;
+      if (id < BM * 8) *(f32x4*)(As + (id >> 3) * LDA + 4 * kq) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int id = tid + 256 * i;
-      if (id < BN * 4) {
+      if (id < BN * 8) {
         if constexpr (!BKM) {
-          *(f32x4*)(Bs + (id >> 2) * LDB + 4 * kq) = rb[i];
+          *(f32x4*)(Bs + (id >> 3) * LDB + 4 * kq) = rb[i];
         } else {
           const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
           *(f32x4*)(Bs + kk * LDB + 4 * nq) = rb[i];
@@ -216,9 +271,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     }
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -232,15 +287,15 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   }
   __syncthreads();
   for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tile(kt + 1);
+    const int buf = (p.dbg & 2) ? 0 : ((kt - kt0) & 1);
+    if (kt + 1 < kt1 && !(p.dbg & 1)) load_tile(kt + 1);
     const float* As = smem + buf * (A_SZ + B_SZ);
     const float* Bs = As + A_SZ;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      f32x4 a[2], b[NT];
+    for (int s = 0; s < BK / 8; ++s) {
+      f32x4 a[MT], b[NT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)(As + (wm + mt * 32 + lr) * LDA + 8 * s + 4 * lh);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(As + (wm + mt * 32 + lr) * LDA + 8 * s + 4 * lh);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if constexpr (!BKM) {
@@ -253,20 +308,28 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
     }
-    if (kt + 1 < kt1) store_tile(buf ^ 1);
-    __syncthreads();
+    if (!(p.dbg & 2)) {
+      if (kt + 1 < kt1) store_tile(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
   const bool fin = p.ksplit == 1;
+  float bv[NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + wn + nt * 32 + lr;
+    bv[nt] = (fin && p.bias && n < p.N) ? p.bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -279,10 +342,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
         const int n = n0 + wn + nt * 32 + lr;
         if (n < p.N) {
           float v = acc[mt][nt][r];
-          if (fin) {
-            if (p.bias) v += p.bias[n];
-            v = vf_act_apply(v, p.act, p.slope);
-          }
+          if (fin) v = vf_act_apply(v + bv[nt], p.act, p.slope);
           out[pix * p.N + n] = v;
         }
       }
@@ -308,8 +368,10 @@ __global__ __launch_bounds__(256) void k_slab_reduce4(const float* __restrict__ 
   const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int64_t i4 = (int64_t)blockIdx.x * 64 + tx;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (i4 < total4)
+  if (i4 < total4) {
+#pragma unroll 4
     for (int k = sl; k < ksplit; k += 4) s += ((const f32x4*)slab)[(int64_t)k * total4 + i4];
+  }
   __shared__ f32x4 red[4][64];
   red[sl][tx] = s;
   __syncthreads();
@@ -345,15 +407,16 @@ struct WGrad {
   const float* V;   // gathered operand on the HIGH-res grid: [B][Hv][Wv][Cv]
   float* dW;        // [Nu][16][Cv]
   float* slab;
+  unsigned u_bytes, v_bytes;
   int P, lgMh, lgMw;
   int Nu, Cv, Hv, Wv;
   int stride, pad;  // iy = my*stride - pad + kh
   int ksplit, nk;   // nk = ceil(P/16)
-  int vecU, vecV;
   float beta;
 };
 
-template <int BM>  // BM over n (64 or 128); BN = 128 columns (tap,c)
+// BM over n (64 or 128); BN = 128 columns (tap,c).  VU / VV: 16-byte loads legal for U / V.
+template <int BM, bool VU, bool VV>
 __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   constexpr int BN = 128, BK = 16;
   constexpr int LDU = BM + 4, LDV = BN + 4;
@@ -387,51 +450,48 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
     v_dy[j] = (tap >> 2) - p.pad;
     v_dx[j] = (tap & 3) - p.pad;
   }
-  const int uq = tid % (BM / 4), ukk = tid / (BM / 4);  // U: 4 consecutive n at pixel row ukk (+ 256/(BM/4) per chunk)
+  const int uq = tid % (BM / 4), ukk = tid / (BM / 4);  // U: 4 consecutive n at pixel row ukk (+ 1024/BM per chunk)
+  const int un = n0 + 4 * uq;
 
   f32x4 ru[U_CH], rv[V_CH];
+  const __amdgpu_buffer_rsrc_t rsU = vf_rsrc(p.U, p.u_bytes), rsV = vf_rsrc(p.V, p.v_bytes);
 
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < U_CH; ++i) {
-      const int kk = ukk + i * (1024 / BM);
-      const int pp = kt * BK + kk;
-      const int n = n0 + 4 * uq;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pp < p.P && n < p.Nu) {
-        const float* src = p.U + (int64_t)pp * p.Nu + n;
-        if (p.vecU) {
-          v = *(const f32x4*)src;
-        } else {
+      const int pp = kt * BK + ukk + i * (1024 / BM);
+      const bool okp = pp < p.P;
+      if constexpr (VU) {
+        ru[i] = vf_bload4(rsU, (okp && un < p.Nu) ? 4u * (unsigned)(pp * p.Nu + un) : VF_OOB);
+      } else {
+        f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (n + j < p.Nu) v[j] = src[j];
+        for (int j = 0; j < 4; ++j) {
+          v[j] = vf_bload1(rsU, (okp && un + j < p.Nu) ? 4u * (unsigned)(pp * p.Nu + un + j) : VF_OOB);
         }
+        ru[i] = v;
       }
-      ru[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < V_CH; ++i) {
-      const int kk = (tid >> 5) + 8 * i;
-      const int pp = kt * BK + kk;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pp < p.P) {
-        const int mx = pp & (Mw - 1), my = (pp >> p.lgMw) & (Mh - 1), b = pp >> (p.lgMw + p.lgMh);
-        const int64_t boff = (int64_t)b * p.Hv * p.Wv * p.Cv;
-        if (p.vecV) {
-          const int iy = my * p.stride + v_dy[0], ix = mx * p.stride + v_dx[0];
-          if (v_okc[0] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv)
-            v = *(const f32x4*)(p.V + boff + ((int64_t)iy * p.Wv + ix) * p.Cv + v_c[0]);
-        } else {
+      const int pp = kt * BK + (tid >> 5) + 8 * i;
+      const bool okp = pp < p.P;
+      const int mx = pp & (Mw - 1), my = (pp >> p.lgMw) & (Mh - 1), b = pp >> (p.lgMw + p.lgMh);
+      const int boff = b * p.Hv * p.Wv * p.Cv;
+      if constexpr (VV) {
+        const int iy = my * p.stride + v_dy[0], ix = mx * p.stride + v_dx[0];
+        const bool ok = okp && v_okc[0] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+        rv[i] = vf_bload4(rsV, ok ? 4u * (unsigned)(boff + (iy * p.Wv + ix) * p.Cv + v_c[0]) : VF_OOB);
+      } else {
+        f32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int iy = my * p.stride + v_dy[j], ix = mx * p.stride + v_dx[j];
-            if (v_okc[j] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv)
-              v[j] = p.V[boff + ((int64_t)iy * p.Wv + ix) * p.Cv + v_c[j]];
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int iy = my * p.stride + v_dy[j], ix = mx * p.stride + v_dx[j];
+          const bool ok = okp && v_okc[j] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+          v[j] = vf_bload1(rsV, ok ? 4u * (unsigned)(boff + (iy * p.Wv + ix) * p.Cv + v_c[j]) : VF_OOB);
         }
+        rv[i] = v;
       }
-      rv[i] = v;
     }
   };
   auto store_tile = [&](int buf) {
@@ -451,7 +511,6 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
   const int lr = lane & 31, lh = lane >> 5;
-  constexpr int MT_VALID = BM == 128 ? 2 : 2;  // BM=64: waves are 1x4, each wave still 64 rows
 
   if (kt0 < kt1) {
     load_tile(kt0);
@@ -470,14 +529,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
       for (int j = 0; j < 4; ++j) {
         const int k = 8 * s + 4 * lh + j;
 #pragma unroll
-        for (int mt = 0; mt < MT_VALID; ++mt) a[mt][j] = Us[k * LDU + wm + mt * 32 + lr];
+        for (int mt = 0; mt < 2; ++mt) a[mt][j] = Us[k * LDU + wm + mt * 32 + lr];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt][j] = Vs[k * LDV + wn + nt * 32 + lr];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < MT_VALID; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
@@ -489,7 +548,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   const int64_t total = (int64_t)p.Nu * Ncols;
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * total : p.dW;
 #pragma unroll
-  for (int mt = 0; mt < MT_VALID; ++mt)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -545,62 +604,91 @@ __global__ void k_dot_bwd_weight(const float* __restrict__ x, const float* __res
 }
 
 // ================================================================================================ host
-static int launch_igemm(vf_ctx* ctx, IGemm& g) {
-  const int zpar = g.parity ? 4 : 1;
-  // tile selection
-  int BM, BN;
-  if (g.N <= 32) {
-    BM = 256;
-    BN = 32;
-  } else if (g.N <= 64) {
-    BM = 128;
-    BN = 64;
-  } else if (g.M <= 64) {
-    BM = 64;
-    BN = 128;
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int BM, int BN, int WM, int WN>
+static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v) {
+  dim3 block(256);
+  if (!bkm) {
+    if (v == 2)
+      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, false, 2>), grid, block, 0, ctx->stream, g);
+    else
+      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, false, 0>), grid, block, 0, ctx->stream, g);
   } else {
-    BM = 128;
-    BN = 128;
+    if (v == 2)
+      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, true, 2>), grid, block, 0, ctx->stream, g);
+    else if (v == 1)
+      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, true, 1>), grid, block, 0, ctx->stream, g);
+    else
+      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, true, 0>), grid, block, 0, ctx->stream, g);
   }
-  const int gm = (int)vf_cdiv(g.M, BM), gn = (int)vf_cdiv(g.N, BN);
+}
+
+// vecA / vecB: 16-byte loads legal for the A / B operand
+static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
+  const int zpar = g.parity ? 4 : 1;
+  const bool bkm = g.wsN == 1 && g.wsC != 1;
+  const int64_t a_elems = (int64_t)(g.M >> (g.lgMh + g.lgMw)) * g.Hi * g.Wi * g.C;
+  const int64_t w_elems = bkm ? (int64_t)g.C * g.wsC : (int64_t)g.N * g.wsN;
+  VF_REQUIRE(a_elems < ((int64_t)1 << 29) && w_elems < ((int64_t)1 << 29), "operand exceeds the 2 GiB buffer-descriptor range");
+  g.a_bytes = (unsigned)(a_elems * 4);
+  g.w_bytes = (unsigned)(w_elems * 4);
+  int v = (vecA && vecB) ? 2 : ((vecA && bkm) ? 1 : 0);
   const int Ktot = g.TH * g.TW * g.C;
-  g.nk = g.vecA ? g.TH * g.TW * (g.C / 16) : (int)vf_cdiv(Ktot, 16);
-  // split-K: fill >= 2 blocks per CU when the K loop is long enough to share
-  int64_t blocks = (int64_t)gm * gn * zpar;
+  g.nq = g.TH * g.TW * (g.C / 16);
+  g.nk = v >= 1 ? (g.nq + 1) / 2 : (int)vf_cdiv(Ktot, 32);
+  // ---- tile selection: the largest tile that still gives >= 2 blocks per CU, else the smallest + split-K
+  struct Tile { int bm, bn; };
+  Tile t;
+  if (g.N <= 32) {
+    t = {256, 32};
+  } else if (g.M <= 64) {
+    t = {64, 128};
+  } else {
+    const Tile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    static const int tune_min_blocks = getenv("VF_TILE_MIN_BLOCKS") ? atoi(getenv("VF_TILE_MIN_BLOCKS")) : 512;
+    int pick = 2;
+    for (int i = 0; i < 3; ++i) {
+      if (cand[i].bn > 64 && g.N <= 64) continue;
+      const int64_t blocks = vf_cdiv(g.M, cand[i].bm) * vf_cdiv(g.N, cand[i].bn) * zpar;
+      if (blocks >= tune_min_blocks) {
+        pick = i;
+        break;
+      }
+    }
+    t = cand[pick];
+  }
+  static const int tune_split_blocks = getenv("VF_SPLIT_BLOCKS") ? atoi(getenv("VF_SPLIT_BLOCKS")) : 512;
+  const int gm = (int)vf_cdiv(g.M, t.bm), gn = (int)vf_cdiv(g.N, t.bn);
+  const int64_t blocks = (int64_t)gm * gn * zpar;
   int ksplit = 1;
-  if (blocks < 512 && g.nk >= 16) {
-    ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(512, blocks));
+  if (blocks < tune_split_blocks * 3 / 4 && g.nk >= 8) {
+    ksplit = (int)std::min<int64_t>(g.nk / 4, vf_cdiv(tune_split_blocks, blocks));
     const size_t slab_bytes = (size_t)g.out_elems * sizeof(float);
     while (ksplit > 1 && (size_t)ksplit * slab_bytes > ctx->ws_bytes) --ksplit;
     if (ksplit < 1) ksplit = 1;
-    // avoid empty trailing splits
-    const int steps = (int)vf_cdiv(g.nk, ksplit);
+    const int steps = (int)vf_cdiv(g.nk, ksplit);  // avoid empty trailing splits
     ksplit = (int)vf_cdiv(g.nk, steps);
   }
   g.ksplit = ksplit;
   g.slab = ksplit > 1 ? (float*)ctx->ws : nullptr;
-  dim3 grid(gm, gn, zpar * ksplit), block(256);
-  const bool bkm = g.wsN == 1 && g.wsC != 1;
+  static const int tune_dbg = getenv("VF_IGEMM_DBG") ? atoi(getenv("VF_IGEMM_DBG")) : 0;
+  g.dbg = tune_dbg;
+  dim3 grid(gm, gn, zpar * ksplit);
   char pname[64];
-  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s%s", BM, BN, bkm ? "kmajorB" : "rowB", g.parity ? "_parity" : "");
+  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "");
   {
-  VfProf prof(ctx, pname, 2.0 * (double)g.M * g.N * Ktot * zpar, 0.0);
-#define VF_IGEMM(BM_, BN_, WN_)                                                             \
-  do {                                                                                      \
-    if (bkm)                                                                                \
-      hipLaunchKernelGGL((k_igemm<BM_, BN_, WN_, true>), grid, block, 0, ctx->stream, g);   \
-    else                                                                                    \
-      hipLaunchKernelGGL((k_igemm<BM_, BN_, WN_, false>), grid, block, 0, ctx->stream, g);  \
-  } while (0)
-  if (BM == 256)
-    VF_IGEMM(256, 32, 32);
-  else if (BM == 128 && BN == 64)
-    VF_IGEMM(128, 64, 32);
-  else if (BM == 64)
-    VF_IGEMM(64, 128, 32);
-  else
-    VF_IGEMM(128, 128, 64);
-#undef VF_IGEMM
+    VfProf prof(ctx, pname, 2.0 * (double)g.M * g.N * Ktot * zpar, 0.0);
+    if (t.bm == 256)
+      launch_igemm_tile<256, 32, 64, 32>(ctx, g, grid, bkm, v);
+    else if (t.bm == 128 && t.bn == 128)
+      launch_igemm_tile<128, 128, 64, 64>(ctx, g, grid, bkm, v);
+    else if (t.bm == 128)
+      launch_igemm_tile<128, 64, 64, 32>(ctx, g, grid, bkm, v);
+    else if (t.bn == 128)
+      launch_igemm_tile<64, 128, 64, 32>(ctx, g, grid, bkm, v);
+    else
+      launch_igemm_tile<64, 64, 32, 32>(ctx, g, grid, bkm, v);
   }
   VF_LAUNCH_CHECK();
   if (ksplit > 1) {
@@ -617,9 +705,9 @@ static int check_conv_args(int B, int H, int W, int Cin, int Cout, int k, int st
   VF_REQUIRE(vf_is_pow2(H) && vf_is_pow2(W), "spatial sizes must be powers of two (got %dx%d)", H, W);
   if (stride == 1) VF_REQUIRE(H >= 4 && W >= 4, "4x4 stride-1 conv needs H,W >= 4");
   if (stride == 2) VF_REQUIRE(H >= 2 && W >= 2, "stride-2 conv needs H,W >= 2");
+  VF_REQUIRE((int64_t)Cin * Cout * 16 < ((int64_t)1 << 31), "weight tensor too large for 32-bit element offsets");
   return 0;
 }
-static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Generic "conv-like" pass: Y[b,oy,ox,n] = sum_{kh,kw,c} A[b, oy*s-pad+kh, ox*s-pad+kw, c] * Wt(n,kh,kw,c)
 // (conv forward: A = x, n = Cout, weights [n][kh][kw][c];  full-conv data-grad: A = gy, n = Cin_full,
@@ -642,13 +730,11 @@ static int conv_like_fwd(vf_ctx* ctx, const float* A, const float* w, const floa
   g.TH = 4; g.TW = 4;
   g.sy = stride; g.ty = 1; g.oy0 = -pad; g.sx = stride; g.tx = 1; g.ox0 = -pad;
   g.kh0 = 0; g.khs = 1; g.kw0 = 0; g.kws = 1;
-  g.wsN = 16 * (int64_t)C; g.wsC = 1; g.wsTap = C;
+  g.wsN = 16 * C; g.wsC = 1; g.wsTap = C;
   g.outH = Ho; g.outW = Wo; g.osy = 1; g.osx = 1;
   g.out_elems = (int64_t)g.M * N;
-  g.vecA = (C % 16 == 0) && aligned16(A);
-  g.vecB = (C % 16 == 0) && aligned16(w);
   g.act = act; g.slope = slope;
-  return launch_igemm(ctx, g);
+  return launch_igemm(ctx, g, (C % 16 == 0) && aligned16(A), (C % 16 == 0) && aligned16(w));
 }
 
 // Generic "transposed" pass: Y[b,oh,ow,n] = sum_{kh,kw,c : oh = 2i-1+kh ...} A[b,i,j,c] * Wt[c][kh][kw][n]
@@ -659,10 +745,10 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
   memset(&g, 0, sizeof(g));
   g.A = A; g.Wt = w; g.bias = bias; g.Y = Y;
   g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
-  g.wsN = 1; g.wsC = 16 * (int64_t)N; g.wsTap = N;
+  g.wsN = 1; g.wsC = 16 * N; g.wsTap = N;
   g.act = act; g.slope = slope;
-  g.vecA = (C % 16 == 0) && aligned16(A);
-  g.vecB = (N % 4 == 0) && aligned16(w);
+  const bool vecA = (C % 16 == 0) && aligned16(A);
+  bool vecB = (N % 4 == 0) && aligned16(w);
   if (stride == 2) {
     // output (2*Hi) x (2*Wi); per parity class a 2x2-tap GEMM over the low-res grid
     g.lgMh = vf_ilog2(Hi); g.lgMw = vf_ilog2(Wi);
@@ -674,35 +760,30 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
     g.parity = 1;
     g.out_elems = (int64_t)B * g.outH * g.outW * N;
   } else {
-    // stride 1, pad 0, low-res 1x1 -> 4x4: plain GEMM with N' = (kh,kw,n)
+    // stride 1, pad 0, low-res 1x1 -> 4x4: plain GEMM whose N' = (kh,kw,n) columns are contiguous in [c][kh][kw][n]
     VF_REQUIRE(Hi == 1 && Wi == 1, "stride-1 transposed pass is built for the 1x1 bottleneck only (got %dx%d)", Hi, Wi);
     g.lgMh = 0; g.lgMw = 0;
     g.M = B;
     g.TH = 1; g.TW = 1;
     g.sy = 1; g.ty = 1; g.sx = 1; g.tx = 1;
-    g.N = 16 * N;                 // columns (kh,kw,n) are contiguous in [c][kh][kw][n]
-    g.wsC = 16 * (int64_t)N; g.wsTap = 0;
+    g.N = 16 * N;
+    g.wsC = 16 * N; g.wsTap = 0;
     g.outH = 1; g.outW = 1; g.osy = 1; g.osx = 1;
     g.out_elems = (int64_t)B * 16 * N;
-    g.vecB = ((16 * N) % 4 == 0) && aligned16(w);
-    if (bias) {
-      // bias is per n, columns are (tap,n): handled by the reduce/epilogue through i % N only when N' == N.
-      // The reference always runs with zero conv biases (train.lua:279-280); add it in a second pass.
-    }
+    vecB = ((16 * N) % 4 == 0) && aligned16(w);
   }
   const float* real_bias = bias;
-  int real_act = act;
-  if (stride == 1 && bias) {  // defer bias+act to a pointwise pass (bias index = col % N)
+  const int real_act = act;
+  if (stride == 1 && bias) {  // bias index = column % N: apply bias + activation in a pointwise pass
     g.bias = nullptr;
     g.act = VF_ACT_NONE;
   }
-  int rc = launch_igemm(ctx, g);
-  if (rc) return rc;
+  if (int rc = launch_igemm(ctx, g, vecA, vecB)) return rc;
   if (stride == 1 && real_bias) {
     const int64_t total = (int64_t)B * 16 * N;
     const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, Y, Y, real_bias, total, N, 0, real_act, slope,
-                       1.f);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, (const float*)Y, Y, real_bias, total, N, 0,
+                       real_act, slope, 1.f);
     VF_LAUNCH_CHECK();
   }
   return 0;
@@ -719,15 +800,19 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.Nu = Nu; g.Cv = Cv; g.Hv = Hv; g.Wv = Wv;
   g.stride = stride; g.pad = pad;
   g.nk = (int)vf_cdiv(g.P, 16);
-  g.vecU = (Nu % 4 == 0) && aligned16(U);
-  g.vecV = (Cv % 4 == 0) && aligned16(V);
+  VF_REQUIRE((int64_t)g.P * Nu < ((int64_t)1 << 29) && (int64_t)B * Hv * Wv * Cv < ((int64_t)1 << 29),
+             "operand exceeds the 2 GiB buffer-descriptor range");
+  g.u_bytes = (unsigned)((int64_t)g.P * Nu * 4);
+  g.v_bytes = (unsigned)((int64_t)B * Hv * Wv * Cv * 4);
+  const bool vecU = (Nu % 4 == 0) && aligned16(U);
+  const bool vecV = (Cv % 4 == 0) && aligned16(V);
   g.beta = beta;
   const int BM = Nu > 64 ? 128 : 64;
   const int gy = (int)vf_cdiv(Nu, BM), gx = (int)vf_cdiv(16 * (int64_t)Cv, 128);
   const int64_t blocks = (int64_t)gx * gy;
   const int64_t total = (int64_t)Nu * 16 * Cv;
   int ksplit = 1;
-  if (blocks < 512 && g.nk >= 16) {
+  if (blocks < 384 && g.nk >= 16) {
     ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(512, blocks));
     while (ksplit > 1 && (size_t)ksplit * total * sizeof(float) > ctx->ws_bytes) --ksplit;
     if (ksplit < 1) ksplit = 1;
@@ -739,10 +824,22 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   dim3 grid(gx, gy, ksplit), block(256);
   {
     VfProf prof(ctx, BM == 128 ? "wgrad_128x128" : "wgrad_64x128", 2.0 * (double)g.P * Nu * 16.0 * Cv, 0.0);
+#define VF_WG(BM_)                                                                                  \
+  do {                                                                                              \
+    if (vecU && vecV)                                                                               \
+      hipLaunchKernelGGL((k_wgrad<BM_, true, true>), grid, block, 0, ctx->stream, g);               \
+    else if (vecU)                                                                                  \
+      hipLaunchKernelGGL((k_wgrad<BM_, true, false>), grid, block, 0, ctx->stream, g);              \
+    else if (vecV)                                                                                  \
+      hipLaunchKernelGGL((k_wgrad<BM_, false, true>), grid, block, 0, ctx->stream, g);              \
+    else                                                                                            \
+      hipLaunchKernelGGL((k_wgrad<BM_, false, false>), grid, block, 0, ctx->stream, g);             \
+  } while (0)
     if (BM == 128)
-      hipLaunchKernelGGL((k_wgrad<128>), grid, block, 0, ctx->stream, g);
+      VF_WG(128);
     else
-      hipLaunchKernelGGL((k_wgrad<64>), grid, block, 0, ctx->stream, g);
+      VF_WG(64);
+#undef VF_WG
   }
   VF_LAUNCH_CHECK();
   if (ksplit > 1) {
