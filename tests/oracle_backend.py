@@ -1,0 +1,243 @@
+"""A CPU stand-in for video_filler_amd.backend.HipBackend, built on the oracle — TESTS ONLY.
+
+It lets the host logic of the package (nn mirror, Sequential fusion plan, flat-parameter layout, trainers'
+closures, data-parallel gradient averaging and SyncBN hooks) run without a GPU, e.g. under gloo with
+world_size 2.  The product never imports this; `set_backend` is the only way it gets installed.
+Tensors are CPU torch tensors with the same logical-NCHW / physical-NHWC convention as on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+def _np(t):
+    """logical-order contiguous float32 numpy copy"""
+    return np.ascontiguousarray(t.detach().contiguous().numpy())
+
+
+def _put(t, arr):
+    t.copy_(torch.from_numpy(np.ascontiguousarray(arr)).reshape(t.shape))
+
+
+_ACT = {"none": lambda v, s: v, "lrelu": lambda v, s: np.where(v > 0, v, v * np.float32(s)),
+        "relu": lambda v, s: np.maximum(v, 0), "tanh": lambda v, s: np.tanh(v),
+        "sigmoid": lambda v, s: 1 / (1 + np.exp(-v))}
+
+
+def _act_grad(y, g, act, s):
+    if act == "lrelu":
+        return np.where(y > 0, g, g * np.float32(s))
+    if act == "relu":
+        return np.where(y > 0, g, 0)
+    if act == "tanh":
+        return g * (1 - y * y)
+    if act == "sigmoid":
+        return g * (1 - y) * y
+    return g
+
+
+class OracleBackend:
+    name = "oracle-cpu (tests only)"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.lib = O.lib()
+
+    # plumbing
+    def use_current_stream(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype)
+
+    def empty_act(self, B, Cc, H, W):
+        return torch.empty((B, H, W, Cc)).permute(0, 3, 1, 2)
+
+    def from_host(self, t):
+        return t
+
+    def all_reduce(self, t, group=None):
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+
+    def copy(self, dst, src):
+        dst.copy_(src)
+
+    def zero(self, t):
+        t.zero_()
+
+    def zero_segments(self, base, offs, lens):
+        for o, n in zip(offs.tolist(), lens.tolist()):
+            base[o:o + n] = 0
+
+    # convolutions
+    def _conv_mod(self, cls, w, k, s, p, full):
+        nIn, nOut = (w.shape[0], w.shape[1]) if full else (w.shape[1], w.shape[0])
+        m = cls(nIn, nOut, k, k, s, s, p, p)
+        m.weight = _np(w)
+        return m
+
+    def conv2d_fwd(self, x, w, bias, y, k, stride, pad, act="none", slope=0.0, full=False):
+        m = self._conv_mod(O.SpatialFullConvolution if full else O.SpatialConvolution, w, k, stride, pad, full)
+        m.bias = _np(bias) if bias is not None else np.zeros(m.nOutputPlane, np.float32)
+        out = m.forward(_np(x))
+        _put(y, _ACT[act](out, slope).astype(np.float32))
+
+    def conv2d_bwd_data(self, gy, w, gx, k, stride, pad, full=False):
+        m = self._conv_mod(O.SpatialFullConvolution if full else O.SpatialConvolution, w, k, stride, pad, full)
+        _put(gx, m.updateGradInput(np.empty(tuple(gx.shape), np.float32), _np(gy)))
+
+    def conv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta, full=False):
+        m = self._conv_mod(O.SpatialFullConvolution if full else O.SpatialConvolution, gw, k, stride, pad, full)
+        m.gradWeight = np.zeros(tuple(gw.shape), np.float32)
+        m.gradBias = np.zeros(m.nOutputPlane, np.float32)
+        m.accGradParameters(_np(x), _np(gy))
+        _put(gw, np.float32(beta) * _np(gw) + m.gradWeight)
+        if gb is not None:
+            _put(gb, np.float32(beta) * _np(gb) + m.gradBias)
+
+    def deconv2d_fwd(self, x, w, bias, y, k, stride, pad, act="none", slope=0.0):
+        self.conv2d_fwd(x, w, bias, y, k, stride, pad, act, slope, full=True)
+
+    def deconv2d_bwd_data(self, gy, w, gx, k, stride, pad):
+        self.conv2d_bwd_data(gy, w, gx, k, stride, pad, full=True)
+
+    def deconv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta):
+        self.conv2d_bwd_weight(x, gy, gw, gb, k, stride, pad, beta, full=True)
+
+    # batch norm, in the HIP backend's two-phase algebra (double accumulators)
+    def bn_stats(self, x, shift, sums):
+        xn = _np(x).astype(np.float64)
+        C_ = xn.shape[1]
+        d = xn - _np(shift).astype(np.float64).reshape(1, C_, 1, 1)
+        sums[:C_] = torch.from_numpy(d.sum(axis=(0, 2, 3)))
+        sums[C_:] = torch.from_numpy((d * d).sum(axis=(0, 2, 3)))
+
+    def bn_finalize(self, sums, rm, rv, save_mean, save_invstd, n_total, momentum, eps):
+        C_ = rm.numel()
+        s1, s2 = sums[:C_].numpy(), sums[C_:].numpy()
+        n = float(n_total)
+        shift = rm.numpy().astype(np.float64)
+        mean = shift + s1 / n
+        m2 = np.maximum(s2 - s1 * s1 / n, 0)
+        invstd = 1.0 / np.sqrt(m2 / n + eps)
+        save_mean.copy_(torch.from_numpy(mean.astype(np.float32)))
+        save_invstd.copy_(torch.from_numpy(invstd.astype(np.float32)))
+        rm.copy_(torch.from_numpy((momentum * mean + (1 - momentum) * rm.numpy()).astype(np.float32)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            unb = m2 / (n - 1.0)
+        rv.copy_(torch.from_numpy((momentum * unb + (1 - momentum) * rv.numpy()).astype(np.float32)))
+
+    def bn_apply(self, x, y, gamma, beta, mean, invstd, act="none", slope=0.0):
+        C_ = x.shape[1]
+        r = lambda t: _np(t).reshape(1, C_, 1, 1)
+        v = ((_np(x) - r(mean)) * r(invstd)) * r(gamma) + r(beta)
+        _put(y, _ACT[act](v.astype(np.float32), slope).astype(np.float32))
+
+    def bn_eval_fwd(self, x, y, gamma, beta, rm, rv, eps, act="none", slope=0.0):
+        invstd = torch.from_numpy((1.0 / np.sqrt(rv.numpy().astype(np.float64) + eps)).astype(np.float32))
+        self.bn_apply(x, y, gamma, beta, rm, invstd, act, slope)
+
+    def bn_bwd_stats(self, x, y_act, gy, save_mean, sums, act="none", slope=0.0):
+        C_ = x.shape[1]
+        g = _act_grad(_np(y_act), _np(gy), act, slope) if act != "none" else _np(gy)
+        g = g.astype(np.float64)
+        xc = _np(x).astype(np.float64) - _np(save_mean).astype(np.float64).reshape(1, C_, 1, 1)
+        sums[:C_] = torch.from_numpy(g.sum(axis=(0, 2, 3)))
+        sums[C_:] = torch.from_numpy((g * xc).sum(axis=(0, 2, 3)))
+
+    def bn_bwd_apply(self, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, n_total, act="none",
+                     slope=0.0, pbeta=1.0):
+        C_ = x.shape[1]
+        r = lambda a: np.asarray(a, np.float64).reshape(1, C_, 1, 1)
+        s, dp = sums[:C_].numpy(), sums[C_:].numpy()
+        inv = _np(save_invstd).astype(np.float64)
+        n = float(n_total)
+        if gx is not None:
+            g = _act_grad(_np(y_act), _np(gy), act, slope) if act != "none" else _np(gy)
+            xc = _np(x).astype(np.float64) - r(_np(save_mean))
+            k = (dp * inv * inv / n).astype(np.float32)
+            out = (g - r(s / n) - xc * r(k)) * r(inv) * r(_np(gamma))
+            _put(gx, out.astype(np.float32))
+        if ggamma is not None:
+            _put(ggamma, np.float32(pbeta) * _np(ggamma) + (dp * inv).astype(np.float32))
+        if gbeta is not None:
+            _put(gbeta, np.float32(pbeta) * _np(gbeta) + s.astype(np.float32))
+
+    # pointwise
+    def act_fwd(self, x, y, act, slope=0.0):
+        _put(y, _ACT[act](_np(x), slope).astype(np.float32))
+
+    def act_bwd(self, y, gy, gx, act, slope=0.0):
+        _put(gx, _act_grad(_np(y), _np(gy), act, slope).astype(np.float32))
+
+    def axpby(self, a, x, b, y):
+        _put(y, np.float32(a) * _np(x) + np.float32(b) * _np(y))
+
+    def cmul(self, x, y):
+        _put(y, _np(y) * _np(x))
+
+    def scale_shift(self, y, a, b):
+        _put(y, _np(y) * np.float32(a) + np.float32(b))
+
+    def masked_compose(self, out, real, fake, mask):
+        _put(out, np.where(_np(mask) != 0, _np(fake), _np(real)))
+
+    # criteria
+    def bce_fwd(self, x, label, loss):
+        xv = _np(x).reshape(-1)
+        t = np.full(xv.shape, label, np.float32)
+        loss[0] = self.lib.vfo_bce_fwd(O._p(xv), O._p(t), xv.size)
+
+    def bce_bwd(self, x, label, gx):
+        xv = _np(x)
+        _put(gx, O.BCECriterion().backward(xv, np.full(xv.reshape(-1).shape, label, np.float32)))
+
+    def mse_fwd(self, x, t, loss):
+        loss[0] = O.MSECriterion().forward(_np(x), _np(t))
+
+    def mse_bwd(self, x, t, gx):
+        _put(gx, O.MSECriterion().backward(_np(x), _np(t)))
+
+    def recon_grad_mix(self, df_dg, x, t, mask, alpha, c0, c1, band, loss):
+        xv, tv = _np(x), _np(t)
+        loss[0] = O.MSECriterion().forward(xv, tv)
+        g = np.float32(2.0 / xv.size) * (xv - tv)
+        if mask is not None:
+            w = np.float32(c0) + np.float32(c1) * _np(mask)
+        elif band > 0:
+            HW = xv.shape[2]
+            w = np.full(xv.shape, np.float32(c0 + c1), np.float32)
+            w[:, :, band:HW - band, band:HW - band] = np.float32(c0)
+        else:
+            w = np.float32(c0)
+        _put(df_dg, np.float32(alpha) * _np(df_dg) + g * w)
+
+    def gdl_fwd(self, yhat, y, loss):
+        loss[0] = O.GDLCriterion(1).forward(_np(yhat), _np(y))
+
+    def masked_mse_fwd(self, x, xhat, mask_u8, w, loss):
+        c = O.MaskedMSECriterion(w)
+        c.setMask(np.ascontiguousarray(mask_u8.contiguous().numpy()))
+        loss[0] = c.forward(_np(x), _np(xhat))
+
+    def masked_mse_bwd(self, x, xhat, mask_u8, w, gx):
+        c = O.MaskedMSECriterion(w)
+        c.setMask(np.ascontiguousarray(mask_u8.contiguous().numpy()))
+        _put(gx, c.backward(_np(x), _np(xhat)))
+
+    # adam: element-wise, so the physical order of x does not matter
+    def adam_step(self, x, g, m, v, lr, beta1, beta2, eps, t_dev):
+        t_dev[0] += 1
+        xa, ga, ma, va = x.numpy(), g.numpy(), m.numpy(), v.numpy()
+        self.lib.vfo_adam_step(O._p(xa), O._p(ga), O._p(ma), O._p(va), None, C.c_size_t(xa.size), C.c_double(lr),
+                               C.c_double(beta1), C.c_double(beta2), C.c_double(eps), int(t_dev[0]))

@@ -1,0 +1,240 @@
+"""Host-side logic of the package on CPU (no GPU needed): the nn mirror, the Sequential fusion plan, the flat
+parameter layout, the trainers' closures and the data-parallel path, driven through tests/oracle_backend.py
+(an oracle-backed stand-in for the HIP backend that only tests may install)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import video_filler_amd  # noqa: F401
+from video_filler_amd import backend as vb
+
+from helpers import rel_err
+from oracle_backend import OracleBackend
+
+SMALL = dict(nBottleneck=32, nef=8, ngf=8, ndf=8)
+
+
+@pytest.fixture()
+def cpu_backend():
+    old = vb._BACKEND
+    b = vb.set_backend(OracleBackend())
+    yield b
+    vb._BACKEND = old
+
+
+def _load(tr, ref):
+    tr.netG.load_reference_flat(torch.from_numpy(ref.parametersG.copy()))
+    tr.netD.load_reference_flat(torch.from_numpy(ref.parametersD.copy()))
+
+
+def test_fusion_plan_and_module_protocol(cpu_backend):
+    from video_filler_amd import nn
+    from video_filler_amd.trainers import build_netD, build_netG
+    netD = build_netD(3, 8, False)
+    kinds = [(type(m).__name__, type(a).__name__ if a else None) for m, a in netD._build_plan()]
+    assert kinds == [("SpatialConvolution", "LeakyReLU"),
+                     ("SpatialConvolution", None), ("SpatialBatchNormalization", "LeakyReLU"),
+                     ("SpatialConvolution", None), ("SpatialBatchNormalization", "LeakyReLU"),
+                     ("SpatialConvolution", None), ("SpatialBatchNormalization", "LeakyReLU"),
+                     ("SpatialConvolution", "Sigmoid"), ("View", None)]
+    netG = build_netG(3, 3, 8, 8, 32, False)
+    assert len(netG.leaves()) == 31                                   # train.lua:87-148: 15 (netE) + 2 + 4*3 + 2
+    assert sum(isinstance(m, nn.SpatialBatchNormalization) for m in netG.leaves()) == 9
+    unf = build_netD(3, 8, False, fuse=False)
+    assert all(a is None for _, a in unf._build_plan())
+    # torch.type(m):find('Convolution') semantics used by weights_init / the bias-zeroing sweep (train.lua:58-67,279)
+    names = [m.type_name() for m in netG.leaves()]
+    assert sum("Convolution" in n for n in names) == 11 and sum("BatchNormalization" in n for n in names) == 9
+    m = netG.leaves()[0]
+    assert (m.nInputPlane, m.nOutputPlane, m.kW, m.kH, m.dW, m.dH, m.padW, m.padH) == (3, 8, 4, 4, 2, 2, 1, 1)
+
+
+def test_parameter_counts_match_the_reference_nets(cpu_backend):
+    """train.lua netD has 2 766 529 parameters; netG (nBottleneck=100) 7.22 M."""
+    from video_filler_amd.trainers import build_netD, build_netG
+    netD = build_netD(3, 64, False)
+    netD.getParameters()
+    assert netD.n_parameters() == 2766529
+    netG = build_netG(3, 3, 64, 64, 100, False)
+    netG.getParameters()
+    n = netG.n_parameters()
+    assert abs(n - 7.22e6) < 0.01e6
+    vidD = build_netD(12, 64, True)
+    vidD.getParameters()
+    assert vidD.n_parameters() == 2802401          # train_vid_weighted.lua netD, predLen = 4
+
+
+def test_flat_layout_alignment_views_and_roundtrip(cpu_backend):
+    from video_filler_amd.trainers import build_netG
+    net = build_netG(3, 3, 8, 8, 32, True)
+    flat, gflat = net.getParameters()
+    rng = np.random.default_rng(0)
+    ref = rng.standard_normal(net.n_parameters()).astype(np.float32)
+    net.load_reference_flat(torch.from_numpy(ref))
+    np.testing.assert_array_equal(net.reference_flat().numpy(), ref)
+    for m, name, gname, o, n in net._flat[2]:
+        assert o % 64 == 0                                           # 256-byte aligned segments
+        t = getattr(m, name)
+        assert t.data_ptr() == flat.data_ptr() + 4 * o                # a VIEW into the flat storage
+        if t.dim() == 4:
+            assert t.permute(0, 2, 3, 1).is_contiguous()              # channels-last physical layout
+    # padding between segments stays zero
+    used = torch.zeros_like(flat, dtype=torch.bool)
+    for m, name, gname, o, n in net._flat[2]:
+        used[o:o + n] = True
+    assert float(flat[~used].abs().sum()) == 0.0
+    # bias zeroing sweep touches conv/full-conv biases only
+    flat.fill_(1.0)
+    net.zeroConvBiases()
+    for m, name, gname, o, n in net._flat[2]:
+        want = 0.0 if (name == "bias" and "Convolution" in m.type_name()) else 1.0
+        assert float(flat[o:o + n].min()) == float(flat[o:o + n].max()) == want
+
+
+def test_lazy_zero_equals_memset(cpu_backend):
+    from video_filler_amd.trainers import CenterTrainer
+    from oracle import oracle as O
+    batch = torch.from_numpy(O.synth_center_batch(2, np.random.default_rng(3)))
+    out = []
+    for lazy in (True, False):
+        tr = CenterTrainer(dict(SMALL, wtl2=0.999, overlapPred=4), seed=5, lazy_zero=lazy)
+        tr.gradParametersD.fill_(7.0)      # stale garbage must not leak into the new gradients
+        tr.gradParametersG.fill_(7.0)
+        tr.set_batch(batch)
+        tr.step()
+        out.append((tr.netD.reference_flat(grads=True).numpy().copy(), tr.netG.reference_flat(grads=True).numpy().copy()))
+    assert rel_err(out[0][0], out[1][0]) < 1e-6 and rel_err(out[0][1], out[1][1]) < 1e-6
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_center_trainer_closures_match_oracle(fuse, cpu_backend):
+    from video_filler_amd.trainers import CenterTrainer
+    from oracle import oracle as O
+    opt = dict(SMALL, wtl2=0.999, overlapPred=4)
+    ref = O.CenterTrainer(opt, np.random.default_rng(1))
+    tr = CenterTrainer(opt, fuse=fuse, lazy_zero=fuse, skip_dead_grads=fuse)
+    _load(tr, ref)
+    for it in range(2):
+        batch = O.synth_center_batch(2, np.random.default_rng(30 + it))
+        ref.set_batch(batch)
+        tr.set_batch(torch.from_numpy(batch))
+        ref.step()
+        tr.step()
+        got = tr.losses()
+        for k in ("errD", "errG", "errG_l2"):
+            assert abs(got[k] - getattr(ref, k)) < 1e-5 * max(1, abs(getattr(ref, k)))
+        assert rel_err(tr.netD.reference_flat(grads=True).numpy(), ref.gradParametersD) < 2e-5
+        assert rel_err(tr.netG.reference_flat(grads=True).numpy(), ref.gradParametersG) < 2e-5
+        sel = np.abs(ref.gradParametersG) > 1e-3 * np.abs(ref.gradParametersG).max()
+        assert np.abs(tr.netG.reference_flat().numpy() - ref.parametersG)[sel].max() < 0.02 * 0.002
+
+
+@pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl"])
+def test_vid_trainer_closures_match_oracle(variant, cpu_backend):
+    from video_filler_amd.trainers import VidTrainer
+    from oracle import oracle as O
+    opt = dict(SMALL, predLen=2) if variant == "weighted" else dict(SMALL, predLen=1, weight_nomask=0, wtgdl=0.5)
+    nc = 6 if variant == "weighted" else 3
+    ref = O.VidTrainer(opt, np.random.default_rng(2))
+    tr = VidTrainer(opt)
+    _load(tr, ref)
+    ctx, full, mask = O.synth_vid_batch(3, np.random.default_rng(9), nc)
+    ref.set_batch(ctx, full, mask)
+    tr.set_batch(torch.from_numpy(ctx), torch.from_numpy(full), torch.from_numpy(mask))
+    ref.step()
+    tr.step()
+    got = tr.losses()
+    for k in ("errD", "errG", "errG_l2", "errG_gdl"):
+        want = getattr(ref, k)
+        if want is not None:
+            assert abs(got[k] - want) < 1e-5 * max(1, abs(want)), k
+    assert rel_err(tr.netD.reference_flat(grads=True).numpy(), ref.gradParametersD) < 2e-5
+    assert rel_err(tr.netG.reference_flat(grads=True).numpy(), ref.gradParametersG) < 2e-5
+
+
+def test_checkpoint_roundtrip(tmp_path, cpu_backend):
+    from video_filler_amd import util
+    from video_filler_amd.trainers import build_netG, weights_init
+    a = build_netG(3, 3, 8, 8, 32, False)
+    weights_init(a, torch.Generator().manual_seed(1))
+    a.getParameters()
+    for m in a.leaves():
+        if hasattr(m, "running_mean"):
+            m.running_mean.uniform_(-1, 1)
+            m.running_var.uniform_(0.5, 2)
+    f = str(tmp_path / "net_G.npz")
+    util.save(f, a)
+    b = util.load(f, build_netG(3, 3, 8, 8, 32, False))
+    np.testing.assert_array_equal(a.reference_flat().numpy(), b.reference_flat().numpy())
+    ra = [m.running_var.numpy() for m in a.leaves() if hasattr(m, "running_var")]
+    rb = [m.running_var.numpy() for m in b.leaves() if hasattr(m, "running_var")]
+    assert len(ra) == 9 and all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    assert util.cudnn(a) is a          # drivers keep their util.cudnn(net) call
+
+
+# ------------------------------------------------------------------ data parallel over gloo, world_size 2
+def _dp_worker(rank, world, port, kind, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import oracle as O
+    from video_filler_amd import backend as vb2
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+    vb2.set_backend(OracleBackend())
+    B = 4
+    if kind == "center":
+        opt = dict(SMALL, wtl2=0.999, overlapPred=4, smooth=True)   # smooth nets: see tests/test_gpu_trainers.py
+        full_batch = torch.from_numpy(O.synth_center_batch(B, np.random.default_rng(77)))
+        mk = lambda w, r, s: CenterTrainer(opt, seed=11, world=w, rank=r, sync_bn=s)
+        feed = lambda tr, lo, hi: tr.set_batch(full_batch[lo:hi])
+    else:
+        opt = dict(SMALL, predLen=2, smooth=True)
+        ctx, full, mask = [torch.from_numpy(a) for a in O.synth_vid_batch(B, np.random.default_rng(78), 6)]
+        mk = lambda w, r, s: VidTrainer(opt, seed=11, world=w, rank=r, sync_bn=s)
+        feed = lambda tr, lo, hi: tr.set_batch(ctx[lo:hi], full[lo:hi], mask[lo:hi])
+    tr = mk(world, rank, True)
+    per = B // world
+    feed(tr, rank * per, (rank + 1) * per)
+    tr.step()
+    g1 = tr.gradParametersG.numpy().copy()      # after ONE iteration: gradients are comparable at fp32 precision
+    rm1 = [m.running_mean.numpy().copy() for m in tr.netG.leaves() if hasattr(m, "running_mean")]
+    feed(tr, rank * per, (rank + 1) * per)
+    tr.step()
+    res = dict(pG=tr.parametersG.numpy().copy(), pD=tr.parametersD.numpy().copy(), gG=g1, rm=rm1)
+    if rank == 0:
+        one = mk(1, 0, False)                 # the single-device big batch the shards must reproduce
+        feed(one, 0, B)
+        one.step()
+        one_g1 = one.gradParametersG.numpy().copy()
+        one_rm1 = [m.running_mean.numpy().copy() for m in one.netG.leaves() if hasattr(m, "running_mean")]
+        feed(one, 0, B)
+        one.step()
+        ok = dict(pG=rel_err(res["pG"], one.parametersG.numpy()), pD=rel_err(res["pD"], one.parametersD.numpy()),
+                  gG=rel_err(res["gG"], one_g1),
+                  rm=max(float(np.abs(a - b).max()) for a, b in zip(res["rm"], one_rm1)))
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([ok["pG"], ok["pD"], ok["gG"], ok["rm"]]))
+    # replicas must stay bit-identical across ranks
+    t = torch.from_numpy(res["pG"]).clone()
+    dist.broadcast(t, 0)
+    same = bool(torch.equal(t, torch.from_numpy(res["pG"])))
+    flag = torch.tensor([1.0 if same else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "same.npy"), flag.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["center", "vid"])
+def test_data_parallel_world2_equals_big_batch(kind, tmp_path):
+    port = 29500 + (os.getpid() % 2000) + (7 if kind == "vid" else 0)
+    mp.spawn(_dp_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    pG, pD, gG, rm = np.load(str(tmp_path / "ok.npy"))
+    assert float(np.load(str(tmp_path / "same.npy"))[0]) == 1.0, "replicas diverged across ranks"
+    # sharded gradients are mean-reduced in a different order than the big batch sums: fp32 tolerance
+    assert gG < 5e-5 and rm < 1e-5, (gG, rm)
+    assert pG < 5e-3 and pD < 5e-3, (pG, pD)     # Adam amplifies rounding on near-zero gradients

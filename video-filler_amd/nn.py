@@ -217,15 +217,25 @@ class SpatialBatchNormalization(Module):
         Bn, Cc, H, W = input.shape
         gx = self._buf("gradInput", Bn, Cc, H, W) if want_gx else None
         B.bn_bwd_stats(input, y_act, gradOutput, self.save_mean, self._sums, act, slope)
-        if self.sync_world > 1:
-            B.all_reduce(self._sums, self.sync_group)
         pbeta = 1.0
         if want_gp:
             pbeta = 0.0 if self._fresh else 1.0
             self._fresh = False
+        n_total = Bn * H * W * self.sync_world
+        if self.sync_world > 1:
+            # SyncBN: gamma/beta gradients come from THIS rank's sums (the flat-gradient all-reduce adds the other
+            # ranks' shares later); gradInput needs the sums over the whole global batch.
+            if want_gp:
+                B.bn_bwd_apply(input, y_act, gradOutput, None, self.gradWeight, self.gradBias, self.weight,
+                               self.save_mean, self.save_std, self._sums, n_total, act, slope, pbeta)
+            B.all_reduce(self._sums, self.sync_group)
+            if want_gx:
+                B.bn_bwd_apply(input, y_act, gradOutput, gx, None, None, self.weight, self.save_mean, self.save_std,
+                               self._sums, n_total, act, slope, 1.0)
+            return gx
         B.bn_bwd_apply(input, y_act, gradOutput, gx, self.gradWeight if want_gp else None,
                        self.gradBias if want_gp else None, self.weight, self.save_mean, self.save_std, self._sums,
-                       Bn * H * W * self.sync_world, act, slope, pbeta)
+                       n_total, act, slope, pbeta)
         return gx
 
     def updateGradInput(self, input, gradOutput):
