@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--sync-bn", action="store_true", help="N>1: all-reduce BatchNorm sums (big-batch parity mode)")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream (no dW || dX, no netG-fwd || netD-real overlap)")
     args = ap.parse_args()
 
     import torch
@@ -61,7 +62,7 @@ def main():
     gen = torch.Generator().manual_seed(1234 + rank)
     if args.workload == "center":
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, wtl2=0.999, overlapPred=4)
-        tr = CenterTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn)
+        tr = CenterTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=not args.no_overlap)
         batch = torch.rand((args.batch, 3, 128, 128), generator=gen) * 2 - 1
         tr.set_batch(batch)
         wl = "train.lua inpaintCenter (nBottleneck=%d wtl2=0.999 overlapPred=4) fineSize=128 batchSize=%d/GPU" % (
@@ -70,7 +71,7 @@ def main():
         predLen = 16 if args.workload == "vid16" else 4
         nc = 3 * predLen
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, predLen=predLen)
-        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn)
+        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=not args.no_overlap)
         full = torch.rand((args.batch, nc, 128, 128), generator=gen) * 2 - 1
         mask = torch.zeros((args.batch, nc, 128, 128), dtype=torch.uint8)
         mask[:, :, 32:96, 32:96] = 1
@@ -113,6 +114,9 @@ def main():
     if rank == 0:
         B.use_current_stream()
         nprof = 3
+        # kernels are timed one at a time: switch the stream-level overlap off for this pass only
+        tr.netD.side = tr.netG.side = None
+        tr.side_g = None
         B.prof_begin()
         for _ in range(nprof):
             tr.step()
@@ -171,7 +175,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl, "global_batch": world * args.batch, "launch": "hipGraph" if use_graph else "eager",
+            "config": {"workload": wl, "global_batch": world * args.batch, "launch": "hipGraph" if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -53,6 +53,31 @@ class HipBackend:
         s = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self.lib.vf_ctx_set_stream(self.ctx, C.c_void_p(s)))
 
+    def fork(self, workspace_bytes=128 << 20):
+        """A second context on its OWN stream with its OWN workspace, for work that may overlap the main stream
+        (weight gradients beside the data-gradient chain; netG forward beside netD's real pass).  Use it through
+        `with side.on(): ...` which orders it after everything issued so far on the current stream; the caller
+        joins with `side.join()`."""
+        side = HipBackend.__new__(HipBackend)
+        side.lib, side.device = self.lib, self.device
+        ctx = C.c_void_p()
+        _lib.check(self.lib.vf_ctx_create(C.byref(ctx), self.device.index, None))
+        side.ctx = ctx
+        side.workspace = torch.empty(workspace_bytes, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.vf_ctx_set_workspace(side.ctx, _ptr(side.workspace), workspace_bytes))
+        side.stream = torch.cuda.Stream(device=self.device)
+        _lib.check(self.lib.vf_ctx_set_stream(side.ctx, C.c_void_p(side.stream.cuda_stream)))
+        side.parent = self
+        return side
+
+    def on(self):
+        """context manager: make this (side) backend current, on its stream, after the current stream's work"""
+        return _SideScope(self)
+
+    def join(self):
+        """the current stream waits for everything issued on this side stream"""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
@@ -208,6 +233,26 @@ class HipBackend:
 
     def synchronize(self):
         _lib.check(self.lib.vf_stream_synchronize(self.ctx))
+
+
+class _SideScope:
+    def __init__(self, side):
+        self.side = side
+
+    def __enter__(self):
+        global _BACKEND
+        self.prev = _BACKEND
+        self.side.stream.wait_stream(torch.cuda.current_stream(self.side.device))
+        self.cm = torch.cuda.stream(self.side.stream)
+        self.cm.__enter__()
+        _BACKEND = self.side
+        return self.side
+
+    def __exit__(self, *exc):
+        global _BACKEND
+        _BACKEND = self.prev
+        self.cm.__exit__(*exc)
+        return False
 
 
 _BACKEND = None

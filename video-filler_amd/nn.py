@@ -342,6 +342,7 @@ class Sequential(Module):
         self.lazy_zero = lazy_zero
         self._plan = None
         self._flat = None
+        self.side = None      # optional side backend (backend.fork()): weight gradients overlap the data-grad chain
 
     def add(self, m):
         self.modules.append(m)
@@ -398,6 +399,7 @@ class Sequential(Module):
         plan = self._plan or self._build_plan()
         B = get_backend()
         g = gradOutput
+        used_side = False
         for idx in range(len(plan) - 1, -1, -1):
             m, a = plan[idx]
             x = input if idx == 0 else plan[idx - 1][0].output
@@ -412,10 +414,19 @@ class Sequential(Module):
                 if a is not None:
                     B.act_bwd(m.output, g, g, a.act, a.slope)   # in place on the incoming gradient
                     a.gradInput = g
-                gin = m.updateGradInput(x, g) if want_gx else None
-                if want_gp:
-                    m.accGradParameters(x, g, 1)
+                if want_gp and self.side is not None and m.parameters():
+                    # dW/db only read x and g; nothing on the main stream writes either before the join below
+                    with self.side.on():
+                        m.accGradParameters(x, g, 1)
+                    used_side = True
+                    gin = m.updateGradInput(x, g) if want_gx else None
+                else:
+                    gin = m.updateGradInput(x, g) if want_gx else None
+                    if want_gp:
+                        m.accGradParameters(x, g, 1)
                 g = gin
+        if used_side:
+            self.side.join()
         self.gradInput = g
         return g
 

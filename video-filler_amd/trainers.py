@@ -124,7 +124,15 @@ def _solver(opt):
 
 
 class _TrainerBase:
-    def _finish_init(self, seed, world, rank, group, sync_bn, skip_dead_grads):
+    def _finish_init(self, seed, world, rank, group, sync_bn, skip_dead_grads, overlap=True):
+        # stream-level overlap: weight gradients beside the data-gradient chain (both nets) and netG's forward
+        # beside netD's real pass.  Each side stream has its own context and workspace (backend.fork()).
+        self.side_g = None
+        B0 = get_backend()
+        if overlap and hasattr(B0, "fork"):
+            self.netD.side = B0.fork()
+            self.netG.side = self.netD.side
+            self.side_g = B0.fork()
         gen = torch.Generator().manual_seed(seed)
         weights_init(self.netG, gen)
         weights_init(self.netD, gen)
@@ -181,7 +189,7 @@ class CenterTrainer(_TrainerBase):
     """train.lua: centre-square inpainting; netD judges the 64x64 centre."""
 
     def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
-                 skip_dead_grads=True):
+                 skip_dead_grads=True, overlap=True):
         o = dict(DEFAULT_OPT_TRAIN)
         o.update(opt or {})
         self.opt = o
@@ -189,7 +197,7 @@ class CenterTrainer(_TrainerBase):
         self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, fuse, lazy_zero, sm)
         self.netD = build_netD(o["nc"], o["ndf"], False, fuse, lazy_zero, sm)
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
-        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads)
+        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn))
         self.real_label, self.fake_label = 1, 0
         self.input_ctx = self.input_center = self.input_real_center = None
 
@@ -215,6 +223,11 @@ class CenterTrainer(_TrainerBase):
         self.netD.zeroConvBiases()
         self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
+        # netG's forward does not depend on netD's real pass: issue it on a side stream (same arithmetic)
+        fake = None
+        if self.side_g is not None:
+            with self.side_g.on():
+                fake = self.netG.forward(self.input_ctx)
         # train with real
         B.copy(self.input_center, self._real_center)
         if o["wtl2"] != 0:
@@ -225,7 +238,10 @@ class CenterTrainer(_TrainerBase):
         df_do = self.criterion.backward(output, label)
         self.netD.backward(self.input_center, df_do, need_input_grad=not self.skip_dead_grads)
         # train with fake
-        fake = self.netG.forward(self.input_ctx)
+        if fake is None:
+            fake = self.netG.forward(self.input_ctx)
+        else:
+            self.side_g.join()
         B.copy(self.input_center, fake)
         label = self.fake_label
         output = self.netD.forward(self.input_center)
@@ -268,7 +284,7 @@ class VidTrainer(_TrainerBase):
     """train_vid_weighted.lua / train_wholeim_input.lua: full-frame output, netD judges the whole frame."""
 
     def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
-                 skip_dead_grads=True):
+                 skip_dead_grads=True, overlap=True):
         o = dict(DEFAULT_OPT_VID)
         o.update(opt or {})
         self.opt = o
@@ -280,7 +296,7 @@ class VidTrainer(_TrainerBase):
         self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero, sm)
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self.criterionGDL = nn.GDLCriterion(1) if o["wtgdl"] != 0 else None
-        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads)
+        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn))
         self.real_label, self.fake_label = 1, 0
         self.input_inpainted = None
 
@@ -305,12 +321,19 @@ class VidTrainer(_TrainerBase):
         if o["wtl2"] != 0:
             B.copy(self.input_real, self._real_full)
         B.copy(self.input_mask, self._real_mask)
+        fake = None
+        if self.side_g is not None:            # netG forward beside netD's real pass (independent work)
+            with self.side_g.on():
+                fake = self.netG.forward(self.input_ctx)
         label = self.real_label
         output = self.netD.forward(self.input_real)
         errD_real = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
         self.netD.backward(self.input_real, df_do, need_input_grad=not self.skip_dead_grads)
-        fake = self.netG.forward(self.input_ctx)
+        if fake is None:
+            fake = self.netG.forward(self.input_ctx)
+        else:
+            self.side_g.join()
         if o["weight_nomask"] == 0:                  # train_vid_weighted.lua:429-432
             B.masked_compose(self.input_inpainted, self.input_real, fake, self.input_mask)
         else:
