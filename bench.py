@@ -38,8 +38,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--sync-bn", action="store_true", help="N>1: all-reduce BatchNorm sums (big-batch parity mode)")
+    ap.add_argument("--force-dist", action="store_true", help="N=1: run the data-parallel path (RCCL init + all-reduce) anyway")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no dW || dX, no netG-fwd || netD-real overlap)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE JSON line: libraries that print banners there (RCCL does at init) go to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -51,8 +57,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from video_filler_amd.backend import get_backend
@@ -81,8 +88,16 @@ def main():
         wl = "train_vid_weighted.lua predLen=%d (nc=%d) nBottleneck=%d fineSize=128 batchSize=%d/GPU" % (
             predLen, nc, args.nBottleneck, args.batch)
 
-    use_graph = world == 1 and not args.no_graph
-    if use_graph:
+    dp = world > 1 or args.force_dist
+    tr.force_comm = args.force_dist
+    use_graph = not args.no_graph and not (dp and args.sync_bn)
+    if dp:
+        if use_graph:
+            tr.capture_phased(warmup=max(args.warmup, 2))
+        run = tr.step_phased
+        for _ in range(max(2, 0 if use_graph else args.warmup)):
+            run()
+    elif use_graph:
         tr.capture(warmup=max(args.warmup, 2))
         run = tr.replay
         for _ in range(2):
@@ -117,6 +132,8 @@ def main():
         # kernels are timed one at a time: switch the stream-level overlap off for this pass only
         tr.netD.side = tr.netG.side = None
         tr.side_g = None
+        tr._graphs = None
+        tr.force_comm = False
         B.prof_begin()
         for _ in range(nprof):
             tr.step()
@@ -175,15 +192,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl, "global_batch": world * args.batch, "launch": "hipGraph" if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
+            "config": {"workload": wl, "global_batch": world * args.batch, "launch": ("hipGraph x3 + RCCL between" if dp else "hipGraph") if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "losses": losses,
             "kernels": kernels,
         }
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

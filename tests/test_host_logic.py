@@ -199,12 +199,15 @@ def _dp_worker(rank, world, port, kind, out_dir):
         feed = lambda tr, lo, hi: tr.set_batch(ctx[lo:hi], full[lo:hi], mask[lo:hi])
     tr = mk(world, rank, True)
     per = B // world
+    # "vid" runs the phased step (A | all-reduce D | B | all-reduce G | C) that bench.py uses for N > 1;
+    # "center" runs the plain loop body with the exchange inside the closures.  Both must equal the big batch.
+    dp_step = tr.step_phased if kind == "vid" else tr.step
     feed(tr, rank * per, (rank + 1) * per)
-    tr.step()
+    dp_step()
     g1 = tr.gradParametersG.numpy().copy()      # after ONE iteration: gradients are comparable at fp32 precision
     rm1 = [m.running_mean.numpy().copy() for m in tr.netG.leaves() if hasattr(m, "running_mean")]
     feed(tr, rank * per, (rank + 1) * per)
-    tr.step()
+    dp_step()
     res = dict(pG=tr.parametersG.numpy().copy(), pD=tr.parametersD.numpy().copy(), gG=g1, rm=rm1)
     if rank == 0:
         one = mk(1, 0, False)                 # the single-device big batch the shards must reproduce

@@ -10,12 +10,19 @@ from .backend import get_backend
 
 
 def adam(opfunc, x, state):
+    fx, dfdx = opfunc(x)
+    adam_update(x, dfdx, state)
+    return x, [fx]
+
+
+def adam_update(x, dfdx, state):
+    """The update half of optim.adam (everything after `local fx, dfdx = opfunc(x)`), callable on its own so a
+    data-parallel step can put a gradient all-reduce between the closure and the update."""
     B = get_backend()
     lr = state.get("learningRate", 0.001)
     beta1 = state.get("beta1", 0.9)
     beta2 = state.get("beta2", 0.999)
     eps = state.get("epsilon", 1e-8)
-    fx, dfdx = opfunc(x)
     if "m" not in state:
         state["t"] = 0
         state["m"] = torch.zeros_like(x)
@@ -23,4 +30,3 @@ def adam(opfunc, x, state):
         state["t_dev"] = B.zeros(2, dtype=torch.int32)
     state["t"] += 1          # host mirror of the device counter (informational)
     B.adam_step(x, dfdx, state["m"], state["v"], lr, beta1, beta2, eps, state["t_dev"])
-    return x, [fx]

@@ -149,10 +149,17 @@ class _TrainerBase:
                         m.sync_world, m.sync_group = world, group
         self.errD = self.errG = self.errG_l2 = self.errG_gdl = None
         self._graph = None
+        self._graphs = None
+        self._defer_comm = False
+        self.force_comm = False      # run the exchange even at world == 1 (exercises the DP path on one GPU)
+
+    def _comm_on(self):
+        return self.world > 1 or self.force_comm
 
     def _allreduce_avg(self, flat):
-        """RCCL all-reduce of a flat gradient vector, then 1/world."""
-        if self.world > 1:
+        """RCCL all-reduce of a flat gradient vector, then 1/world.  Inside a phased step the
+        closure leaves both to the step (`_defer_comm`)."""
+        if self._comm_on() and not self._defer_comm:
             B = get_backend()
             B.all_reduce(flat, self.group)
             B.scale_shift(flat, 1.0 / self.world, 0.0)
@@ -162,9 +169,44 @@ class _TrainerBase:
         optim.adam(self.fDx, self.parametersD, self.optimStateD)
         optim.adam(self.fGx, self.parametersG, self.optimStateG)
 
+    # -- the same iteration cut at the two gradient exchanges (data parallel): A | all-reduce D | B | all-reduce G | C
+    def _phase_a(self):
+        self._defer_comm = True
+        self.fDx(self.parametersD)
+        self._defer_comm = False
+
+    def _phase_b(self):
+        B = get_backend()
+        B.scale_shift(self.gradParametersD, 1.0 / self.world, 0.0)
+        optim.adam_update(self.parametersD, self.gradParametersD, self.optimStateD)
+        self._defer_comm = True
+        self.fGx(self.parametersG)
+        self._defer_comm = False
+
+    def _phase_c(self):
+        B = get_backend()
+        B.scale_shift(self.gradParametersG, 1.0 / self.world, 0.0)
+        optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
+
+    def step_phased(self):
+        B = get_backend()
+        if self._graphs is not None:
+            ga, gb, gc = self._graphs
+            ga.replay()
+            B.all_reduce(self.gradParametersD, self.group)
+            gb.replay()
+            B.all_reduce(self.gradParametersG, self.group)
+            gc.replay()
+        else:
+            self._phase_a()
+            B.all_reduce(self.gradParametersD, self.group)
+            self._phase_b()
+            B.all_reduce(self.gradParametersG, self.group)
+            self._phase_c()
+
     # -- HIP graph of one whole iteration (single-GPU): zero launch gaps, no host work per step
     def capture(self, warmup=3):
-        assert self.world == 1, "graph capture covers the single-device iteration; DP runs eagerly"
+        assert not self._comm_on(), "one graph covers the single-device iteration; use capture_phased() for DP"
         B = get_backend()
         for _ in range(warmup):
             self.step()
@@ -176,6 +218,26 @@ class _TrainerBase:
         B.use_current_stream()
         self._graph = g
         return g
+
+    def capture_phased(self, warmup=3):
+        """Three graphs (phases A, B, C) with the two RCCL all-reduces launched between them.  SyncBN puts
+        collectives inside the phases, so it runs eagerly instead."""
+        B = get_backend()
+        for _ in range(warmup):
+            self.step_phased()
+        torch.cuda.synchronize()
+        graphs = []
+        pool = None
+        for phase in (self._phase_a, self._phase_b, self._phase_c):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                B.use_current_stream()
+                phase()
+            B.use_current_stream()
+            pool = g.pool()
+            graphs.append(g)
+        self._graphs = tuple(graphs)
+        return self._graphs
 
     def replay(self):
         self._graph.replay()
