@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -75,13 +76,15 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int iters, const floa
 
 template <int NACC, int MODE>
 void run(const char* name, int blocks, float* out, const float* in, const float* gbig = nullptr, size_t gbig_f4 = 0) {
-  const int iters = 2000;
+  const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 2000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k_probe<NACC, MODE><<<blocks, 256>>>(out, iters, in, gbig, gbig_f4);
+  for (int w = 0; w < 5; ++w) k_probe<NACC, MODE><<<blocks, 256>>>(out, iters, in, gbig, gbig_f4);
   hipEventRecord(e0);
-  k_probe<NACC, MODE><<<blocks, 256>>>(out, iters, in, gbig, gbig_f4);
+  const int reps = 50;
+  for (int w = 0; w < reps; ++w) k_probe<NACC, MODE><<<blocks, 256>>>(out, iters, in, gbig, gbig_f4);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
   double fl = (double)blocks * 4 * iters * 16 * 4096.0;
   printf("%-34s blocks=%5d  %8.3f ms  %7.1f TFLOP/s\n", name, blocks, ms, fl / ms / 1e9);
 }

@@ -140,6 +140,11 @@ class HipBackend:
         self._c("vf_bn_apply", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), B * H * W, Cc,
                 ACT[act], slope)
 
+    def bn_train_fwd(self, x, y, gamma, beta, rm, rv, save_mean, save_invstd, sums, momentum, eps, act="none", slope=0.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_train_fwd", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(save_mean),
+                _ptr(save_invstd), _ptr(sums), B * H * W, Cc, momentum, eps, ACT[act], slope)
+
     def bn_eval_fwd(self, x, y, gamma, beta, rm, rv, eps, act="none", slope=0.0):
         B, Cc, H, W = x.shape
         self._c("vf_bn_eval_fwd", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), B * H * W, Cc, eps,

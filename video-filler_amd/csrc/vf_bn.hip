@@ -76,21 +76,73 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, c
   }
 }
 
-// second stage: 8 columns x 32 slab lanes per block, fixed combination order (deterministic)
-__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ part, double* __restrict__ sums, int nslab,
-                                                      int twoC) {
-  const int ci = threadIdx.x & 7, lane = threadIdx.x >> 3;
-  const int i = blockIdx.x * 8 + ci;
-  double s = 0;
-  if (i < twoC)
-    for (int k = lane; k < nslab; k += 32) s += part[(int64_t)k * twoC + i];
-  __shared__ double red[32][8];
-  red[lane][ci] = s;
-  __syncthreads();
-  if (lane == 0 && i < twoC) {
-    double t = 0;
-    for (int j = 0; j < 32; ++j) t += red[j][ci];
-    sums[i] = t;
+// Second stage of every two-stage reduction: partial[slab][ncol] (double) -> per-column totals.
+// 4 columns per block, one wave (64 slab lanes) per column, 4 independent loads in flight per lane, then a fixed
+// shuffle tree: deterministic, and short enough (~16 loads per lane) to sit at the launch floor.
+//   EPI 0: sums[col] = total                                   (two-phase BN API, backward statistics)
+//   EPI 1: BatchNorm finalize fused: the block owns 2 channels = columns {c, C+c}; writes save_mean/save_invstd and
+//          updates the running statistics (THNN BatchNormalization_updateOutput, train branch); also stores sums
+//   EPI 2: bias gradient: gb[col] = beta*gb[col] + total
+template <int EPI>
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ part, int nslab, int ncol,
+                                                         double* __restrict__ sums, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                         float* __restrict__ save_invstd, double n, float momentum, float eps,
+                                                         float* __restrict__ gb, float beta) {
+  const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  int col;
+  bool ok;
+  if constexpr (EPI == 1) {
+    const int C = ncol >> 1;
+    const int c = blockIdx.x * 2 + (slot >> 1);
+    ok = c < C;
+    col = (slot & 1) * C + c;
+  } else {
+    col = blockIdx.x * 4 + slot;
+    ok = col < ncol;
+  }
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (ok) {
+    const double* p = part + col;
+    int k = lane;
+    for (; k + 192 < nslab; k += 256) {
+      s0 += p[(int64_t)k * ncol];
+      s1 += p[(int64_t)(k + 64) * ncol];
+      s2 += p[(int64_t)(k + 128) * ncol];
+      s3 += p[(int64_t)(k + 192) * ncol];
+    }
+    for (; k < nslab; k += 64) s0 += p[(int64_t)k * ncol];
+  }
+  double t = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if constexpr (EPI == 0) {
+    if (lane == 0 && ok) sums[col] = t;
+  } else if constexpr (EPI == 2) {
+    if (lane == 0 && ok) gb[col] = (beta != 0.f ? beta * gb[col] : 0.f) + (float)t;
+  } else {
+    __shared__ double tot[4];
+    if (lane == 0) tot[slot] = t;
+    __syncthreads();
+    if (lane == 0 && ok && (slot & 1) == 0) {
+      const int C = ncol >> 1;
+      const int c = blockIdx.x * 2 + (slot >> 1);
+      const double q1 = tot[slot], q2 = tot[slot + 1];
+      if (sums) {
+        sums[c] = q1;
+        sums[C + c] = q2;
+      }
+      const double shift = running_mean[c];
+      const double mean = shift + q1 / n;
+      double m2 = q2 - q1 * q1 / n;  // = sum (x - mean)^2
+      if (m2 < 0) m2 = 0;
+      const float invstd = (m2 == 0 && eps == 0.f) ? 0.f : (float)(1.0 / sqrt(m2 / n + (double)eps));
+      save_mean[c] = (float)mean;
+      save_invstd[c] = invstd;
+      running_mean[c] = (float)(momentum * mean + (1.0 - momentum) * running_mean[c]);
+      const double unbiased = m2 / (n - 1.0);  // n == 1 -> inf/NaN, as the reference
+      running_var[c] = (float)(momentum * unbiased + (1.0 - momentum) * running_var[c]);
+    }
   }
 }
 
@@ -134,11 +186,6 @@ __global__ __launch_bounds__(256) void k_colsum1(const float* __restrict__ g, do
   }
   if (threadIdx.x == 0) part[(int64_t)blockIdx.x * C + c] = red[0];
 }
-__global__ void k_colsum_final(const double* __restrict__ sums, float* __restrict__ gb, int C, float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) gb[c] = (beta != 0.f ? beta * gb[c] : 0.f) + (float)sums[c];
-}
-
 // mean/invstd + running statistics (THNN BatchNormalization_updateOutput, train branch)
 __global__ void k_bn_finalize(const double* __restrict__ sums, float* __restrict__ running_mean,
                               float* __restrict__ running_var, float* __restrict__ save_mean,
@@ -286,8 +333,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 
 // ================================================================================================ host
 static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C) {
-  hipLaunchKernelGGL(k_sum_partials, dim3((int)vf_cdiv(2 * C, 8)), dim3(256), 0, ctx->stream, (const double*)ctx->ws,
-                     sums, g.gx, 2 * C);
+  hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4)), dim3(256), 0, ctx->stream,
+                     (const double*)ctx->ws, g.gx, 2 * C, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, 0.0, 0.f, 0.f, (float*)nullptr, 0.f);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -309,10 +357,9 @@ int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C,
     hipLaunchKernelGGL(k_colsum1, dim3(nslab, C), dim3(256), 0, ctx->stream, g, part, P, C, (int)rpb);
   }
   VF_LAUNCH_CHECK();
-  double* sums = part + (int64_t)nslab * C;
-  hipLaunchKernelGGL(k_sum_partials, dim3((int)vf_cdiv(C, 8)), dim3(256), 0, ctx->stream, (const double*)part, sums, nslab, C);
-  VF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_colsum_final, dim3((int)vf_cdiv(C, 256)), dim3(256), 0, ctx->stream, (const double*)sums, gb, C, beta);
+  hipLaunchKernelGGL((k_reduce_partials<2>), dim3((int)vf_cdiv(C, 4)), dim3(256), 0, ctx->stream, (const double*)part, nslab,
+                     C, (double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.0, 0.f, 0.f,
+                     gb, beta);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -350,8 +397,20 @@ VF_API int vf_bn_apply(vf_ctx* ctx, const float* x, float* y, const float* gamma
 VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
                            int64_t npix, int C, float momentum, float eps, int act, float slope) {
-  if (int rc = vf_bn_stats(ctx, x, running_mean, sums, npix, C)) return rc;
-  if (int rc = vf_bn_finalize(ctx, sums, running_mean, running_var, save_mean, save_invstd, npix, C, momentum, eps)) return rc;
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  const BnGeom g = bn_geom(npix, C);
+  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  {
+    VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C);
+    hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, (const float*)running_mean,
+                       (double*)ctx->ws, npix, C, g.cq, g.rows_per_block);
+    VF_LAUNCH_CHECK();
+    // second stage + finalize in one launch (the single-device path needs no hook between them)
+    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 2)), dim3(256), 0, ctx->stream, (const double*)ctx->ws,
+                       g.gx, 2 * C, sums, running_mean, running_var, save_mean, save_invstd, (double)npix, momentum, eps,
+                       (float*)nullptr, 0.f);
+    VF_LAUNCH_CHECK();
+  }
   return vf_bn_apply(ctx, x, y, gamma, beta, save_mean, save_invstd, npix, C, act, slope);
 }
 

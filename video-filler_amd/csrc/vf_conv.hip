@@ -159,22 +159,39 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
       }
     }
   }
-  // uniform description of one 16-wide chunk q: (tap, byte delta for A, byte delta for W, in range)
+  // uniform description of one 16-wide chunk: (tap, byte delta for A, byte delta for W, in range).  The K loop walks
+  // chunks in order, so (tap, c0) advance incrementally — no division in the loop (a wave issues ~1 instruction per
+  // 4-5 cycles; every instruction that is not an MFMA shortens the time the matrix pipe is fed).
   struct Chunk { int tap; unsigned dA, dW; bool ok; };
-  auto chunk_of = [&](int q) {
+  const int lgTW = p.TW == 4 ? 2 : (p.TW == 2 ? 1 : 0);
+  const int sA_th = 4 * p.ty * p.Wi * p.C, sA_tw = 4 * p.tx * p.C;
+  const int sW_th = 4 * p.khs * 4 * p.wsTap, sW_tw = 4 * p.kws * p.wsTap, sW_0 = 4 * (kh0 * 4 + kw0) * p.wsTap;
+  const int sW_c = 4 * (BKM ? p.wsC : 1);
+  int it_tap = 0, it_c0 = 0, it_q = 0;     // state of the NEXT chunk to be described
+  if constexpr (V >= 1) {
+    it_q = 2 * kt0;
+    it_tap = it_q / spt;
+    it_c0 = (it_q - it_tap * spt) << 4;
+  }
+  auto next_chunk = [&]() {
     Chunk c;
-    const int tap = q / spt, c0 = (q - tap * spt) << 4;
-    const int th = tap / p.TW, tw = tap - th * p.TW;
-    c.tap = tap;
-    c.dA = 4u * (unsigned)((th * p.ty * p.Wi + tw * p.tx) * p.C + c0);
-    c.dW = 4u * (unsigned)(((kh0 + th * p.khs) * 4 + (kw0 + tw * p.kws)) * p.wsTap + c0 * (BKM ? p.wsC : 1));
-    c.ok = q < p.nq;
+    const int th = it_tap >> lgTW, tw = it_tap & (p.TW - 1);
+    c.tap = it_tap;
+    c.dA = (unsigned)(th * sA_th + tw * sA_tw + 4 * it_c0);
+    c.dW = (unsigned)(sW_0 + th * sW_th + tw * sW_tw + it_c0 * sW_c);
+    c.ok = it_q < p.nq;
+    ++it_q;
+    it_c0 += 16;
+    if (it_c0 >= p.C) {
+      it_c0 = 0;
+      ++it_tap;
+    }
     return c;
   };
 
   auto load_tile = [&](int kt) {
     if constexpr (V >= 1) {
-      const Chunk c0 = chunk_of(2 * kt), c1 = chunk_of(2 * kt + 1);   // SALU
+      const Chunk c0 = next_chunk(), c1 = next_chunk();   // SALU; load_tile is called with consecutive kt
       // ---------------- A: lanes with kh = 0 / 1 fetch chunk 0 / 1
       const int tapv = kh ? c1.tap : c0.tap;
       const unsigned dA = kh ? c1.dA : c0.dA;

@@ -199,7 +199,10 @@ class SpatialBatchNormalization(Module):
         Bn, Cc, H, W = input.shape
         assert Cc == self.nOutputPlane
         y = self._buf("output", Bn, Cc, H, W)
-        if self.train:
+        if self.train and self.sync_world == 1 and hasattr(B, "bn_train_fwd"):
+            B.bn_train_fwd(input, y, self.weight, self.bias, self.running_mean, self.running_var, self.save_mean,
+                           self.save_std, self._sums, self.momentum, self.eps, act, slope)
+        elif self.train:
             B.bn_stats(input, self.running_mean, self._sums)
             if self.sync_world > 1:
                 B.all_reduce(self._sums, self.sync_group)
