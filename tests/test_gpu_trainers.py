@@ -171,9 +171,10 @@ def test_graph_replay_matches_eager(oracle, hipb):
     b.set_batch(batch)
     for _ in range(5):
         a.step()
-    b.capture(warmup=3)          # 3 eager steps; the step issued during capture is recorded, not executed
+    b.capture(warmup=3, defer_adam_g=True)   # 3 eager steps; the step issued during capture is recorded, not executed
     b.replay()
     b.replay()
+    b.flush()                    # the graph defers Adam(G) into the next replay's netD-real window
     torch.cuda.synchronize()
     assert rel_err(to_np(b.parametersG), to_np(a.parametersG)) < 1e-6
     assert rel_err(to_np(b.parametersD), to_np(a.parametersD)) < 1e-6

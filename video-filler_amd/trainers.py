@@ -152,6 +152,9 @@ class _TrainerBase:
         self._graphs = None
         self._defer_comm = False
         self.force_comm = False      # run the exchange even at world == 1 (exercises the DP path on one GPU)
+        self.defer_adam_g = False
+        self._pending_g = False
+        self._graph_stale = False
 
     def _comm_on(self):
         return self.world > 1 or self.force_comm
@@ -165,9 +168,31 @@ class _TrainerBase:
             B.scale_shift(flat, 1.0 / self.world, 0.0)
 
     def step(self):
-        """The loop body: optim.adam(fDx, ...) ; optim.adam(fGx, ...)  (train.lua:421-424)."""
+        """The loop body: optim.adam(fDx, ...) ; optim.adam(fGx, ...)  (train.lua:421-424).
+
+        With `defer_adam_g` the update half of the second call is issued at the start of the NEXT iteration, on the
+        side stream that also runs netG's forward, beside netD's real pass (which reads no generator state): the
+        28 B/param HBM-bound update then overlaps MFMA-bound work.  Same arithmetic, same order on every buffer;
+        `flush()` applies a pending update (call it before reading parametersG)."""
         optim.adam(self.fDx, self.parametersD, self.optimStateD)
-        optim.adam(self.fGx, self.parametersG, self.optimStateG)
+        if self.defer_adam_g and self.side_g is not None:
+            self.fGx(self.parametersG)
+            self._pending_g = True
+        else:
+            optim.adam(self.fGx, self.parametersG, self.optimStateG)
+
+    def _apply_pending_g(self):
+        if self._pending_g:
+            optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
+            self._pending_g = False
+
+    def flush(self):
+        """Apply a deferred Adam(G).  A captured graph always begins with that update, so after a flush the graph
+        must not be replayed again (capture anew instead)."""
+        if self._pending_g:
+            self._apply_pending_g()
+            if self._graph is not None and self.defer_adam_g:
+                self._graph_stale = True
 
     # -- the same iteration cut at the two gradient exchanges (data parallel): A | all-reduce D | B | all-reduce G | C
     def _phase_a(self):
@@ -205,9 +230,12 @@ class _TrainerBase:
             self._phase_c()
 
     # -- HIP graph of one whole iteration (single-GPU): zero launch gaps, no host work per step
-    def capture(self, warmup=3):
+    def capture(self, warmup=3, defer_adam_g=False):
         assert not self._comm_on(), "one graph covers the single-device iteration; use capture_phased() for DP"
         B = get_backend()
+        # optional: rotate Adam(G) into the next iteration's netD-real window (measured: +2% on the video nets, nothing
+        # on train.lua's — the side stream that must also run netG's forward becomes the critical path)
+        self.defer_adam_g = bool(defer_adam_g) and self.side_g is not None
         for _ in range(warmup):
             self.step()
         torch.cuda.synchronize()
@@ -217,6 +245,8 @@ class _TrainerBase:
             self.step()
         B.use_current_stream()
         self._graph = g
+        self._graph_stale = False
+        self._pending_g = self.defer_adam_g      # the graph leaves the last iteration's Adam(G) pending
         return g
 
     def capture_phased(self, warmup=3):
@@ -240,9 +270,11 @@ class _TrainerBase:
         return self._graphs
 
     def replay(self):
+        assert not self._graph_stale, "flush() was called: the captured graph would apply Adam(G) twice; capture() again"
         self._graph.replay()
 
     def losses(self):
+        self.flush()
         out = dict(errD=self.errD, errG=self.errG, errG_l2=self.errG_l2, errG_gdl=self.errG_gdl)
         return {k: (None if v is None else float(v)) for k, v in out.items()}
 
@@ -283,12 +315,16 @@ class CenterTrainer(_TrainerBase):
     def fDx(self, x):
         B, o = get_backend(), self.opt
         self.netD.zeroConvBiases()
-        self.netG.zeroConvBiases()
+        if not self._pending_g:
+            self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
         # netG's forward does not depend on netD's real pass: issue it on a side stream (same arithmetic)
         fake = None
         if self.side_g is not None:
             with self.side_g.on():
+                if self._pending_g:               # deferred Adam(G) of the previous iteration, then the bias sweep
+                    self._apply_pending_g()
+                    self.netG.zeroConvBiases()
                 fake = self.netG.forward(self.input_ctx)
         # train with real
         B.copy(self.input_center, self._real_center)
@@ -377,7 +413,8 @@ class VidTrainer(_TrainerBase):
     def fDx(self, x):
         B, o = get_backend(), self.opt
         self.netD.zeroConvBiases()
-        self.netG.zeroConvBiases()
+        if not self._pending_g:
+            self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
         B.copy(self.input_ctx, self._real_ctx)
         if o["wtl2"] != 0:
@@ -386,6 +423,9 @@ class VidTrainer(_TrainerBase):
         fake = None
         if self.side_g is not None:            # netG forward beside netD's real pass (independent work)
             with self.side_g.on():
+                if self._pending_g:
+                    self._apply_pending_g()
+                    self.netG.zeroConvBiases()
                 fake = self.netG.forward(self.input_ctx)
         label = self.real_label
         output = self.netD.forward(self.input_real)
