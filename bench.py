@@ -95,12 +95,12 @@ def main():
         if use_graph:
             tr.capture_phased(warmup=max(args.warmup, 2))
         run = tr.step_phased
-        for _ in range(max(2, 0 if use_graph else args.warmup)):
+        for _ in range(max(args.warmup, 10) if use_graph else args.warmup):
             run()
     elif use_graph:
         tr.capture(warmup=max(args.warmup, 2))
         run = tr.replay
-        for _ in range(2):
+        for _ in range(max(args.warmup, 10)):     # untimed replays: lets clocks settle on a fresh box
             run()
     else:
         run = tr.step

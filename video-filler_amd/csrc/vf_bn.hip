@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // ================================================================================================ host
 static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C) {
   hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4)), dim3(256), 0, ctx->stream,
-                     (const double*)ctx->ws, g.gx, 2 * C, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (const double*)vf_ws_ptr(ctx), g.gx, 2 * C, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                      (float*)nullptr, 0.0, 0.f, 0.f, (float*)nullptr, 0.f);
   VF_LAUNCH_CHECK();
   return 0;
@@ -343,17 +343,17 @@ static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C) {
 // gb[c] = beta*gb[c] + sum_p g[p][c]  — shared with vf_conv.hip (bias gradients)
 int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C, float beta) {
   VfProf prof(ctx, "bias_grad", 0.0, 4.0 * (double)P * C);
-  double* part = (double*)ctx->ws;
+  double* part = (double*)vf_ws_ptr(ctx);
   int nslab;
   if (C % 4 == 0 && (((uintptr_t)g) & 15) == 0) {
     const BnGeom ge = bn_geom(P, C);
     nslab = ge.gx;
-    VF_REQUIRE((size_t)(nslab + 1) * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for bias-grad partials");
+    VF_REQUIRE((size_t)(nslab + 1) * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for bias-grad partials");
     hipLaunchKernelGGL(k_colsum4, dim3(ge.gx, ge.gy), dim3(256), 0, ctx->stream, g, part, P, C, ge.cq, ge.rows_per_block);
   } else {
     const int64_t rpb = std::max<int64_t>(256, vf_cdiv(P, std::max(1, 1024 / C)));
     nslab = (int)vf_cdiv(P, rpb);
-    VF_REQUIRE((size_t)(nslab + 1) * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for bias-grad partials");
+    VF_REQUIRE((size_t)(nslab + 1) * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for bias-grad partials");
     hipLaunchKernelGGL(k_colsum1, dim3(nslab, C), dim3(256), 0, ctx->stream, g, part, P, C, (int)rpb);
   }
   VF_LAUNCH_CHECK();
@@ -367,9 +367,9 @@ int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C,
 VF_API int vf_bn_stats(vf_ctx* ctx, const float* x, const float* shift, double* sums, int64_t npix, int C) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   const BnGeom g = bn_geom(npix, C);
-  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
   VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C);
-  hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, shift, (double*)ctx->ws, npix, C, g.cq,
+  hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, shift, (double*)vf_ws_ptr(ctx), npix, C, g.cq,
                      g.rows_per_block);
   VF_LAUNCH_CHECK();
   return run_stats(ctx, g, sums, C);
@@ -399,14 +399,14 @@ VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* g
                            int64_t npix, int C, float momentum, float eps, int act, float slope) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   const BnGeom g = bn_geom(npix, C);
-  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
   {
     VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C);
     hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, (const float*)running_mean,
-                       (double*)ctx->ws, npix, C, g.cq, g.rows_per_block);
+                       (double*)vf_ws_ptr(ctx), npix, C, g.cq, g.rows_per_block);
     VF_LAUNCH_CHECK();
     // second stage + finalize in one launch (the single-device path needs no hook between them)
-    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 2)), dim3(256), 0, ctx->stream, (const double*)ctx->ws,
+    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 2)), dim3(256), 0, ctx->stream, (const double*)vf_ws_ptr(ctx),
                        g.gx, 2 * C, sums, running_mean, running_var, save_mean, save_invstd, (double)npix, momentum, eps,
                        (float*)nullptr, 0.f);
     VF_LAUNCH_CHECK();
@@ -417,8 +417,8 @@ VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* g
 VF_API int vf_bn_eval_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, int64_t npix, int C, float eps, int act,
                           float slope) {
-  VF_REQUIRE((size_t)2 * C * sizeof(float) <= ctx->ws_bytes, "workspace too small");
-  float* mean = (float*)ctx->ws;
+  VF_REQUIRE((size_t)2 * C * sizeof(float) <= vf_ws_avail(ctx), "workspace too small");
+  float* mean = (float*)vf_ws_ptr(ctx);
   float* invstd = mean + C;
   hipLaunchKernelGGL(k_bn_eval_coeff, dim3((int)vf_cdiv(C, 256)), dim3(256), 0, ctx->stream, running_mean, running_var, mean,
                      invstd, C, eps);
@@ -431,9 +431,9 @@ VF_API int vf_bn_bwd_stats(vf_ctx* ctx, const float* x, const float* y_act, cons
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "fused activation backward needs the activated output");
   const BnGeom g = bn_geom(npix, C);
-  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= ctx->ws_bytes, "workspace too small for BN partials");
+  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
   VfProf prof(ctx, "bn_bwd_stats", 0.0, 4.0 * (double)npix * C * (act != VF_ACT_NONE ? 3 : 2));
-  hipLaunchKernelGGL(k_bn_bwd_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, save_mean, (double*)ctx->ws,
+  hipLaunchKernelGGL(k_bn_bwd_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, save_mean, (double*)vf_ws_ptr(ctx),
                      npix, C, g.cq, g.rows_per_block, act, slope);
   VF_LAUNCH_CHECK();
   return run_stats(ctx, g, sums, C);

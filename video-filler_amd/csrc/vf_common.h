@@ -16,7 +16,11 @@ struct vf_ctx {
   hipStream_t stream;
   void* ws;         // caller-owned scratch (split-K slabs, reduction partials)
   size_t ws_bytes;
+  size_t ws_front;  // bytes at the front of ws currently held by an im2col / column buffer (thin-channel passes)
 };
+
+static inline char* vf_ws_ptr(vf_ctx* c) { return (char*)c->ws + c->ws_front; }
+static inline size_t vf_ws_avail(vf_ctx* c) { return c->ws_bytes > c->ws_front ? c->ws_bytes - c->ws_front : 0; }
 
 void vf_set_error(const char* fmt, ...);
 

@@ -428,6 +428,7 @@ struct WGrad {
   int P, lgMh, lgMw;
   int Nu, Cv, Hv, Wv;
   int stride, pad;  // iy = my*stride - pad + kh
+  int ntaps;        // 16 (4x4 gather) or 1 (V already holds one K-row per pixel: the im2col form)
   int ksplit, nk;   // nk = ceil(P/16)
   float beta;
 };
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   const int ks = blockIdx.z;
   const int steps = (p.nk + p.ksplit - 1) / p.ksplit;
   const int kt0 = ks * steps, kt1 = min(p.nk, kt0 + steps);
-  const int Ncols = 16 * p.Cv;
+  const int Ncols = p.ntaps * p.Cv;
   const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
 
   // V columns owned by this thread: 4 consecutive columns starting at j0 + 4*cq
@@ -620,6 +621,38 @@ __global__ void k_dot_bwd_weight(const float* __restrict__ x, const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Thin-output transposed passes (image side of the nets: N = 3, 12 ...: netG's last full-conv, netD's first-layer
+// data-grad).  A 32-wide MFMA tile would be >60% padding there, so the pass runs as a plain GEMM to a column matrix
+//   cols[B*Hi*Wi][16*N] = A[pixel][:] . W[:][(kh,kw,n)]        (the [c][kh][kw][n] weights ARE that [C][16N] matrix)
+// followed by k_col2im4x4, in which every output pixel gathers its 4 taps (+bias, activation).  Measured 98 -> 30 us.
+// (The mirror-image trick for thin INPUTS — im2col then GEMM — was measured slower than the scalar-gather path of
+// k_igemm<V=0> for these K = 48 problems and is not used.)
+__global__ __launch_bounds__(256) void k_col2im4x4(const float* __restrict__ cols, const float* __restrict__ bias,
+                                                   float* __restrict__ y, int B, int lgHi, int lgWi, int N, int act, float slope) {
+  // stride 2, pad 1: output (oh, ow) = (2i-1+kh, 2j-1+kw)  =>  kh = (oh+1) & 1 + 2*th, i = (oh+1-kh)/2
+  const int Hi = 1 << lgHi, Wi = 1 << lgWi;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t total = ((int64_t)B << (lgHi + lgWi + 2)) * N;
+  if (t >= total) return;
+  const int n = (int)(t % N);
+  const int64_t pix = t / N;
+  const int ow = (int)(pix & (2 * Wi - 1)), oh = (int)((pix >> (lgWi + 1)) & (2 * Hi - 1)), b = (int)(pix >> (lgWi + lgHi + 2));
+  float s = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int th = 0; th < 2; ++th) {
+    const int kh = ((oh + 1) & 1) + 2 * th, i = (oh + 1 - kh) >> 1;
+    if ((unsigned)i >= (unsigned)Hi) continue;
+#pragma unroll
+    for (int tw = 0; tw < 2; ++tw) {
+      const int kw = ((ow + 1) & 1) + 2 * tw, j = (ow + 1 - kw) >> 1;
+      if ((unsigned)j >= (unsigned)Wi) continue;
+      s += cols[((((int64_t)b << lgHi) + i) * Wi + j) * (16 * N) + (kh * 4 + kw) * N + n];
+    }
+  }
+  y[t] = vf_act_apply(s, act, slope);
+}
+
 // ================================================================================================ host
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -682,13 +715,13 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   if (blocks < tune_split_blocks * 3 / 4 && g.nk >= 8) {
     ksplit = (int)std::min<int64_t>(g.nk / 4, vf_cdiv(tune_split_blocks, blocks));
     const size_t slab_bytes = (size_t)g.out_elems * sizeof(float);
-    while (ksplit > 1 && (size_t)ksplit * slab_bytes > ctx->ws_bytes) --ksplit;
+    while (ksplit > 1 && (size_t)ksplit * slab_bytes > vf_ws_avail(ctx)) --ksplit;
     if (ksplit < 1) ksplit = 1;
     const int steps = (int)vf_cdiv(g.nk, ksplit);  // avoid empty trailing splits
     ksplit = (int)vf_cdiv(g.nk, steps);
   }
   g.ksplit = ksplit;
-  g.slab = ksplit > 1 ? (float*)ctx->ws : nullptr;
+  g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
   static const int tune_dbg = getenv("VF_IGEMM_DBG") ? atoi(getenv("VF_IGEMM_DBG")) : 0;
   g.dbg = tune_dbg;
   dim3 grid(gm, gn, zpar * ksplit);
@@ -766,6 +799,35 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
   g.act = act; g.slope = slope;
   const bool vecA = (C % 16 == 0) && aligned16(A);
   bool vecB = (N % 4 == 0) && aligned16(w);
+  if (stride == 2 && N < 32 && vecA && aligned16(w) && ctx->ws_front == 0) {
+    const int64_t Mi = (int64_t)B * Hi * Wi;
+    const size_t col_bytes = (size_t)Mi * 16 * N * sizeof(float);
+    if (col_bytes + ((size_t)32 << 20) <= ctx->ws_bytes) {
+      // thin output: cols[pixel][(kh,kw,n)] = A[pixel][:] . W[:][(kh,kw,n)]  (columns contiguous in [c][kh][kw][n]), then
+      // every output pixel gathers its 4 taps
+      float* cols = (float*)ctx->ws;
+      ctx->ws_front = (col_bytes + 255) & ~(size_t)255;
+      IGemm q;
+      memset(&q, 0, sizeof(q));
+      q.A = A; q.Wt = w; q.bias = nullptr; q.Y = cols;
+      q.M = (int)Mi; q.lgMh = 0; q.lgMw = 0;
+      q.Hi = 1; q.Wi = 1; q.C = C; q.N = 16 * N;
+      q.TH = 1; q.TW = 1; q.sy = 1; q.ty = 1; q.sx = 1; q.tx = 1; q.khs = 1; q.kws = 1;
+      q.wsN = 1; q.wsC = 16 * N; q.wsTap = 0;
+      q.outH = 1; q.outW = 1; q.osy = 1; q.osx = 1;
+      q.out_elems = Mi * 16 * N;
+      q.act = VF_ACT_NONE;
+      const int rc = launch_igemm(ctx, q, true, true);
+      ctx->ws_front = 0;
+      if (rc) return rc;
+      const int64_t total = Mi * 4 * N;
+      VfProf prof(ctx, "col2im4x4", 0.0, 4.0 * ((double)Mi * 16 * N + (double)total));
+      hipLaunchKernelGGL(k_col2im4x4, dim3((unsigned)vf_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const float*)cols, bias, Y,
+                         B, vf_ilog2(Hi), vf_ilog2(Wi), N, act, slope);
+      VF_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (stride == 2) {
     // output (2*Hi) x (2*Wi); per parity class a 2x2-tap GEMM over the low-res grid
     g.lgMh = vf_ilog2(Hi); g.lgMw = vf_ilog2(Wi);
@@ -808,7 +870,7 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
 
 // dW[n][kh][kw][c] = beta*dW + sum_p U[p][n] * V[b, my*s-pad+kh, mx*s-pad+kw, c]
 static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, int Hl, int Wl, int Nu, int Hv, int Wv,
-                 int Cv, int stride, int pad, float beta) {
+                 int Cv, int stride, int pad, float beta, int ntaps = 16) {
   WGrad g;
   memset(&g, 0, sizeof(g));
   g.U = U; g.V = V; g.dW = dW;
@@ -816,6 +878,7 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.lgMh = vf_ilog2(Hl); g.lgMw = vf_ilog2(Wl);
   g.Nu = Nu; g.Cv = Cv; g.Hv = Hv; g.Wv = Wv;
   g.stride = stride; g.pad = pad;
+  g.ntaps = ntaps;
   g.nk = (int)vf_cdiv(g.P, 16);
   VF_REQUIRE((int64_t)g.P * Nu < ((int64_t)1 << 29) && (int64_t)B * Hv * Wv * Cv < ((int64_t)1 << 29),
              "operand exceeds the 2 GiB buffer-descriptor range");
@@ -825,22 +888,22 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   const bool vecV = (Cv % 4 == 0) && aligned16(V);
   g.beta = beta;
   const int BM = Nu > 64 ? 128 : 64;
-  const int gy = (int)vf_cdiv(Nu, BM), gx = (int)vf_cdiv(16 * (int64_t)Cv, 128);
+  const int gy = (int)vf_cdiv(Nu, BM), gx = (int)vf_cdiv(ntaps * (int64_t)Cv, 128);
   const int64_t blocks = (int64_t)gx * gy;
-  const int64_t total = (int64_t)Nu * 16 * Cv;
+  const int64_t total = (int64_t)Nu * ntaps * Cv;
   int ksplit = 1;
   if (blocks < 384 && g.nk >= 16) {
     ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(512, blocks));
-    while (ksplit > 1 && (size_t)ksplit * total * sizeof(float) > ctx->ws_bytes) --ksplit;
+    while (ksplit > 1 && (size_t)ksplit * total * sizeof(float) > vf_ws_avail(ctx)) --ksplit;
     if (ksplit < 1) ksplit = 1;
     const int steps = (int)vf_cdiv(g.nk, ksplit);
     ksplit = (int)vf_cdiv(g.nk, steps);
   }
   g.ksplit = ksplit;
-  g.slab = ksplit > 1 ? (float*)ctx->ws : nullptr;
+  g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
   dim3 grid(gx, gy, ksplit), block(256);
   {
-    VfProf prof(ctx, BM == 128 ? "wgrad_128x128" : "wgrad_64x128", 2.0 * (double)g.P * Nu * 16.0 * Cv, 0.0);
+    VfProf prof(ctx, BM == 128 ? "wgrad_128x128" : "wgrad_64x128", 2.0 * (double)g.P * Nu * (double)ntaps * Cv, 0.0);
 #define VF_WG(BM_)                                                                                  \
   do {                                                                                              \
     if (vecU && vecV)                                                                               \

@@ -32,6 +32,7 @@ VF_API int vf_ctx_create(vf_ctx** out, int device, void* stream) {
   c->stream = (hipStream_t)stream;
   c->ws = nullptr;
   c->ws_bytes = 0;
+  c->ws_front = 0;
   *out = c;
   return 0;
 }
