@@ -303,3 +303,38 @@ def test_adam(oracle, hipb):
     assert int(t_dev[0].item()) == 3
     np.testing.assert_allclose(to_np(m[:n]), state["m"], rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(to_np(v[:n]), state["v"], rtol=1e-6, atol=1e-15)
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 8, 8), (16, 4000, 1, 1), (8, 512, 4, 4), (2, 64, 128, 64), (4, 128, 64, 64)])
+@pytest.mark.parametrize("act", ["none", "lrelu"])
+def test_batchnorm_fused_entry_points(shape, act, oracle, hipb):
+    """vf_bn_train_fwd / vf_bn_bwd: the single-launch channel-sliced kernels (npix <= 8192) and the three-launch
+    path (larger tensors) behind the same entry points."""
+    B, C, H, W = shape
+    rng = np.random.default_rng(C + H)
+    ref = oracle.SpatialBatchNormalization(C)
+    ref.weight[...] = 1 + 0.1 * _rand(rng, C)
+    ref.bias[...] = 0.1 * _rand(rng, C)
+    ref.running_mean[...] = 0.2 * _rand(rng, C)
+    rm0, rv0 = ref.running_mean.copy(), ref.running_var.copy()
+    x = (_rand(rng, *shape) * 1.3 + 0.4).astype(np.float32)
+    y = ref.forward(x).copy()
+    slope = 0.2
+    ya = np.where(y > 0, y, slope * y).astype(np.float32) if act == "lrelu" else y
+    gy = _rand(rng, *shape)
+    g_eff = np.where(ya > 0, gy, slope * gy).astype(np.float32) if act == "lrelu" else gy
+    ref.backward(x, g_eff)
+    dx, dy = to_dev(x, hipb), hipb.empty_act(*shape)
+    gamma, beta = to_dev(ref.weight, hipb), to_dev(ref.bias, hipb)
+    rm, rv, sm, si = to_dev(rm0, hipb), to_dev(rv0, hipb), hipb.zeros(C), hipb.zeros(C)
+    sums = hipb.zeros(2 * C, dtype=torch.float64)
+    hipb.bn_train_fwd(dx, dy, gamma, beta, rm, rv, sm, si, sums, 0.1, 1e-5, act, slope)
+    assert_close(to_np(dy), ya, 1e-5, "bn fused fwd")
+    assert_close(to_np(rm), ref.running_mean, 1e-5, "running_mean")
+    assert_close(to_np(rv), ref.running_var, 1e-5, "running_var")
+    assert_close(to_np(si), ref.save_std, 1e-5, "save_invstd")
+    dgx, gg, gb = hipb.empty_act(*shape), hipb.zeros(C), hipb.zeros(C)
+    hipb.bn_bwd(dx, dy if act != "none" else None, to_dev(gy, hipb), dgx, gg, gb, gamma, sm, si, sums, act, slope, 0.0)
+    assert_close(to_np(dgx), ref.gradInput, 5e-5, "bn fused gradInput")
+    assert_close(to_np(gg), ref.gradWeight, 2e-5, "bn fused gradWeight")
+    assert_close(to_np(gb), ref.gradBias, 2e-5, "bn fused gradBias")

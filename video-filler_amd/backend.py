@@ -161,6 +161,11 @@ class HipBackend:
         self._c("vf_bn_bwd_apply", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
                 _ptr(save_mean), _ptr(save_invstd), _ptr(sums), B * H * W, n_total, Cc, ACT[act], slope, pbeta)
 
+    def bn_bwd(self, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, act="none", slope=0.0, pbeta=1.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_bwd", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
+                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), B * H * W, Cc, ACT[act], slope, pbeta)
+
     # ---- pointwise
     def act_fwd(self, x, y, act, slope=0.0):
         self._c("vf_act_fwd", _ptr(x), _ptr(y), x.numel(), ACT[act], slope)

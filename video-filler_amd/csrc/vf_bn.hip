@@ -6,6 +6,8 @@
 // combined in a fixed order (deterministic).  Statistics are shifted by the running mean so that
 // var = E[(x-s)^2] - E[x-s]^2 does not cancel catastrophically; the two-phase split (stats | finalize+apply)
 // is the hook where a data-parallel caller all-reduces the per-channel sums (SyncBN).
+// (Measured and rejected: a single-launch form in which a block owns one float4 channel column over all rows — 22 us
+// per 2 MB tensor against ~17 us for the three launches; too few blocks to pull L2 bandwidth.)
 #include <algorithm>
 
 #include "vf_common.h"
@@ -454,6 +456,7 @@ VF_API int vf_bn_bwd_apply(vf_ctx* ctx, const float* x, const float* y_act, cons
 VF_API int vf_bn_bwd(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
                      float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
                      int64_t npix, int C, int act, float slope, float pbeta) {
+  VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "fused activation backward needs the activated output");
   if (int rc = vf_bn_bwd_stats(ctx, x, y_act, gy, save_mean, sums, npix, C, act, slope)) return rc;
   return vf_bn_bwd_apply(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix, npix, C, act, slope,
                          pbeta);

@@ -219,11 +219,15 @@ class SpatialBatchNormalization(Module):
         input, gradOutput = to_nhwc(input), to_nhwc(gradOutput)
         Bn, Cc, H, W = input.shape
         gx = self._buf("gradInput", Bn, Cc, H, W) if want_gx else None
-        B.bn_bwd_stats(input, y_act, gradOutput, self.save_mean, self._sums, act, slope)
         pbeta = 1.0
         if want_gp:
             pbeta = 0.0 if self._fresh else 1.0
             self._fresh = False
+        if self.sync_world == 1 and hasattr(B, "bn_bwd"):
+            B.bn_bwd(input, y_act, gradOutput, gx, self.gradWeight if want_gp else None, self.gradBias if want_gp else None,
+                     self.weight, self.save_mean, self.save_std, self._sums, act, slope, pbeta)
+            return gx
+        B.bn_bwd_stats(input, y_act, gradOutput, self.save_mean, self._sums, act, slope)
         n_total = Bn * H * W * self.sync_world
         if self.sync_world > 1:
             # SyncBN: gamma/beta gradients come from THIS rank's sums (the flat-gradient all-reduce adds the other
