@@ -182,3 +182,32 @@ def test_graph_replay_matches_eager(oracle, hipb):
     la, lb = a.losses(), b.losses()
     for k in ("errD", "errG", "errG_l2"):
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k]))
+
+
+def test_netG_evaluate_mode_forward(oracle, hipb):
+    """test_vid.lua:47-48,102: util.load(net); net:evaluate(); net:forward(input) — BatchNorm uses running statistics."""
+    from video_filler_amd.trainers import build_netG
+    rng = np.random.default_rng(42)
+    ref = oracle.build_netG(6, 6, 16, 16, 64, True)
+    oracle.weights_init(ref, rng)
+    pref, _ = ref.getParameters()
+    net = build_netG(6, 6, 16, 16, 64, True)
+    net.getParameters()
+    net.load_reference_flat(torch.from_numpy(pref.copy()).to(hipb.device))
+    rb = [m for m in _leaves(ref) if hasattr(m, "running_mean")]
+    hb = [m for m in net.leaves() if hasattr(m, "running_mean")]
+    for a, b in zip(rb, hb):
+        a.running_mean[...] = 0.1 * rng.standard_normal(a.running_mean.shape).astype(np.float32)
+        a.running_var[...] = (1 + 0.3 * rng.random(a.running_var.shape)).astype(np.float32)
+        b.running_mean.copy_(torch.from_numpy(a.running_mean).to(hipb.device))
+        b.running_var.copy_(torch.from_numpy(a.running_var).to(hipb.device))
+    ref.evaluate()
+    net.evaluate()
+    x = rng.uniform(-1, 1, (2, 6, 128, 128)).astype(np.float32)
+    want = ref.forward(x.copy())
+    got = net.forward(torch.from_numpy(x).to(hipb.device))
+    assert tuple(got.shape) == want.shape == (2, 6, 128, 128)
+    assert rel_err(to_np(got), want) < 5e-5
+    # evaluate mode must not touch the running statistics
+    for a, b in zip(rb, hb):
+        np.testing.assert_array_equal(to_np(b.running_mean), a.running_mean)

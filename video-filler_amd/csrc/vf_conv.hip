@@ -41,6 +41,16 @@ __device__ __forceinline__ float vf_bload1(__amdgpu_buffer_rsrc_t r, unsigned by
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+// XCD-aware block order.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its
+// own 4 MiB L2), so neighbouring tiles — which share input halos (k_igemm) or the whole gathered operand (k_wgrad's
+// column tiles) — land on different L2s and every one of them fetches the shared rows from the fabric again
+// (measured with FETCH_SIZE: 3-5x the algorithmic bytes).  This bijective remap gives each XCD one contiguous run of
+// logical tile ids instead; it only ever changes speed, never results.
+__device__ __forceinline__ int vf_xcd_remap(int h, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = h & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (h >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------
 struct IGemm {
   const float* A;     // gathered activations [B][Hi][Wi][C]
@@ -59,6 +69,7 @@ struct IGemm {
   int wsN, wsC, wsTap;             // weight offset = n*wsN + (kh*4+kw)*wsTap + c*wsC   (all tensors < 2^31 elements)
   int outH, outW, osy, ooy0, osx, oox0;  // output pixel = (my*osy + ooy0, mx*osx + oox0)
   int parity;                      // 1: z&3 = (ph<<1)|pw shifts oy0/ox0/ooy0/oox0 and selects kh0/kw0
+  int gm, gn, gz;                  // logical grid (the launch is 1-D, remapped per XCD)
   int ksplit, nk, nq;              // K steps (of 32), number of splits, 16-wide chunks on the vector path
   int dbg;                         // ablation switches (timing experiments only; wrong results): 1 no reload, 2 no LDS restage
   int act;
@@ -83,14 +94,18 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  int z = blockIdx.z;
+  // logical tile id: output parity fastest (the 4 parity classes of a transposed pass read the same input rows),
+  // then M tiles (halo sharing), then N tiles, then split-K
+  int lid = vf_xcd_remap(blockIdx.x, p.gm * p.gn * p.gz);
   int ph = 0, pw = 0;
   if (p.parity) {
-    ph = (z >> 1) & 1;
-    pw = z & 1;
-    z >>= 2;
+    ph = (lid >> 1) & 1;
+    pw = lid & 1;
+    lid >>= 2;
   }
+  const int bx = lid % p.gm, byz = lid / p.gm;
+  const int m0 = bx * BM, n0 = (byz % p.gn) * BN;
+  const int z = byz / p.gn;
   const int ks = z;
   const int steps = (p.nk + p.ksplit - 1) / p.ksplit;
   const int kt0 = ks * steps;
@@ -100,7 +115,6 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   const int ooy0 = p.ooy0 + ph, oox0 = p.oox0 + pw;
   const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
   const int Ktot = p.TH * p.TW * p.C;
-  const int spt = p.C >> 4;  // K steps per tap on the chunked (V >= 1) path
 
   // ---- per-thread A rows (fixed for the whole K loop)
   int a_iy0[A_CH], a_ix0[A_CH], a_boff[A_CH];
@@ -168,10 +182,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   const int sW_th = 4 * p.khs * 4 * p.wsTap, sW_tw = 4 * p.kws * p.wsTap, sW_0 = 4 * (kh0 * 4 + kw0) * p.wsTap;
   const int sW_c = 4 * (BKM ? p.wsC : 1);
   int it_tap = 0, it_c0 = 0, it_q = 0;     // state of the NEXT chunk to be described
+  const int ntaps = p.TH * p.TW;
   if constexpr (V >= 1) {
+    // chunk order: channel chunk OUTER, tap INNER — the 16 taps of one channel chunk touch the same input window, so
+    // the re-reads are temporally close (L1/L2 hits) instead of one full window sweep per tap
     it_q = 2 * kt0;
-    it_tap = it_q / spt;
-    it_c0 = (it_q - it_tap * spt) << 4;
+    it_c0 = (it_q / ntaps) << 4;
+    it_tap = it_q % ntaps;
   }
   auto next_chunk = [&]() {
     Chunk c;
@@ -181,10 +198,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     c.dW = (unsigned)(sW_0 + th * sW_th + tw * sW_tw + it_c0 * sW_c);
     c.ok = it_q < p.nq;
     ++it_q;
-    it_c0 += 16;
-    if (it_c0 >= p.C) {
-      it_c0 = 0;
-      ++it_tap;
+    if (++it_tap >= ntaps) {
+      it_tap = 0;
+      it_c0 += 16;
     }
     return c;
   };
@@ -428,7 +444,8 @@ struct WGrad {
   int P, lgMh, lgMw;
   int Nu, Cv, Hv, Wv;
   int stride, pad;  // iy = my*stride - pad + kh
-  int ntaps;        // 16 (4x4 gather) or 1 (V already holds one K-row per pixel: the im2col form)
+  int ntaps;        // 16 (4x4 gather) or 1 (V already holds one K-row per pixel)
+  int gx, gy, gz;   // logical grid (1-D launch, remapped per XCD)
   int ksplit, nk;   // nk = ceil(P/16)
   float beta;
 };
@@ -448,8 +465,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
-  const int n0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-  const int ks = blockIdx.z;
+  const int lid = vf_xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int n0 = ((lid / p.gx) % p.gy) * BM, j0 = (lid % p.gx) * BN;
+  const int ks = lid / (p.gx * p.gy);
   const int steps = (p.nk + p.ksplit - 1) / p.ksplit;
   const int kt0 = ks * steps, kt1 = min(p.nk, kt0 + steps);
   const int Ncols = p.ntaps * p.Cv;
@@ -724,7 +742,8 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
   static const int tune_dbg = getenv("VF_IGEMM_DBG") ? atoi(getenv("VF_IGEMM_DBG")) : 0;
   g.dbg = tune_dbg;
-  dim3 grid(gm, gn, zpar * ksplit);
+  g.gm = gm; g.gn = gn; g.gz = zpar * ksplit;
+  dim3 grid((unsigned)gm * gn * zpar * ksplit);
   char pname[64];
   snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "");
   {
@@ -901,7 +920,8 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   }
   g.ksplit = ksplit;
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
-  dim3 grid(gx, gy, ksplit), block(256);
+  g.gx = gx; g.gy = gy; g.gz = ksplit;
+  dim3 grid((unsigned)gx * gy * ksplit), block(256);
   {
     VfProf prof(ctx, BM == 128 ? "wgrad_128x128" : "wgrad_64x128", 2.0 * (double)g.P * Nu * (double)ntaps * Cv, 0.0);
 #define VF_WG(BM_)                                                                                  \
