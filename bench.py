@@ -129,15 +129,23 @@ def main():
     if rank == 0:
         B.use_current_stream()
         nprof = 3
-        # kernels are timed one at a time: switch the stream-level overlap off for this pass only
-        tr.netD.side = tr.netG.side = None
-        tr.side_g = None
+        # Pass 1: same stream set-up as the timed region (with overlap on, a kernel's duration includes what it
+        # shares the chip with).  Eager launches so that each one can carry its own start/stop events.
         tr._graphs = None
         tr.force_comm = False
         B.prof_begin()
         for _ in range(nprof):
             tr.step()
         kernels = B.prof_end()
+        isolated = None
+        if tr.side_g is not None or tr.netD.side is not None:
+            # Pass 2: one stream, every kernel alone on the chip (what `--no-overlap` times)
+            tr.netD.side = tr.netG.side = None
+            tr.side_g = None
+            B.prof_begin()
+            for _ in range(nprof):
+                tr.step()
+            isolated = B.prof_end()
         tot = sum(k["ms"] for k in kernels.values())
         name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = dom["ms"] / dom["launches"]
@@ -151,6 +159,13 @@ def main():
             roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, avg_launch_us=round(avg_ms * 1e3, 2),
                             launches_per_step=dom["launches"] / nprof, share_of_step=round(dom["ms"] / tot, 3))
+        if isolated is not None and name in isolated and isolated[name]["flops"] > 0:
+            iso = isolated[name]
+            iavg = iso["ms"] / iso["launches"]
+            iach = iso["flops"] / iso["launches"] / (iavg * 1e-3) / 1e12
+            roofline["isolated"] = dict(achieved=round(iach, 2), frac=round(iach / PEAK_F32_MFMA_TFLOPS, 4),
+                                        avg_launch_us=round(iavg * 1e3, 2),
+                                        note="same kernel with nothing else on the chip (single stream; bench.py --no-overlap)")
         kernels = {k: dict(launches_per_step=v["launches"] / nprof, ms_per_step=round(v["ms"] / nprof, 4),
                            tflops=(round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 and v["ms"] > 0 else None),
                            gbs=(round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] > 0 and v["ms"] > 0 else None))

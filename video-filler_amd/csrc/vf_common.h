@@ -1,6 +1,7 @@
 // vf_common.h — shared host-side plumbing for the gfx950 backend (context, error reporting, launch checks).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -56,6 +57,18 @@ struct VfProf {
     if (on) vf_prof_push(c, nullptr, 0, 0, false);
   }
 };
+
+// Single-kernel launches are timed with hipExtLaunchKernelGGL's start/stop events: the elapsed time is the kernel's own
+// execution (what rocprofv3's kernel trace reports), without the launch gap an event pair around the call would add.
+bool vf_prof_ext(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
+#define VF_LAUNCH_TIMED(ctx, name, flops, bytes, kernel, grid, block, ...)                                   \
+  do {                                                                                                       \
+    hipEvent_t _e0, _e1;                                                                                     \
+    if (vf_prof_ext(name, flops, bytes, &_e0, &_e1))                                                         \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, _e0, _e1, 0, __VA_ARGS__);                \
+    else                                                                                                     \
+      hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);                                \
+  } while (0)
 
 static inline int vf_ilog2(int v) {  // v must be a power of two
   int l = 0;

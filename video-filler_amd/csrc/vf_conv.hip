@@ -675,20 +675,20 @@ __global__ __launch_bounds__(256) void k_col2im4x4(const float* __restrict__ col
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v) {
+static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
   dim3 block(256);
   if (!bkm) {
     if (v == 2)
-      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, false, 2>), grid, block, 0, ctx->stream, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2>), grid, block, g);
     else
-      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, false, 0>), grid, block, 0, ctx->stream, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 0>), grid, block, g);
   } else {
     if (v == 2)
-      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, true, 2>), grid, block, 0, ctx->stream, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 2>), grid, block, g);
     else if (v == 1)
-      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, true, 1>), grid, block, 0, ctx->stream, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 1>), grid, block, g);
     else
-      hipLaunchKernelGGL((k_igemm<BM, BN, WM, WN, true, 0>), grid, block, 0, ctx->stream, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 0>), grid, block, g);
   }
 }
 
@@ -747,17 +747,17 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   char pname[64];
   snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "");
   {
-    VfProf prof(ctx, pname, 2.0 * (double)g.M * g.N * Ktot * zpar, 0.0);
+    const double fl = 2.0 * (double)g.M * g.N * Ktot * zpar;
     if (t.bm == 256)
-      launch_igemm_tile<256, 32, 64, 32>(ctx, g, grid, bkm, v);
+      launch_igemm_tile<256, 32, 64, 32>(ctx, g, grid, bkm, v, pname, fl);
     else if (t.bm == 128 && t.bn == 128)
-      launch_igemm_tile<128, 128, 64, 64>(ctx, g, grid, bkm, v);
+      launch_igemm_tile<128, 128, 64, 64>(ctx, g, grid, bkm, v, pname, fl);
     else if (t.bm == 128)
-      launch_igemm_tile<128, 64, 64, 32>(ctx, g, grid, bkm, v);
+      launch_igemm_tile<128, 64, 64, 32>(ctx, g, grid, bkm, v, pname, fl);
     else if (t.bn == 128)
-      launch_igemm_tile<64, 128, 64, 32>(ctx, g, grid, bkm, v);
+      launch_igemm_tile<64, 128, 64, 32>(ctx, g, grid, bkm, v, pname, fl);
     else
-      launch_igemm_tile<64, 64, 32, 32>(ctx, g, grid, bkm, v);
+      launch_igemm_tile<64, 64, 32, 32>(ctx, g, grid, bkm, v, pname, fl);
   }
   VF_LAUNCH_CHECK();
   if (ksplit > 1) {
@@ -923,17 +923,18 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.gx = gx; g.gy = gy; g.gz = ksplit;
   dim3 grid((unsigned)gx * gy * ksplit), block(256);
   {
-    VfProf prof(ctx, BM == 128 ? "wgrad_128x128" : "wgrad_64x128", 2.0 * (double)g.P * Nu * (double)ntaps * Cv, 0.0);
+    const char* wname = BM == 128 ? "wgrad_128x128" : "wgrad_64x128";
+    const double wfl = 2.0 * (double)g.P * Nu * (double)ntaps * Cv;
 #define VF_WG(BM_)                                                                                  \
   do {                                                                                              \
     if (vecU && vecV)                                                                               \
-      hipLaunchKernelGGL((k_wgrad<BM_, true, true>), grid, block, 0, ctx->stream, g);               \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, true, true>), grid, block, g);            \
     else if (vecU)                                                                                  \
-      hipLaunchKernelGGL((k_wgrad<BM_, true, false>), grid, block, 0, ctx->stream, g);              \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, true, false>), grid, block, g);           \
     else if (vecV)                                                                                  \
-      hipLaunchKernelGGL((k_wgrad<BM_, false, true>), grid, block, 0, ctx->stream, g);              \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, false, true>), grid, block, g);           \
     else                                                                                            \
-      hipLaunchKernelGGL((k_wgrad<BM_, false, false>), grid, block, 0, ctx->stream, g);             \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, false, false>), grid, block, g);          \
   } while (0)
     if (BM == 128)
       VF_WG(128);

@@ -108,6 +108,19 @@ void vf_prof_push(vf_ctx* ctx, const char* name, double flops, double bytes, boo
     hipEventRecord(g_prof_recs.back().e1, ctx->stream);
   }
 }
+bool vf_prof_ext(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1) {
+  if (!g_prof_on) return false;
+  ProfRec r;
+  r.name = name;
+  r.flops = flops;
+  r.bytes = bytes;
+  hipEventCreate(&r.e0);
+  hipEventCreate(&r.e1);
+  *e0 = r.e0;
+  *e1 = r.e1;
+  g_prof_recs.push_back(r);
+  return true;
+}
 VF_API int vf_prof_begin(vf_ctx* ctx) {
   VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   g_prof_recs.clear();
@@ -494,9 +507,8 @@ VF_API int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* 
   VF_REQUIRE((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam operands must be 16-byte aligned");
   hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, ctx->stream, t_dev, lr, beta1, beta2);
   VF_LAUNCH_CHECK();
-  VfProf prof(ctx, "adam", 0.0, 28.0 * (double)n);
-  hipLaunchKernelGGL(k_adam, dim3(grid_for(n, 4)), dim3(256), 0, ctx->stream, x, g, m, v, n, (float)beta1, (float)(1.0 - beta1),
-                     (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
+  VF_LAUNCH_TIMED(ctx, "adam", 0.0, 28.0 * (double)n, k_adam, dim3(grid_for(n, 4)), dim3(256), x, g, m, v, n, (float)beta1,
+                  (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
   VF_LAUNCH_CHECK();
   return 0;
 }
