@@ -207,7 +207,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl, "global_batch": world * args.batch, "launch": ("hipGraph x3 + RCCL between" if dp else "hipGraph") if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
+            "config": {"workload": wl, "global_batch": world * args.batch, "launch": ("hipGraph x4 + bucketed RCCL all-reduce between (G tail bucket overlaps the encoder backward)" if dp else "hipGraph") if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -184,6 +184,43 @@ def test_graph_replay_matches_eager(oracle, hipb):
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k]))
 
 
+@pytest.mark.parametrize("kind", ["center", "vid"])
+def test_phased_dp_step_over_rccl_matches_plain_step(kind, oracle, hipb):
+    """The data-parallel iteration (4 HIP graphs with RCCL all-reduce-average between them, G's gradient in two
+    buckets, the tail one in flight during the encoder's backward) on a world of ONE rank must walk exactly the
+    trajectory of the plain loop body: averaging over one rank is the identity."""
+    import os
+    import torch.distributed as dist
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if kind == "center":
+        opt = dict(nBottleneck=256, wtl2=0.999, overlapPred=4)
+        batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)
+        mk = lambda: CenterTrainer(opt, seed=3)
+    else:
+        opt = dict(nBottleneck=256, predLen=2)
+        batch = tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(4, np.random.default_rng(5), 6))
+        mk = lambda: VidTrainer(opt, seed=3)
+    a, b = mk(), mk()
+    a.set_batch(*batch)
+    b.set_batch(*batch)
+    b.force_comm = True
+    for _ in range(5):
+        a.step()
+    b.capture_phased(warmup=3)
+    b.step_phased()
+    b.step_phased()
+    torch.cuda.synchronize()
+    assert torch.equal(b.parametersG, a.parametersG)
+    assert torch.equal(b.parametersD, a.parametersD)
+    la, lb = a.losses(), b.losses()
+    for k in ("errD", "errG", "errG_l2"):
+        assert abs(la[k] - lb[k]) <= 1e-9 * max(1.0, abs(la[k]))
+
+
 def test_netG_evaluate_mode_forward(oracle, hipb):
     """test_vid.lua:47-48,102: util.load(net); net:evaluate(); net:forward(input) — BatchNorm uses running statistics."""
     from video_filler_amd.trainers import build_netG

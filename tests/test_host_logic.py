@@ -110,6 +110,34 @@ def test_lazy_zero_equals_memset(cpu_backend):
     assert rel_err(out[0][0], out[1][0]) < 1e-6 and rel_err(out[0][1], out[1][1]) < 1e-6
 
 
+def test_gradient_buckets_and_split_backward(cpu_backend):
+    """Data-parallel bucketing: the tail bucket (bottleneck conv + decoder) owns > 90 % of netG's gradient bytes and is
+    final after the upper part of the backward walk; the cut walk equals the uncut one."""
+    from video_filler_amd.trainers import CenterTrainer
+    from video_filler_amd import nn
+    from oracle import oracle as O
+    batch = torch.from_numpy(O.synth_center_batch(3, np.random.default_rng(3)))
+    opt = dict(SMALL, nBottleneck=512, wtl2=0.999, overlapPred=4)     # bottleneck-dominated, like the real nets
+    tr = CenterTrainer(opt, seed=5)
+    k, off = tr.netG.bucket_split()
+    m = tr.netG._plan[k][0]
+    assert isinstance(m, nn.SpatialConvolution) and m.dW == 1 and m.nOutputPlane == 512
+    n = tr.gradParametersG.numel()
+    assert 0 < off < n and (n - off) >= 0.9 * tr.netG.n_parameters()
+    tr.set_batch(batch)
+    tr.step()
+    whole = tr.gradParametersG.clone()
+    # the same fGx with the pass cut at the bucket boundary (what _phase_b / _phase_b2 do)
+    tr2 = CenterTrainer(opt, seed=5)
+    tr2.set_batch(batch)
+    tr2._phase_a()
+    tr2._phase_b()
+    tail_after_b = tr2.gradParametersG[off:].clone()
+    tr2._phase_b2()
+    assert torch.equal(tail_after_b, tr2.gradParametersG[off:])          # B2 does not touch the tail bucket
+    assert torch.equal(tr2.gradParametersG, whole)
+
+
 @pytest.mark.parametrize("fuse", [True, False])
 def test_center_trainer_closures_match_oracle(fuse, cpu_backend):
     from video_filler_amd.trainers import CenterTrainer

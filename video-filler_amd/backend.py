@@ -94,6 +94,18 @@ class HipBackend:
         import torch.distributed as dist
         dist.all_reduce(t, group=group)
 
+    def all_reduce_avg(self, t, world, group=None, async_op=False):
+        """Mean over ranks of a flat gradient bucket.  RCCL averages inside the collective (no extra pass over the
+        bucket); other backends sum, then scale.  async_op: returns a handle whose wait() orders the current stream
+        after the collective, so kernels launched in between overlap it."""
+        import torch.distributed as dist
+        if dist.get_backend(group) == "nccl":
+            h = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+            return h if async_op else None
+        dist.all_reduce(t, group=group)
+        self.scale_shift(t, 1.0 / world, 0.0)
+        return None
+
     def _c(self, name, *args):
         _lib.check(getattr(self.lib, name)(self.ctx, *args))
 

@@ -402,12 +402,15 @@ class Sequential(Module):
         self.output = cur
         return cur
 
-    def _walk(self, input, gradOutput, want_gp, need_input_grad=True):
+    def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0):
+        """Backward over plan entries hi-1 .. lo (default: all of them).  A partial walk lets the caller cut the
+        pass where a gradient bucket is complete (data parallel: that bucket's all-reduce then overlaps the rest)."""
         plan = self._plan or self._build_plan()
         B = get_backend()
         g = gradOutput
         used_side = False
-        for idx in range(len(plan) - 1, -1, -1):
+        hi = len(plan) if hi is None else hi
+        for idx in range(hi - 1, lo - 1, -1):
             m, a = plan[idx]
             x = input if idx == 0 else plan[idx - 1][0].output
             want_gx = need_input_grad or idx > 0
@@ -434,8 +437,30 @@ class Sequential(Module):
                 g = gin
         if used_side:
             self.side.join()
-        self.gradInput = g
+        if lo == 0:
+            self.gradInput = g
         return g
+
+    def bucket_split(self, frac=0.9):
+        """(plan index k, flat offset): the shortest tail plan[k:] of the backward order's head that owns at least
+        `frac` of the parameters.  After a walk over plan[k:] the flat gradient [offset, end) is final."""
+        plan = self._plan or self._build_plan()
+        segs = self._flat[2]
+        total = float(sum(n for *_, n in segs))
+        first_off = {}
+        count = {}
+        for m, name, gname, o, n in segs:
+            first_off.setdefault(id(m), o)
+            count[id(m)] = count.get(id(m), 0) + n
+        acc, best = 0, (0, 0)
+        for idx in range(len(plan) - 1, -1, -1):
+            m = plan[idx][0]
+            if id(m) in count:
+                acc += count[id(m)]
+                best = (idx, first_off[id(m)])
+                if acc >= frac * total:
+                    break
+        return best
 
     def updateGradInput(self, input, gradOutput):
         return self._walk(input, gradOutput, False)
@@ -445,6 +470,10 @@ class Sequential(Module):
         drivers never read it for netD's two full backward passes nor for netG (train.lua:318,348,403)."""
         assert scale == 1
         return self._walk(input, gradOutput, True, need_input_grad)
+
+    def backward_range(self, input, gradOutput, hi, lo, need_input_grad=True):
+        """backward() restricted to plan entries hi-1 .. lo; gradOutput is what the entry above `hi` returned."""
+        return self._walk(input, gradOutput, True, need_input_grad, hi, lo)
 
     def parameters(self):
         ws, gs = [], []

@@ -151,6 +151,8 @@ class _TrainerBase:
         self._graph = None
         self._graphs = None
         self._defer_comm = False
+        self._split_g = None
+        self._g_mid = None
         self.force_comm = False      # run the exchange even at world == 1 (exercises the DP path on one GPU)
         self.defer_adam_g = False
         self._pending_g = False
@@ -160,12 +162,22 @@ class _TrainerBase:
         return self.world > 1 or self.force_comm
 
     def _allreduce_avg(self, flat):
-        """RCCL all-reduce of a flat gradient vector, then 1/world.  Inside a phased step the
-        closure leaves both to the step (`_defer_comm`)."""
+        """RCCL all-reduce-average of a flat gradient vector.  Inside a phased step the closure
+        leaves the exchange to the step (`_defer_comm`)."""
         if self._comm_on() and not self._defer_comm:
-            B = get_backend()
-            B.all_reduce(flat, self.group)
-            B.scale_shift(flat, 1.0 / self.world, 0.0)
+            get_backend().all_reduce_avg(flat, self.world, self.group)
+
+    def _backward_G(self, df_dg):
+        """netG:backward(input_ctx, df_dg) + the exchange of its gradients.  In a phased step only the part of the
+        pass that completes the big bucket (bottleneck + decoder, > 90 % of the bytes) runs here; `_phase_b2`
+        runs the rest while that bucket is on the wire."""
+        need = not self.skip_dead_grads
+        if self._split_g is not None:
+            k, _ = self._split_g
+            self._g_mid = self.netG.backward_range(self.input_ctx, df_dg, None, k, need)
+            return
+        self.netG.backward(self.input_ctx, df_dg, need_input_grad=need)
+        self._allreduce_avg(self.gradParametersG)
 
     def step(self):
         """The loop body: optim.adam(fDx, ...) ; optim.adam(fGx, ...)  (train.lua:421-424).
@@ -194,40 +206,49 @@ class _TrainerBase:
             if self._graph is not None and self.defer_adam_g:
                 self._graph_stale = True
 
-    # -- the same iteration cut at the two gradient exchanges (data parallel): A | all-reduce D | B | all-reduce G | C
+    # -- the same iteration cut at the gradient exchanges (data parallel):
+    #    A | all-reduce D | B | all-reduce G[tail] ∥ B2 | all-reduce G[head] | C
+    # G's gradient goes out in two buckets: the tail of the flat vector (bottleneck conv + decoder, complete once the
+    # backward pass has come down to the bottleneck) is on the wire while the encoder's backward convs still run.
     def _phase_a(self):
         self._defer_comm = True
         self.fDx(self.parametersD)
         self._defer_comm = False
 
     def _phase_b(self):
-        B = get_backend()
-        B.scale_shift(self.gradParametersD, 1.0 / self.world, 0.0)
         optim.adam_update(self.parametersD, self.gradParametersD, self.optimStateD)
         self._defer_comm = True
-        self.fGx(self.parametersG)
-        self._defer_comm = False
+        self._split_g = self.netG.bucket_split()
+        try:
+            self.fGx(self.parametersG)
+        finally:
+            self._split_g = None
+            self._defer_comm = False
+
+    def _phase_b2(self):
+        k, _ = self.netG.bucket_split()
+        if k > 0:
+            self.netG.backward_range(self.input_ctx, self._g_mid, k, 0, not self.skip_dead_grads)
 
     def _phase_c(self):
-        B = get_backend()
-        B.scale_shift(self.gradParametersG, 1.0 / self.world, 0.0)
         optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
 
     def step_phased(self):
         B = get_backend()
-        if self._graphs is not None:
-            ga, gb, gc = self._graphs
-            ga.replay()
-            B.all_reduce(self.gradParametersD, self.group)
-            gb.replay()
-            B.all_reduce(self.gradParametersG, self.group)
-            gc.replay()
-        else:
-            self._phase_a()
-            B.all_reduce(self.gradParametersD, self.group)
-            self._phase_b()
-            B.all_reduce(self.gradParametersG, self.group)
-            self._phase_c()
+        pa, pb, pb2, pc = ([g.replay for g in self._graphs] if self._graphs is not None
+                           else [self._phase_a, self._phase_b, self._phase_b2, self._phase_c])
+        _, off = self.netG.bucket_split()
+        gG = self.gradParametersG
+        pa()
+        B.all_reduce_avg(self.gradParametersD, self.world, self.group)
+        pb()
+        h_tail = B.all_reduce_avg(gG[off:], self.world, self.group, async_op=True)
+        pb2()
+        h_head = B.all_reduce_avg(gG[:off], self.world, self.group, async_op=True) if off > 0 else None
+        for h in (h_tail, h_head):
+            if h is not None:
+                h.wait()
+        pc()
 
     # -- HIP graph of one whole iteration (single-GPU): zero launch gaps, no host work per step
     def capture(self, warmup=3, defer_adam_g=False):
@@ -250,7 +271,7 @@ class _TrainerBase:
         return g
 
     def capture_phased(self, warmup=3):
-        """Three graphs (phases A, B, C) with the two RCCL all-reduces launched between them.  SyncBN puts
+        """Four graphs (phases A, B, B2, C) with the RCCL all-reduces launched between them.  SyncBN puts
         collectives inside the phases, so it runs eagerly instead."""
         B = get_backend()
         for _ in range(warmup):
@@ -258,7 +279,7 @@ class _TrainerBase:
         torch.cuda.synchronize()
         graphs = []
         pool = None
-        for phase in (self._phase_a, self._phase_b, self._phase_c):
+        for phase in (self._phase_a, self._phase_b, self._phase_b2, self._phase_c):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
                 B.use_current_stream()
@@ -373,8 +394,7 @@ class CenterTrainer(_TrainerBase):
             B.recon_grad_mix(df_dg, self.input_center, self.input_real_center, None, alpha, c0, c1, band, slot)
             self.errG_l2 = nn.DeviceScalar.of(slot)
             errG_total = (alpha if (0 < wt < 1) else 1.0) * self.errG + wt * self.errG_l2
-        self.netG.backward(self.input_ctx, df_dg, need_input_grad=not self.skip_dead_grads)
-        self._allreduce_avg(self.gradParametersG)
+        self._backward_G(df_dg)
         return errG_total, self.gradParametersG
 
 
@@ -482,6 +502,5 @@ class VidTrainer(_TrainerBase):
             raise RuntimeError("wtgdl ~= 0 with wtl2 == 0 indexes a nil criterionMSE in the reference (:525)")
         if wtgdl != 0:
             errG_total = errG_total + wtgdl * self.errG_gdl
-        self.netG.backward(self.input_ctx, df_dg, need_input_grad=not self.skip_dead_grads)
-        self._allreduce_avg(self.gradParametersG)
+        self._backward_G(df_dg)
         return errG_total, self.gradParametersG
