@@ -71,7 +71,8 @@ struct IGemm {
   int parity;                      // 1: z&3 = (ph<<1)|pw shifts oy0/ox0/ooy0/oox0 and selects kh0/kw0
   int gm, gn, gz;                  // logical grid (the launch is 1-D, remapped per XCD)
   int ksplit, nk, nq;              // K steps (of 32), number of splits, 16-wide chunks on the vector path
-  int dbg;                         // ablation switches (timing experiments only; wrong results): 1 no reload, 2 no LDS restage
+  int dbg;                         // ablation switch (timing experiments only; wrong results): 1 = no operand reload
+  long long* stamps;               // timing experiments only: 8 stamp slots per block (VF_IGEMM_STAMPS=<file>)
   int act;
   float slope;
 };
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+  if (p.stamps && tid == 0) { p.stamps[8 * blockIdx.x + 0] = wall_clock64(); p.stamps[8 * blockIdx.x + 4] = (long long)__builtin_readcyclecounter(); }
   // logical tile id: output parity fastest (the 4 parity classes of a transposed pass read the same input rows),
   // then M tiles (halo sharing), then N tiles, then split-K
   int lid = vf_xcd_remap(blockIdx.x, p.gm * p.gn * p.gz);
@@ -150,13 +152,19 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       a_byte[i] = 4u * (unsigned)(a_boff[i] + (a_iy0[i] * p.Wi + a_ix0[i]) * p.C + 4 * kl);
-      unsigned mk = 0;
-      for (int t = 0; t < p.TH * p.TW; ++t) {
-        const int th = t / p.TW, tw = t - th * p.TW;
-        const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
-        if (a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mk |= 1u << t;
+      // bit (th*TW + tw) = row th and column tw of the tap window are inside the image: an outer product of a row
+      // mask and a column mask (TH, TW <= 4) — a loop over all taps with a division each cost 8 us of prologue
+      unsigned ym = 0, xm = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < p.TH && (unsigned)(a_iy0[i] + t * p.ty) < (unsigned)p.Hi) ym |= 1u << t;
+        if (t < p.TW && (unsigned)(a_ix0[i] + t * p.tx) < (unsigned)p.Wi) xm |= 1u << t;
       }
-      a_mask[i] = mk;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if ((ym >> t) & 1u) mk |= xm << (t * p.TW);
+      a_mask[i] = a_ok[i] ? mk : 0u;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
@@ -205,29 +213,47 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     return c;
   };
 
-  auto load_tile = [&](int kt) {
+  // One K step's operands arrive as A_CH + B_CH independent pieces (one 16-byte register each).  `begin_tile` does
+  // the wave-uniform part once per step; the pieces are issued one at a time BETWEEN the MFMAs of the running step
+  // (a contiguous block of ~60 address/load instructions would leave the matrix pipe empty: it queues one MFMA).
+  Chunk tc0, tc1;
+  int t_tapv = 0;
+  unsigned t_dA = 0;
+  bool t_okq = false;
+  int t_kt = 0;
+  auto begin_tile = [&](int kt, bool live) {
+    t_kt = kt;
     if constexpr (V >= 1) {
-      const Chunk c0 = next_chunk(), c1 = next_chunk();   // SALU; load_tile is called with consecutive kt
-      // ---------------- A: lanes with kh = 0 / 1 fetch chunk 0 / 1
-      const int tapv = kh ? c1.tap : c0.tap;
-      const unsigned dA = kh ? c1.dA : c0.dA;
-      const bool okq = kh ? c1.ok : c0.ok;
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        const bool ok = okq && ((a_mask[i] >> tapv) & 1u);
-        ra[i] = vf_bload4(rsA, ok ? a_byte[i] + dA : VF_OOB);
-      }
-      // ---------------- B
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) {
+      tc0 = next_chunk();      // SALU; begin_tile is called with consecutive kt
+      tc1 = next_chunk();
+      tc0.ok = tc0.ok && live;
+      tc1.ok = tc1.ok && live;
+      t_tapv = kh ? tc1.tap : tc0.tap;
+      t_dA = kh ? tc1.dA : tc0.dA;
+      t_okq = kh ? tc1.ok : tc0.ok;
+    } else {
+      t_okq = live;
+    }
+  };
+  auto load_piece = [&](int pc) {
+    const int kt = t_kt;
+    if constexpr (V >= 1) {
+      if (pc < A_CH) {
+        // ---------------- A: lanes with kh = 0 / 1 fetch chunk 0 / 1
+        const int i = pc;
+        const bool ok = t_okq && ((a_mask[i] >> t_tapv) & 1u);
+        ra[i] = vf_bload4(rsA, ok ? a_byte[i] + t_dA : VF_OOB);
+      } else {
+        // ---------------- B
+        const int i = pc - A_CH;
         bool hi;
         if constexpr (!BKM) {
           hi = kh;
         } else {
           hi = (((tid + 256 * i) / (BN / 4)) >> 4) & 1;
         }
-        const unsigned dW = hi ? c1.dW : c0.dW;
-        const bool ok = w_ok[i] && (hi ? c1.ok : c0.ok);
+        const unsigned dW = hi ? tc1.dW : tc0.dW;
+        const bool ok = w_ok[i] && (hi ? tc1.ok : tc0.ok);
         if constexpr (V == 2) {
           rb[i] = vf_bload4(rsW, ok ? w_byte[i] + dW : VF_OOB);
         } else {   // V == 1: k-major B whose N is not a multiple of 4 -> four scalar loads along n
@@ -240,8 +266,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
       }
     } else {
       // ---------------- scalar path: flattened K index, per-element (tap, c)
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
+      if (pc < A_CH) {
+        const int i = pc;
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -249,18 +275,17 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           const int tap = k / p.C, c = k - tap * p.C;
           const int th = tap / p.TW, tw = tap - th * p.TW;
           const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
-          const bool ok = a_ok[i] && k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+          const bool ok = t_okq && a_ok[i] && k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
           v[j] = vf_bload1(rsA, ok ? 4u * (unsigned)(a_boff[i] + (iy * p.Wi + ix) * p.C + c) : VF_OOB);
         }
         ra[i] = v;
-      }
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) {
+      } else {
+        const int i = pc - A_CH;
         const int id = tid + 256 * i;
         f32x4 v;
         if constexpr (!BKM) {
           const int n = n0 + (id >> 3);
-          const bool okn = id < BN * 8 && n < p.N;
+          const bool okn = t_okq && id < BN * 8 && n < p.N;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int k = kt * BK + 4 * kq + j;
@@ -272,7 +297,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           const int n = n0 + 4 * nq;
           const int k = kt * BK + kk;
           const int tap = k / p.C, c = k - tap * p.C;
-          const bool okk = id < BN * 8 && k < Ktot;
+          const bool okk = t_okq && id < BN * 8 && k < Ktot;
           const int base = tap_index(tap) * p.wsTap + c * p.wsC;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = vf_bload1(rsW, (okk && n + j < p.N) ? 4u * (unsigned)(base + n + j) : VF_OOB);
@@ -281,19 +306,21 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
       }
     }
   };
+  auto load_tile = [&](int kt) {
+    begin_tile(kt, true);
+#pragma unroll
+    for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc);
+  };
 
-  auto store_tile = [&](int buf) {
+  auto store_piece = [&](int buf, int pc) {
     float* As = smem + buf * (A_SZ + B_SZ);
     float* Bs = As + A_SZ;
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int id = tid + 256 * i;
-      if (id < BM * 8) *(f32x4*)(As + (id >> 3) * LDA + 4 * kq) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-      const int id = tid + 256 * i;
-      if (id < BN * 8) {
+    if (pc < A_CH) {
+      const int i = pc, id = tid + 256 * i;
+      if (256 * i + 255 < BM * 8 || id < BM * 8) *(f32x4*)(As + (id >> 3) * LDA + 4 * kq) = ra[i];
+    } else {
+      const int i = pc - A_CH, id = tid + 256 * i;
+      if (256 * i + 255 < BN * 8 || id < BN * 8) {     // constant-true for full pieces: no exec-mask branch in the loop
         if constexpr (!BKM) {
           *(f32x4*)(Bs + (id >> 3) * LDB + 4 * kq) = rb[i];
         } else {
@@ -302,6 +329,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
         }
       }
     }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int pc = 0; pc < A_CH + B_CH; ++pc) store_piece(buf, pc);
   };
 
   f32x16 acc[MT][NT];
@@ -319,39 +350,59 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     store_tile(0);
   }
   __syncthreads();
+  if (p.stamps && tid == 0) p.stamps[8 * blockIdx.x + 1] = wall_clock64();
+  constexpr int NPC = A_CH + B_CH;             // operand pieces per K step
+  constexpr int NMF = 4 * MT * NT;             // MFMAs per 8-wide sub-step
+  constexpr int SLOTS = (BK / 8) * NMF;        // MFMA slots per K step
+  static_assert(2 * NPC <= SLOTS, "loads and LDS writes of one K step must fit between its MFMAs");
   for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (p.dbg & 2) ? 0 : ((kt - kt0) & 1);
-    if (kt + 1 < kt1 && !(p.dbg & 1)) load_tile(kt + 1);
+    const int buf = (kt - kt0) & 1;
     const float* As = smem + buf * (A_SZ + B_SZ);
     const float* Bs = As + A_SZ;
+    // The step's schedule, pinned with scheduling barriers (left alone, the compiler gathers all loads at the top and
+    // all LDS writes at the bottom, and the matrix pipe idles through both):
+    //   fragment reads run one sub-step ahead of the MFMAs that consume them (two waves sharing a SIMD interleave
+    //   their MFMAs one for one and finish a group together, so a read issued only then is latency nobody covers);
+    //   MFMA slot i < NPC is followed by operand piece i of step kt+1 (global -> register);
+    //   the last NPC slots are each followed by one register -> LDS write into the other buffer.
+    auto read_frag = [&](int ss, f32x4 (&a)[MT], f32x4 (&b)[NT]) {
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      f32x4 a[MT], b[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(As + (wm + mt * 32 + lr) * LDA + 8 * s + 4 * lh);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(As + (wm + mt * 32 + lr) * LDA + 8 * ss + 4 * lh);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if constexpr (!BKM) {
-          b[nt] = *(const f32x4*)(Bs + (wn + nt * 32 + lr) * LDB + 8 * s + 4 * lh);
+          b[nt] = *(const f32x4*)(Bs + (wn + nt * 32 + lr) * LDB + 8 * ss + 4 * lh);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) b[nt][j] = Bs[(8 * s + 4 * lh + j) * LDB + wn + nt * 32 + lr];
+          for (int j = 0; j < 4; ++j) b[nt][j] = Bs[(8 * ss + 4 * lh + j) * LDB + wn + nt * 32 + lr];
         }
       }
+    };
+    const bool more = kt + 1 < kt1 && !(p.dbg & 1);
+    begin_tile(kt + 1, more);
+    f32x4 fa[2][MT], fb[2][NT];
+    read_frag(0, fa[0], fb[0]);
+#pragma unroll
+    for (int ss = 0; ss < BK / 8; ++ss) {
+      if (ss + 1 < BK / 8) read_frag(ss + 1, fa[(ss + 1) & 1], fb[(ss + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ss & 1][mt][j], fb[ss & 1][nt][j], acc[mt][nt], 0, 0, 0);
+            const int slot = ss * NMF + (j * MT + mt) * NT + nt;
+            if (slot < NPC) load_piece(slot);
+            if (slot >= SLOTS - NPC) store_piece(buf ^ 1, slot - (SLOTS - NPC));
+            __builtin_amdgcn_sched_barrier(0);
+          }
     }
-    if (!(p.dbg & 2)) {
-      if (kt + 1 < kt1) store_tile(buf ^ 1);
-      __syncthreads();
-    }
+    __syncthreads();
   }
 
+  if (p.stamps && tid == 0) p.stamps[8 * blockIdx.x + 2] = wall_clock64();
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
   const bool fin = p.ksplit == 1;
@@ -380,6 +431,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
         }
       }
     }
+  }
+  if (p.stamps && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);     // stores retired (vmcnt 0)
+    p.stamps[8 * blockIdx.x + 3] = wall_clock64();
+    p.stamps[8 * blockIdx.x + 5] = (long long)__builtin_readcyclecounter();
   }
 }
 
@@ -744,6 +800,19 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   g.dbg = tune_dbg;
   g.gm = gm; g.gn = gn; g.gz = zpar * ksplit;
   dim3 grid((unsigned)gm * gn * zpar * ksplit);
+  // timing experiments only: per-block stamps; every 32nd launch is synchronised and appended to the file
+  // VF_IGEMM_STAMPS names (the launches in between run unsynchronised, so the dumped one sees sustained conditions)
+  static const char* stamp_file = getenv("VF_IGEMM_STAMPS");
+  static long long* stamp_buf = nullptr;
+  static unsigned stamp_count = 0;
+  g.stamps = nullptr;
+  bool stamp_dump = false;
+  if (stamp_file && grid.x <= 32768) {
+    if (!stamp_buf) VF_CHECK_HIP(hipHostMalloc((void**)&stamp_buf, 8 * 32768 * sizeof(long long), hipHostMallocDefault));
+    g.stamps = stamp_buf;
+    stamp_dump = (++stamp_count % 32) == 0;
+    if (stamp_dump) VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
   char pname[64];
   snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "");
   {
@@ -760,6 +829,18 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
       launch_igemm_tile<64, 64, 32, 32>(ctx, g, grid, bkm, v, pname, fl);
   }
   VF_LAUNCH_CHECK();
+  if (stamp_dump) {
+    VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (FILE* f = fopen(stamp_file, "a")) {
+      fprintf(f, "# %s blocks=%u M=%d N=%d K=%d ksplit=%d\n", pname, grid.x, g.M, g.N, Ktot, ksplit);
+      for (unsigned b = 0; b < grid.x; ++b) {
+        fprintf(f, "%u", b);
+        for (int q = 0; q < 6; ++q) fprintf(f, " %lld", g.stamps[8 * b + q]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
   if (ksplit > 1) {
     VfProf prof(ctx, "slab_reduce_igemm", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
     return launch_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, 0.f);
