@@ -548,11 +548,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   f32x4 ru[U_CH], rv[V_CH];
   const __amdgpu_buffer_rsrc_t rsU = vf_rsrc(p.U, p.u_bytes), rsV = vf_rsrc(p.V, p.v_bytes);
 
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < U_CH; ++i) {
+  // one K step = U_CH + V_CH operand pieces (one 16-byte register each); `live` false turns a piece into a no-op load
+  auto load_piece = [&](int kt, int pc, bool live) {
+    if (pc < U_CH) {
+      const int i = pc;
       const int pp = kt * BK + ukk + i * (1024 / BM);
-      const bool okp = pp < p.P;
+      const bool okp = live && pp < p.P;
       if constexpr (VU) {
         ru[i] = vf_bload4(rsU, (okp && un < p.Nu) ? 4u * (unsigned)(pp * p.Nu + un) : VF_OOB);
       } else {
@@ -563,11 +564,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
         }
         ru[i] = v;
       }
-    }
-#pragma unroll
-    for (int i = 0; i < V_CH; ++i) {
+    } else {
+      const int i = pc - U_CH;
       const int pp = kt * BK + (tid >> 5) + 8 * i;
-      const bool okp = pp < p.P;
+      const bool okp = live && pp < p.P;
       const int mx = pp & (Mw - 1), my = (pp >> p.lgMw) & (Mh - 1), b = pp >> (p.lgMw + p.lgMh);
       const int boff = b * p.Hv * p.Wv * p.Cv;
       if constexpr (VV) {
@@ -586,13 +586,24 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
       }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_piece = [&](int buf, int pc) {
     float* Us = smem + buf * (U_SZ + V_SZ);
     float* Vs = Us + U_SZ;
+    if (pc < U_CH) {
+      *(f32x4*)(Us + (ukk + pc * (1024 / BM)) * LDU + 4 * uq) = ru[pc];
+    } else {
+      const int i = pc - U_CH;
+      *(f32x4*)(Vs + ((tid >> 5) + 8 * i) * LDV + 4 * cq) = rv[i];
+    }
+  };
+  constexpr int NPC = U_CH + V_CH;
+  auto load_tile = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < U_CH; ++i) *(f32x4*)(Us + (ukk + i * (1024 / BM)) * LDU + 4 * uq) = ru[i];
+    for (int pc = 0; pc < NPC; ++pc) load_piece(kt, pc, true);
+  };
+  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < V_CH; ++i) *(f32x4*)(Vs + ((tid >> 5) + 8 * i) * LDV + 4 * cq) = rv[i];
+    for (int pc = 0; pc < NPC; ++pc) store_piece(buf, pc);
   };
 
   f32x16 acc[2][NT];
@@ -609,31 +620,45 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
     store_tile(0);
   }
   __syncthreads();
+  constexpr int NMF = 4 * 2 * NT;              // MFMAs per 8-wide sub-step
+  constexpr int SLOTS = 2 * NMF;               // MFMA slots per K step (BK = 16)
+  static_assert(2 * NPC <= SLOTS, "loads and LDS writes of one K step must fit between its MFMAs");
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tile(kt + 1);
+    const bool more = kt + 1 < kt1;
     const float* Us = smem + buf * (U_SZ + V_SZ);
     const float* Vs = Us + U_SZ;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float a[2][4], b[NT][4];
+    // same pinned schedule as k_igemm: fragment reads one sub-step ahead; MFMA slot i < NPC is followed by operand
+    // piece i of step kt+1, the last NPC slots by the register -> LDS writes into the other buffer
+    auto read_frag = [&](int ss, float (&a)[2][4], float (&b)[NT][4]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k = 8 * s + 4 * lh + j;
+        const int k = 8 * ss + 4 * lh + j;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) a[mt][j] = Us[k * LDU + wm + mt * 32 + lr];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt][j] = Vs[k * LDV + wn + nt * 32 + lr];
       }
+    };
+    float fa[2][2][4], fb[2][NT][4];
+    read_frag(0, fa[0], fb[0]);
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      if (ss == 0) read_frag(1, fa[1], fb[1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ss][mt][j], fb[ss][nt][j], acc[mt][nt], 0, 0, 0);
+            const int slot = ss * NMF + (j * 2 + mt) * NT + nt;
+            if (slot < NPC) load_piece(kt + 1, slot, more);
+            if (slot >= SLOTS - NPC) store_piece(buf ^ 1, slot - (SLOTS - NPC));
+            __builtin_amdgcn_sched_barrier(0);
+          }
     }
-    if (kt + 1 < kt1) store_tile(buf ^ 1);
     __syncthreads();
   }
 
