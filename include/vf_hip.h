@@ -154,6 +154,29 @@ int vf_masked_mse_bwd(vf_ctx* ctx, const float* x, const float* xhat, const uint
 int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                  double beta2, double eps, int32_t* t_dev);
 
+/* ---- batch preparation and the inference tile loop (the data formats either side of the closures) ---------
+ * train.lua:284-298: from the loader's batch (B x C x fs x fs planar, [-1,1]) produce the NHWC generator input with
+ * the centre hole [fs/4+ov, 3fs/4-ov)^2 painted with fill[c] (DEVICE float[C]; 2*{117,104,123}/255-1 in the reference)
+ * and the NHWC clone of the centre crop [fs/4, 3fs/4)^2 taken BEFORE painting. */
+int vf_center_prepare(vf_ctx* ctx, const float* batch_nchw, float* ctx_nhwc, float* center_nhwc, const float* fill,
+                      int B, int C, int fs, int overlapPred);
+/* datavid/donkey_folder.lua:135-189 (trainHook, withMask) for ONE sample: crop the decoded clip (C x iH x iW planar,
+ * [0,1]) at 0-based (w1, h1), build the mask (nblocks == 0: crop of the mask image `mask` (iH x iW), non-zero =
+ * masked, :162-166; nblocks > 0: randomBlockMask's squares of side block_size at 1-based HOST coordinates tlx/tly,
+ * :114-129), fill masked pixels with mask_value, mirror horizontally if flip (:178-183), map [0,1] -> [-1,1]
+ * (:185-187).  Outputs are fs x fs x C NHWC: full clip, masked clip, mask as 0/1 floats. */
+int vf_clip_prepare(vf_ctx* ctx, const float* clip, const float* mask, float* full, float* masked, float* maskout,
+                    int C, int iH, int iW, int fs, int w1, int h1, int flip, float mask_value, int nblocks,
+                    int block_size, const int* tlx, const int* tly);
+/* test_vid_wholeim.lua:159-205: the padded planar clip (groups*nc x H x W; H, W multiples of fs) cut into
+ * (H/fs)*(W/fs) tiles, all gathered into ONE NHWC batch — row (tile*groups + g) is fs x fs x nc — so the generator
+ * runs once instead of once per tile (evaluate-mode BatchNorm makes that exact); vflip (DEVICE uint8 per tile, or
+ * NULL) flips a tile vertically on the way in (:167-170) and back on the way out (:191-197). */
+int vf_tiles_gather(vf_ctx* ctx, const float* full, float* tiles, int groups, int nc, int H, int W, int fs,
+                    const unsigned char* vflip);
+int vf_tiles_scatter(vf_ctx* ctx, const float* tiles, float* out, int groups, int nc, int H, int W, int fs,
+                     const unsigned char* vflip);
+
 /* ---- per-kernel timers (the reference has three torch.Timers, train.lua:241-243; these are finer) ----
  * Between vf_prof_begin and vf_prof_end every kernel launch of the library is bracketed by HIP events on the
  * context's stream.  vf_prof_end synchronises and aggregates per kernel name; vf_prof_get reads entry i:

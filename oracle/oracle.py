@@ -776,3 +776,88 @@ def synth_vid_batch(B, rng, nc_in, nc_out=None, fineSize=128, maskValue=110.0 / 
         ctx = rng.uniform(-1.0, 1.0, (B, nc_in, fineSize, fineSize)).astype(np.float32)
         ctx[:, :, lo:hi, lo:hi] = np.float32(2 * maskValue - 1)
     return ctx, full, mask
+
+
+# ------------------------------------------------------------------ batch preparation (loader side of the path)
+def center_prepare(batch, overlapPred=0, fill=(117.0, 104.0, 123.0)):
+    """train.lua:284-298 on the loader's batch (B x nc x fs x fs in [-1,1]): returns (input_ctx, real_center).
+    The centre crop is cloned BEFORE the hole (minus the overlap band) is painted with the channel means."""
+    real_ctx = np.ascontiguousarray(batch, np.float32).copy()
+    fs = real_ctx.shape[-1]
+    lo, hi, ov = fs // 4, fs // 2 + fs // 4, overlapPred
+    real_center = real_ctx[:, :, lo:hi, lo:hi].copy()
+    for ch, mean in enumerate(fill):
+        real_ctx[:, ch, lo + ov:hi - ov, lo + ov:hi - ov] = np.float32(2 * mean / 255.0 - 1.0)
+    return real_ctx, real_center
+
+
+def clip_train_hook(clip, mask, fineSize, w1, h1, flip, maskValue=110.0 / 255.0, blocks=None, blockSize=None):
+    """datavid/donkey_folder.lua:135-189 (trainHook, withMask) with the random draws passed in.
+
+    clip: (predLen*nc) x iH x iW in [0,1] (loadContImages' result); mask: 1 x iH x iW Byte 0/1 (:33-35, scaled :103).
+    (w1, h1): 0-based crop corner (image.crop(input, w1, h1, w1+oW, h1+oH), :147).  If the cropped mask has a set
+    pixel (:165) the clip is maskedFill'ed with maskValue (:166); otherwise randomBlockMask (:114-129) paints `blocks`
+    = [(tlx, tly)] (1-based, side blockSize = floor(h/6)) — its mask tensor is torch.Tensor(size) i.e. UNINITIALISED
+    outside the blocks in the reference; the evident intent (0) is restated here.  hflip (:178-183) mirrors all three,
+    then [0,1] -> [-1,1] (:185-187).  Returns (out, maskout, masked), each (predLen*nc) x fs x fs."""
+    fs = fineSize
+    out = np.ascontiguousarray(clip[:, h1:h1 + fs, w1:w1 + fs], np.float32).copy()
+    maskout = np.broadcast_to(mask[:, h1:h1 + fs, w1:w1 + fs], out.shape).astype(np.uint8).copy()
+    masked = out.copy()
+    if maskout.max() > 0.5:
+        masked[maskout != 0] = np.float32(maskValue)
+    else:
+        bs = blockSize if blockSize is not None else fs // 6
+        maskout = np.zeros(out.shape, np.uint8)
+        for tlx, tly in blocks:
+            maskout[:, tly - 1:tly - 1 + bs, tlx - 1:tlx - 1 + bs] = 1
+            masked[:, tly - 1:tly - 1 + bs, tlx - 1:tlx - 1 + bs] = np.float32(maskValue)
+    if flip:
+        out, masked, maskout = out[:, :, ::-1].copy(), masked[:, :, ::-1].copy(), maskout[:, :, ::-1].copy()
+    out = out * np.float32(2) + np.float32(-1)
+    masked = masked * np.float32(2) + np.float32(-1)
+    return out, maskout, masked
+
+
+# ------------------------------------------------------------------ inference (test_vid.lua / test_vid_wholeim.lua)
+def whole_image_inpaint(net, fullImages, padmask, predLen, inputLen, fineSize=128, nc=3, netI=None, mid_mask=None):
+    """test_vid_wholeim.lua:150-226, tile by tile exactly as the script walks them.
+
+    net (and netI) must already be in evaluate() mode (:62,67).  fullImages: (predLen*nc) x outh x outw in [-1,1],
+    padded bottom-right to multiples of fineSize (:137-141); padmask: nc x outh x outw Byte (:209-212).
+    Returns (outImages, inpaintImages, fullImages) AFTER the final add(1):mul(0.5) (:222-224), shaped predLen x nc x H x W
+    (fullImages stays (predLen*nc) x H x W)."""
+    fs = fineSize
+    C, outh, outw = fullImages.shape
+    ncinput = nc * inputLen
+    batch = predLen // inputLen
+    assert C == nc * predLen and predLen % inputLen == 0
+    outImages = np.zeros((predLen, nc, outh, outw), np.float32)
+    for h in range(0, outh, fs):
+        for w in range(0, outw, fs):
+            flipped = h == 0 and w in (0, fs, 2 * fs)                       # :167 (1-based h==1, w in {1, fs+1, 2fs+1})
+            patch = np.zeros((batch, ncinput, fs, fs), np.float32)
+            for idx in range(batch):
+                tmp = fullImages[idx * ncinput:(idx + 1) * ncinput, h:h + fs, w:w + fs]
+                if flipped:
+                    tmp = tmp[:, ::-1, :]                                    # image.vflip
+                patch[idx] = tmp
+            if netI is None:
+                out_image = net.forward(patch.copy())
+            else:                                                            # :181-190
+                mid = netI.forward(patch.copy())
+                tmask = mid_mask[:, h:h + fs, w:w + fs]
+                filled = patch.copy()
+                for b in range(batch):                                       # inpaint_utils.fillIn, 4-D dst / 3-D mask
+                    filled[b][tmask != 0] = mid[b][tmask != 0]
+                out_image = net.forward(filled)
+            out_image = np.array(out_image, np.float32, copy=True)
+            if flipped:                                                      # :191-197
+                for idx in range(batch):
+                    out_image[idx] = out_image[idx][:, ::-1, :]
+            outImages[:, :, h:h + fs, w:w + fs] = out_image.reshape(predLen, nc, fs, fs)
+    inpaint = np.array(fullImages, np.float32, copy=True).reshape(predLen, nc, outh, outw)
+    for i in range(predLen):                                                 # :214-220
+        inpaint[i][padmask != 0] = outImages[i][padmask != 0]
+    half = np.float32(0.5)
+    return (outImages + np.float32(1)) * half, (inpaint + np.float32(1)) * half, (fullImages + np.float32(1)) * half

@@ -201,6 +201,49 @@ class OracleBackend:
     def scale_shift(self, y, a, b):
         _put(y, _np(y) * np.float32(a) + np.float32(b))
 
+    # batch preparation / inference tile loop: numpy restatements of the same index maps
+    def center_prepare(self, batch_nchw, ctx_out, center_out, fill, overlapPred):
+        x = _np(batch_nchw)
+        fs = x.shape[-1]
+        lo, hi, ov = fs // 4, fs // 2 + fs // 4, overlapPred
+        _put(center_out, x[:, :, lo:hi, lo:hi])
+        c = x.copy()
+        c[:, :, lo + ov:hi - ov, lo + ov:hi - ov] = _np(fill)[None, :, None, None]
+        _put(ctx_out, c)
+
+    def clip_prepare(self, clip, mask, full, masked, maskout, w1, h1, flip, mask_value, blocks=None, block_size=0):
+        fs = full.shape[-1]
+        m = (np.zeros((1,) + tuple(clip.shape[1:]), np.uint8) if mask is None else (_np(mask) != 0).astype(np.uint8)[None])
+        o, mo, ma = O.clip_train_hook(_np(clip), m, fs, w1, h1, flip, mask_value, blocks, block_size)
+        _put(full, o[None])
+        _put(masked, ma[None])
+        _put(maskout, mo[None].astype(np.float32))
+
+    def _tile_index(self, Ct, H, W, fs, groups, vflip):
+        TX = W // fs
+        flips = np.zeros((H // fs) * TX, np.uint8) if vflip is None else _np(vflip.float()).astype(np.uint8)
+        nc = Ct // groups
+        for t in range((H // fs) * TX):
+            ty, tx = divmod(t, TX)
+            for g in range(groups):
+                yield t * groups + g, slice(g * nc, (g + 1) * nc), slice(ty * fs, (ty + 1) * fs), slice(tx * fs, (tx + 1) * fs), bool(flips[t])
+
+    def tiles_gather(self, full, tiles, groups, vflip=None):
+        Ct, H, W = full.shape
+        fs = tiles.shape[-1]
+        f, out = _np(full), np.zeros(tuple(tiles.shape), np.float32)
+        for b, cs, ys, xs, fl in self._tile_index(Ct, H, W, fs, groups, vflip):
+            out[b] = f[cs, ys, xs][:, ::-1] if fl else f[cs, ys, xs]
+        _put(tiles, out)
+
+    def tiles_scatter(self, tiles, out, groups, vflip=None):
+        Ct, H, W = out.shape
+        fs = tiles.shape[-1]
+        t, o = _np(tiles), np.zeros((Ct, H, W), np.float32)
+        for b, cs, ys, xs, fl in self._tile_index(Ct, H, W, fs, groups, vflip):
+            o[cs, ys, xs] = t[b][:, ::-1] if fl else t[b]
+        _put(out, o)
+
     def masked_compose(self, out, real, fake, mask):
         _put(out, np.where(_np(mask) != 0, _np(fake), _np(real)))
 

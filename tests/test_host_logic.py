@@ -269,3 +269,47 @@ def test_data_parallel_world2_equals_big_batch(kind, tmp_path):
     # sharded gradients are mean-reduced in a different order than the big batch sums: fp32 tolerance
     assert gG < 5e-5 and rm < 1e-5, (gG, rm)
     assert pG < 5e-3 and pD < 5e-3, (pG, pD)     # Adam amplifies rounding on near-zero gradients
+
+
+def test_whole_image_batched_tiles_equal_the_tile_loop(cpu_backend):
+    """inference.WholeImageInpainter (all tiles in one batch) against the oracle's tile-by-tile restatement of
+    test_vid_wholeim.lua:150-226, both on the CPU: the batching, the vflip rule and the masked paste."""
+    from video_filler_amd.inference import WholeImageInpainter
+    from video_filler_amd.trainers import build_netG
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    predLen, inputLen, nc, fs, H, W = 4, 2, 3, 128, 128, 512
+    ref = O.build_netG(6, 6, 8, 8, 16, True)
+    O.weights_init(ref, rng)
+    pref, _ = ref.getParameters()
+    net = build_netG(6, 6, 8, 8, 16, True)
+    net.getParameters()
+    net.load_reference_flat(torch.from_numpy(pref.copy()))
+    ref.evaluate()
+    full = rng.uniform(-1, 1, (predLen * nc, H, W)).astype(np.float32)
+    padmask = np.zeros((nc, H, W), np.uint8)
+    padmask[:, 30:100, 200:330] = 1
+    want_out, want_inp, _ = O.whole_image_inpaint(ref, full, padmask, predLen, inputLen, fs, nc)
+    out, inp, _ = WholeImageInpainter(net, predLen, inputLen, fs, nc)(torch.from_numpy(full), torch.from_numpy(padmask))
+    assert rel_err(out.numpy(), want_out) < 1e-5 and rel_err(inp.numpy(), want_inp) < 1e-5
+
+
+def test_center_prepare_and_clip_batcher_on_cpu(cpu_backend):
+    from video_filler_amd import data
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    batch = O.synth_center_batch(2, rng)
+    ctx, center = data.center_prepare(torch.from_numpy(batch), 4)
+    wc, wr = O.center_prepare(batch, 4)
+    np.testing.assert_array_equal(ctx.numpy(), wc)
+    np.testing.assert_array_equal(center.numpy(), wr)
+    cb = data.ClipBatcher(2, 6, 128, rng=np.random.default_rng(1))
+    mask = np.zeros((1, 160, 160), np.uint8)
+    mask[:, 50:110, 50:110] = 1
+    while cb.n < 2:
+        cb.add(rng.uniform(0.3, 1, (6, 160, 160)).astype(np.float32), mask)
+    c, f, m = cb.batch()
+    assert tuple(c.shape) == (2, 6, 128, 128) and float(m.max()) == 1.0
+    sel = m.numpy() == 1
+    np.testing.assert_array_equal(c.numpy()[sel], np.float32(110.0 / 255.0) * np.float32(2) + np.float32(-1))   # FloatTensor arithmetic: fill, then mul(2):add(-1)
+    np.testing.assert_array_equal(c.numpy()[~sel], f.numpy()[~sel])

@@ -50,6 +50,10 @@ SIGNATURES = {
     "vf_cmul": (i32, [vp, vp, vp, i64]),
     "vf_scale_shift": (i32, [vp, vp, f32, f32, i64]),
     "vf_masked_compose": (i32, [vp, vp, vp, vp, vp, i64]),
+    "vf_center_prepare": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),
+    "vf_clip_prepare": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp]),
+    "vf_tiles_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "vf_tiles_scatter": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "vf_bce_fwd": (i32, [vp, vp, f32, i32, vp]),
     "vf_bce_bwd": (i32, [vp, vp, f32, vp, i32]),
     "vf_mse_fwd": (i32, [vp, vp, vp, i64, vp]),

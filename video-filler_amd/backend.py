@@ -194,6 +194,40 @@ class HipBackend:
     def scale_shift(self, y, a, b):
         self._c("vf_scale_shift", _ptr(y), a, b, y.numel())
 
+    # ---- batch preparation / inference tile loop (vf_pipeline.hip)
+    def center_prepare(self, batch_nchw, ctx_out, center_out, fill, overlapPred):
+        """train.lua:284-298.  batch_nchw: contiguous B x C x fs x fs; outputs are channels-last tensors."""
+        B, Cc, fs, _ = batch_nchw.shape
+        assert batch_nchw.is_contiguous()
+        self._c("vf_center_prepare", _ptr(batch_nchw), _ptr(ctx_out), _ptr(center_out), _ptr(fill), B, Cc, fs, overlapPred)
+
+    def clip_prepare(self, clip, mask, full, masked, maskout, w1, h1, flip, mask_value, blocks=None, block_size=0):
+        """datavid/donkey_folder.lua:135-189 for one sample.  clip: C x iH x iW planar in [0,1]; mask: iH x iW float or
+        None (then `blocks` = [(tlx, tly)] 1-based, randomBlockMask); outputs: 1 x C x fs x fs channels-last."""
+        import ctypes
+        Cc, iH, iW = clip.shape
+        fs = full.shape[-1]
+        blocks = blocks or []
+        n = len(blocks)
+        tlx = (ctypes.c_int * 10)(*([b[0] for b in blocks] + [0] * (10 - n)))
+        tly = (ctypes.c_int * 10)(*([b[1] for b in blocks] + [0] * (10 - n)))
+        self._c("vf_clip_prepare", _ptr(clip), _ptr(mask) if mask is not None else None, _ptr(full), _ptr(masked),
+                _ptr(maskout), Cc, iH, iW, fs, w1, h1, int(bool(flip)), mask_value, n, block_size,
+                ctypes.cast(tlx, ctypes.c_void_p), ctypes.cast(tly, ctypes.c_void_p))
+
+    def tiles_gather(self, full, tiles, groups, vflip=None):
+        """test_vid_wholeim.lua:159-175.  full: (groups*nc) x H x W planar; tiles: (T*groups) x nc x fs x fs channels-last."""
+        Ct, H, W = full.shape
+        fs = tiles.shape[-1]
+        self._c("vf_tiles_gather", _ptr(full), _ptr(tiles), groups, Ct // groups, H, W, fs,
+                _ptr(vflip) if vflip is not None else None)
+
+    def tiles_scatter(self, tiles, out, groups, vflip=None):
+        Ct, H, W = out.shape
+        fs = tiles.shape[-1]
+        self._c("vf_tiles_scatter", _ptr(tiles), _ptr(out), groups, Ct // groups, H, W, fs,
+                _ptr(vflip) if vflip is not None else None)
+
     def masked_compose(self, out, real, fake, mask):
         self._c("vf_masked_compose", _ptr(out), _ptr(real), _ptr(fake), _ptr(mask), out.numel())
 

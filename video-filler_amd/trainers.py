@@ -17,7 +17,7 @@ import os
 
 import torch
 
-from . import nn, optim
+from . import data, nn, optim
 from .backend import get_backend, to_nhwc
 
 DEFAULT_OPT_TRAIN = dict(batchSize=64, fineSize=128, nBottleneck=100, nef=64, ngf=64, ndf=64, nc=3, wtl2=0.0,
@@ -320,15 +320,9 @@ class CenterTrainer(_TrainerBase):
         """What train.lua:284-298 does on the loader's batch (a B x nc x fineSize x fineSize tensor in [-1,1]):
         clone the centre crop, paint the hole (minus the overlap band) with the channel means, and copy to the
         device buffers input_ctx / input_center / input_real_center."""
-        o, B = self.opt, get_backend()
-        fs, ov = o["fineSize"], o["overlapPred"]
-        real_ctx = B.from_host(real_ctx).clone()
-        lo, hi = fs // 4, fs // 2 + fs // 4
-        real_center = real_ctx[:, :, lo:hi, lo:hi].clone()
-        for ch, mean in enumerate((117.0, 104.0, 123.0)):
-            real_ctx[:, ch, lo + ov:hi - ov, lo + ov:hi - ov] = 2 * mean / 255.0 - 1.0
-        self.input_ctx = to_nhwc(real_ctx)
-        self._real_center = to_nhwc(real_center)
+        o = self.opt
+        self.input_ctx, self._real_center = data.center_prepare(real_ctx, o["overlapPred"])
+        real_center = self._real_center
         if self.input_center is None or self.input_center.shape != real_center.shape:
             self.input_center = torch.empty_like(self._real_center)
             self.input_real_center = torch.empty_like(self._real_center)
