@@ -3,9 +3,10 @@
 util.cudnn(net) (util.lua:108-131) is where the reference swaps nn.SpatialConvolution for the GPU backend
 under opt.gpu > 0 (train.lua:245-258).  In this package the nn mirror classes ARE the gfx950-backed modules,
 so `util.hip(net)` only validates that the library is loaded and returns the net — drivers keep the call.
-Checkpoints: a flat fp32 dump in the reference's parameter order plus BN running statistics,
-stored as .npz; Torch7's .t7 container is a "next" row.  Like util.save (util.lua:72-97), neither
-gradients nor Adam state are saved.
+Checkpoints: `*.t7` = Torch7's own container, the object tree util.save writes (util.lua:72-97; t7.py), so a
+checkpoint moves between this backend and a Torch7 install in either direction; any other extension = a flat fp32
+dump in the reference's parameter order plus BN running statistics, stored as .npz.  Like util.save,
+neither gradients nor Adam state are saved.
 """
 import numpy as np
 import torch
@@ -23,6 +24,10 @@ cudnn = hip  # drivers written against the reference call util.cudnn(net)
 
 
 def save(filename, net, gpu=1):
+    if str(filename).endswith(".t7"):
+        from . import t7
+        t7.save(filename, t7.net_to_t7(net))
+        return
     if net._flat is None:
         net.getParameters()
     arrays = {"parameters": net.reference_flat().cpu().numpy()}
@@ -34,8 +39,23 @@ def save(filename, net, gpu=1):
         np.savez(fh, **arrays)
 
 
-def load(filename, net, gpu=1):
-    """Fill an already-constructed net (same topology) from a checkpoint written by `save`."""
+def load(filename, net=None, gpu=1):
+    """`.t7`: util.load(filename, gpu) (util.lua:99-105) — builds the net the file describes and returns it (with `net`
+    given, copies into that net instead).  Otherwise: fill an already-constructed net from a `.npz` written by `save`."""
+    if str(filename).endswith(".t7"):
+        from . import t7
+        loaded = t7.net_from_t7(t7.load(filename))
+        if net is None:
+            return loaded
+        if net._flat is None:
+            net.getParameters()
+        loaded.getParameters()
+        net.load_reference_flat(loaded.reference_flat())
+        for a, b in zip(net.leaves(), loaded.leaves()):
+            if isinstance(a, SpatialBatchNormalization):
+                a.running_mean.copy_(b.running_mean)
+                a.running_var.copy_(b.running_var)
+        return net
     if net._flat is None:
         net.getParameters()
     z = np.load(filename)
