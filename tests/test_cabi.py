@@ -66,3 +66,29 @@ def test_product_never_touches_the_oracle():
                 with open(os.path.join(dp, f)) as fh:
                     src = fh.read()
                 assert "import oracle" not in src and "from oracle" not in src and "vf_oracle" not in src, os.path.join(dp, f)
+
+
+def test_lua_binding_declares_the_header_faithfully():
+    """video-filler_amd/lua/hipnn.lua cannot be executed here (no LuaJIT/Torch7); at least its ffi.cdef must declare
+    only functions the header declares, with the same number of parameters, and every C.vf_* call in the file must be
+    declared in that cdef."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lua = open(os.path.join(root, "video-filler_amd", "lua", "hipnn.lua")).read()
+    cdef = re.search(r"ffi\.cdef\[\[(.*?)\]\]", lua, flags=re.S).group(1)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "vf_hip.h")).read(), flags=re.S)
+
+    def protos(text):
+        out = {}
+        for name, args in re.findall(r"\b(vf_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+            args = args.strip()
+            out[name] = 0 if args in ("", "void") else args.count(",") + 1
+        return out
+    h, l = protos(hdr), protos(cdef)
+    assert len(l) >= 35
+    for name, n in l.items():
+        assert name in h, "hipnn.lua declares %s, which include/vf_hip.h does not" % name
+        assert n == h[name], "%s: %d parameters in hipnn.lua, %d in the header" % (name, n, h[name])
+    called = set(re.findall(r"\bC\.(vf_[a-z0-9_]+)\s*\(", lua))
+    assert called and called <= set(l), "called but not declared in the cdef: %s" % sorted(called - set(l))

@@ -1,8 +1,9 @@
 --[[ hipnn.lua — LuaJIT/Torch7 binding of the gfx950 backend (include/vf_hip.h).
 
-  STATUS: written against the Torch7 API, NOT executed — this build environment has no Lua/LuaJIT/Torch7 and no
-  network (SURVEY.md D7).  The same C-ABI is exercised end to end by the Python mirror in video-filler_amd/nn.py,
-  which implements exactly the protocol below; INTEGRATION.md walks through the mapping.
+  STATUS: complete against the Torch7 API as published, NOT executed — this build environment has no
+  Lua/LuaJIT/Torch7 and no network (SURVEY.md D7), so expect the usual first-run typos.  The same C-ABI is exercised
+  end to end by the Python mirror in video-filler_amd/nn.py, which implements exactly the protocol below and is what the
+  tests and the bench run; INTEGRATION.md walks through the mapping.
 
   What it provides (the protocol the reference drivers use, SURVEY.md 8(b)):
     hipnn.SpatialConvolution / SpatialFullConvolution / SpatialBatchNormalization / LeakyReLU / ReLU / Tanh / Sigmoid
@@ -57,6 +58,10 @@ int vf_gdl_fwd(vf_ctx*, const float* yhat, const float* y, int B, int H, int W, 
 int vf_masked_mse_fwd(vf_ctx*, const float* x, const float* xhat, const uint8_t* mask, float w, int64_t n, double* loss);
 int vf_masked_mse_bwd(vf_ctx*, const float* x, const float* xhat, const uint8_t* mask, float w, float* gx, int64_t n);
 int vf_adam_step(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int32_t* t_dev);
+int vf_center_prepare(vf_ctx*, const float* batch_nchw, float* ctx_nhwc, float* center_nhwc, const float* fill, int B, int C, int fs, int overlapPred);
+int vf_clip_prepare(vf_ctx*, const float* clip, const float* mask, float* full, float* masked, float* maskout, int C, int iH, int iW, int fs, int w1, int h1, int flip, float mask_value, int nblocks, int block_size, const int* tlx, const int* tly);
+int vf_tiles_gather(vf_ctx*, const float* full, float* tiles, int groups, int nc, int H, int W, int fs, const unsigned char* vflip);
+int vf_tiles_scatter(vf_ctx*, const float* tiles, float* out, int groups, int nc, int H, int W, int fs, const unsigned char* vflip);
 ]]
 
 local C = ffi.load(os.getenv('VF_HIP_LIB') or 'libvf_hip.so')
@@ -118,9 +123,294 @@ function Conv:accGradParameters(input, gradOutput, scale)
                                 self.nInputPlane, self.nOutputPlane, self.kH, self.dH, self.padH, 1.0))   -- beta = 1: Torch accumulates
 end
 
--- hipnn.SpatialFullConvolution, hipnn.SpatialBatchNormalization, activations and criteria follow the same pattern over
--- vf_deconv2d_*, vf_bn_train_fwd / vf_bn_eval_fwd / vf_bn_bwd, vf_act_* and vf_bce_* / vf_mse_* / vf_gdl_fwd /
--- vf_masked_mse_* — one C call per Module method; video-filler_amd/nn.py is the executable statement of each.
+---------------------------------------------------------------------------------------------------------------
+-- nn.SpatialFullConvolution replacement (train.lua:134-146).  weight logical nIn x nOut x kH x kW, physical
+-- [nIn][kH][kW][nOut]; the three passes read the same buffer (vf_hip.h).
+---------------------------------------------------------------------------------------------------------------
+local Full, fparent = torch.class('hipnn.SpatialFullConvolution', 'nn.Module')
+function Full:__init(nIn, nOut, kW, kH, dW, dH, padW, padH)
+   fparent.__init(self)
+   self.nInputPlane, self.nOutputPlane = nIn, nOut
+   self.kW, self.kH, self.dW, self.dH = kW, kH, dW or 1, dH or 1
+   self.padW, self.padH = padW or 0, padH or 0
+   self.weight = hipnn.Tensor(nIn, kH, kW, nOut):permute(1, 4, 2, 3)
+   self.gradWeight = hipnn.Tensor(nIn, kH, kW, nOut):permute(1, 4, 2, 3)
+   self.bias, self.gradBias = hipnn.Tensor(nOut), hipnn.Tensor(nOut)
+   self.fusedAct, self.fusedSlope = 'none', 0
+end
+function Full:updateOutput(input)
+   local B, H, W = input:size(1), input:size(3), input:size(4)
+   local Ho = (H - 1) * self.dH - 2 * self.padH + self.kH
+   local Wo = (W - 1) * self.dW - 2 * self.padW + self.kW
+   self.output = hipnn.resizeNHWC(self.output, B, self.nOutputPlane, Ho, Wo)
+   check(C.vf_deconv2d_fwd(hipnn.ctx, fptr(input), fptr(self.weight), fptr(self.bias), fptr(self.output), B, H, W,
+                           self.nInputPlane, self.nOutputPlane, self.kH, self.dH, self.padH, ACT[self.fusedAct], self.fusedSlope))
+   return self.output
+end
+function Full:updateGradInput(input, gradOutput)
+   local B, H, W = input:size(1), input:size(3), input:size(4)
+   self.gradInput = hipnn.resizeNHWC(self.gradInput, B, self.nInputPlane, H, W)
+   check(C.vf_deconv2d_bwd_data(hipnn.ctx, fptr(gradOutput), fptr(self.weight), fptr(self.gradInput), B, H, W,
+                                self.nInputPlane, self.nOutputPlane, self.kH, self.dH, self.padH))
+   return self.gradInput
+end
+function Full:accGradParameters(input, gradOutput, scale)
+   assert((scale or 1) == 1)
+   local B, H, W = input:size(1), input:size(3), input:size(4)
+   check(C.vf_deconv2d_bwd_weight(hipnn.ctx, fptr(input), fptr(gradOutput), fptr(self.gradWeight), fptr(self.gradBias), B, H, W,
+                                  self.nInputPlane, self.nOutputPlane, self.kH, self.dH, self.padH, 1.0))
+end
+
+---------------------------------------------------------------------------------------------------------------
+-- nn.SpatialBatchNormalization replacement (train.lua:92).  Training: batch statistics, running_mean/var updated
+-- with `momentum`, unbiased running_var (SURVEY A.3); evaluate(): running statistics (test_vid.lua:48).
+---------------------------------------------------------------------------------------------------------------
+local BN, bparent = torch.class('hipnn.SpatialBatchNormalization', 'nn.Module')
+function BN:__init(nOutput, eps, momentum, affine)
+   bparent.__init(self)
+   assert(affine == nil or affine == true, 'the reference only builds affine BatchNorm')
+   self.eps, self.momentum, self.affine, self.train = eps or 1e-5, momentum or 0.1, true, true
+   self.weight, self.bias = hipnn.Tensor(nOutput), hipnn.Tensor(nOutput)
+   self.gradWeight, self.gradBias = hipnn.Tensor(nOutput):zero(), hipnn.Tensor(nOutput):zero()
+   self.running_mean, self.running_var = hipnn.Tensor(nOutput):zero(), hipnn.Tensor(nOutput):fill(1)
+   self.save_mean, self.save_std = hipnn.Tensor(nOutput), hipnn.Tensor(nOutput)       -- save_std holds 1/sqrt(var+eps)
+   self.sums = hipnn.DoubleTensor(2 * nOutput)
+   self.fusedAct, self.fusedSlope = 'none', 0
+end
+function BN:updateOutput(input)
+   local B, Cc, H, W = input:size(1), input:size(2), input:size(3), input:size(4)
+   self.output = hipnn.resizeNHWC(self.output, B, Cc, H, W)
+   if self.train then
+      check(C.vf_bn_train_fwd(hipnn.ctx, fptr(input), fptr(self.output), fptr(self.weight), fptr(self.bias),
+                              fptr(self.running_mean), fptr(self.running_var), fptr(self.save_mean), fptr(self.save_std),
+                              ffi.cast('double*', self.sums:data()), B * H * W, Cc, self.momentum, self.eps,
+                              ACT[self.fusedAct], self.fusedSlope))
+   else
+      check(C.vf_bn_eval_fwd(hipnn.ctx, fptr(input), fptr(self.output), fptr(self.weight), fptr(self.bias),
+                             fptr(self.running_mean), fptr(self.running_var), B * H * W, Cc, self.eps,
+                             ACT[self.fusedAct], self.fusedSlope))
+   end
+   return self.output
+end
+-- Torch7's BN computes gradInput and the parameter gradients from the same two reductions; `backward` does both in
+-- one pass (the drivers only ever call net:backward or net:updateGradInput on the container).
+function BN:backward(input, gradOutput, scale)
+   assert(self.train, 'the reference never back-propagates through BatchNorm in evaluate mode')
+   local B, Cc, H, W = input:size(1), input:size(2), input:size(3), input:size(4)
+   self.gradInput = hipnn.resizeNHWC(self.gradInput, B, Cc, H, W)
+   check(C.vf_bn_bwd(hipnn.ctx, fptr(input), fptr(self.output), fptr(gradOutput), fptr(self.gradInput),
+                     self._noParamGrad and nil or fptr(self.gradWeight), self._noParamGrad and nil or fptr(self.gradBias),
+                     fptr(self.weight), fptr(self.save_mean), fptr(self.save_std), ffi.cast('double*', self.sums:data()),
+                     B * H * W, Cc, ACT[self.fusedAct], self.fusedSlope, 1.0))
+   return self.gradInput
+end
+function BN:updateGradInput(input, gradOutput)
+   self._noParamGrad = true
+   local g = self:backward(input, gradOutput, 1)
+   self._noParamGrad = nil
+   return g
+end
+function BN:accGradParameters(input, gradOutput, scale) end      -- done by backward (see above)
+
+---------------------------------------------------------------------------------------------------------------
+-- Activations.  In-place LeakyReLU / ReLU directly after a conv or BatchNorm are folded into the producer by
+-- hipnn.fuse(net) (its epilogue applies them; the module then only forwards tensors), exactly what nn.py's
+-- Sequential does; unfused they are one vf_act_fwd / vf_act_bwd pass.
+---------------------------------------------------------------------------------------------------------------
+local function defAct(name, act, ctor)
+   local A, aparent = torch.class('hipnn.' .. name, 'nn.Module')
+   function A:__init(a, b)
+      aparent.__init(self)
+      self.act, self.slope, self.inplace, self.fusedInto = act, 0, false, nil
+      if ctor then ctor(self, a, b) end
+   end
+   function A:updateOutput(input)
+      if self.fusedInto then self.output = input; return input end
+      self.output = self.inplace and input or hipnn.resizeLike(self.output, input)
+      check(C.vf_act_fwd(hipnn.ctx, fptr(input), fptr(self.output), input:nElement(), ACT[act], self.slope))
+      return self.output
+   end
+   function A:updateGradInput(input, gradOutput)
+      -- f'(x) is taken from the OUTPUT (y > 0 <=> x > 0 for the leaky/plain ReLU; tanh, sigmoid are functions of y)
+      self.gradInput = self.inplace and gradOutput or hipnn.resizeLike(self.gradInput, gradOutput)
+      if not (self.fusedInto and self.fusedInto.bwdFused) then
+         check(C.vf_act_bwd(hipnn.ctx, fptr(self.output), fptr(gradOutput), fptr(self.gradInput), gradOutput:nElement(), ACT[act], self.slope))
+      else
+         self.gradInput = gradOutput     -- BatchNorm's backward applies the activation derivative itself
+      end
+      return self.gradInput
+   end
+end
+defAct('LeakyReLU', 'lrelu', function(self, negval, inplace) self.slope, self.negval, self.inplace = negval or 0.01, negval or 0.01, inplace or false end)
+defAct('ReLU', 'relu', function(self, inplace) self.inplace = inplace or false end)
+defAct('Tanh', 'tanh')
+defAct('Sigmoid', 'sigmoid')
+
+-- hipnn.fuse(net): mark (conv|BN, in-place activation) and (conv, Tanh|Sigmoid) pairs of a flat nn.Sequential.
+function hipnn.fuse(net)
+   local mods = net.modules
+   for i = 1, #mods - 1 do
+      local m, a = mods[i], mods[i + 1]
+      local tm, ta = torch.type(m), torch.type(a)
+      local prod = tm == 'hipnn.SpatialConvolution' or tm == 'hipnn.SpatialFullConvolution' or tm == 'hipnn.SpatialBatchNormalization'
+      local isAct = ta == 'hipnn.LeakyReLU' or ta == 'hipnn.ReLU' or ta == 'hipnn.Tanh' or ta == 'hipnn.Sigmoid'
+      local ok = prod and isAct and (a.inplace or ((ta == 'hipnn.Tanh' or ta == 'hipnn.Sigmoid') and tm ~= 'hipnn.SpatialBatchNormalization'))
+      if ok then
+         m.fusedAct, m.fusedSlope = a.act, a.slope
+         m.bwdFused = (tm == 'hipnn.SpatialBatchNormalization')
+         a.fusedInto = m
+      end
+   end
+   return net
+end
+
+---------------------------------------------------------------------------------------------------------------
+-- Criteria (train.lua:204-207, gdl_criterion.lua, MaskedMSECriterion.lua).  Losses are device doubles; :forward
+-- returns a Lua number, i.e. it synchronises like Torch7's criteria do (use hipnn.lossSlot to keep them on the device).
+---------------------------------------------------------------------------------------------------------------
+local function readLoss(slot)
+   local host = ffi.new('double[1]')
+   check(C.vf_memcpy_d2h(hipnn.ctx, host, slot:data(), 8))
+   return host[0]
+end
+local BCE = torch.class('hipnn.BCECriterion', 'nn.Criterion')
+function BCE:__init() self.gradInput = hipnn.Tensor(); self.slot = hipnn.DoubleTensor(1) end
+function BCE:updateOutput(input, target)        -- target: a label tensor filled with one value (label:fill(real_label))
+   local label = type(target) == 'number' and target or target:hostScalar()
+   check(C.vf_bce_fwd(hipnn.ctx, fptr(input), label, input:nElement(), ffi.cast('double*', self.slot:data())))
+   self.output = readLoss(self.slot)
+   return self.output
+end
+function BCE:updateGradInput(input, target)
+   local label = type(target) == 'number' and target or target:hostScalar()
+   self.gradInput = hipnn.resizeLike(self.gradInput, input)
+   check(C.vf_bce_bwd(hipnn.ctx, fptr(input), label, fptr(self.gradInput), input:nElement()))
+   return self.gradInput
+end
+local MSE = torch.class('hipnn.MSECriterion', 'nn.Criterion')
+function MSE:__init() self.gradInput = hipnn.Tensor(); self.slot = hipnn.DoubleTensor(1) end
+function MSE:updateOutput(input, target)
+   check(C.vf_mse_fwd(hipnn.ctx, fptr(input), fptr(target), input:nElement(), ffi.cast('double*', self.slot:data())))
+   self.output = readLoss(self.slot)
+   return self.output
+end
+function MSE:updateGradInput(input, target)
+   self.gradInput = hipnn.resizeLike(self.gradInput, input)
+   check(C.vf_mse_bwd(hipnn.ctx, fptr(input), fptr(target), fptr(self.gradInput), input:nElement()))
+   return self.gradInput
+end
+local GDL = torch.class('hipnn.GDLCriterion', 'nn.Criterion')      -- forward value only, as the drivers use it
+function GDL:__init(alpha) assert((alpha or 1) == 1); self.slot = hipnn.DoubleTensor(1) end
+function GDL:updateOutput(input, target)
+   check(C.vf_gdl_fwd(hipnn.ctx, fptr(input), fptr(target), input:size(1), input:size(3), input:size(4), input:size(2),
+                      ffi.cast('double*', self.slot:data())))
+   self.output = readLoss(self.slot)
+   return self.output
+end
+local MMSE = torch.class('hipnn.MaskedMSECriterion', 'nn.Criterion')
+function MMSE:__init(mWeight) self.mWeight = mWeight or 1; self.gradInput = hipnn.Tensor(); self.slot = hipnn.DoubleTensor(1) end
+function MMSE:setMask(m) self.mask = m end      -- device uint8 0/1, same element order as the input
+function MMSE:updateOutput(input, target)
+   check(C.vf_masked_mse_fwd(hipnn.ctx, fptr(input), fptr(target), ffi.cast('const uint8_t*', self.mask:data()), self.mWeight,
+                             input:nElement(), ffi.cast('double*', self.slot:data())))
+   self.output = readLoss(self.slot)
+   return self.output
+end
+function MMSE:updateGradInput(input, target)
+   self.gradInput = hipnn.resizeLike(self.gradInput, input)
+   check(C.vf_masked_mse_bwd(hipnn.ctx, fptr(input), fptr(target), ffi.cast('const uint8_t*', self.mask:data()), self.mWeight,
+                             fptr(self.gradInput), input:nElement()))
+   return self.gradInput
+end
+
+---------------------------------------------------------------------------------------------------------------
+-- hipnn.Tensor: the device tensor the classes above hold — a device pointer plus sizes/strides, the few methods the
+-- binding and the drivers touch.  (In a Torch7 tree built for ROCm, cutorch's CudaTensor plays this role and the
+-- classes work on it unchanged: they only call :size, :nElement, :data.)
+---------------------------------------------------------------------------------------------------------------
+local DT = {}
+DT.__index = DT
+local function newTensor(elemSize, ...)
+   local sizes = { ... }
+   local n = #sizes > 0 and 1 or 0
+   for _, s in ipairs(sizes) do n = n * s end
+   local self = setmetatable({ sizes = sizes, elemSize = elemSize, n = n }, DT)
+   self.strides = {}
+   local st = 1
+   for i = #sizes, 1, -1 do self.strides[i] = st; st = st * sizes[i] end
+   if n > 0 then
+      local p = ffi.new('void*[1]')
+      check(C.vf_malloc(p, n * elemSize))
+      self.ptr = ffi.gc(p[0], C.vf_free)
+   end
+   return self
+end
+function hipnn.Tensor(...) return newTensor(4, ...) end
+function hipnn.DoubleTensor(...) return newTensor(8, ...) end
+function hipnn.IntTensor(...) return newTensor(4, ...) end
+function hipnn.ByteTensor(...) return newTensor(1, ...) end
+function DT:data() return self.ptr end
+function DT:nElement() return self.n end
+function DT:dim() return #self.sizes end
+function DT:size(i) if i then return self.sizes[i] end; return torch.LongStorage(self.sizes) end
+function DT:permute(...)      -- a view with permuted logical axes over the same storage
+   local o = setmetatable({ ptr = self.ptr, elemSize = self.elemSize, n = self.n, sizes = {}, strides = {}, base = self }, DT)
+   for i, d in ipairs({ ... }) do o.sizes[i], o.strides[i] = self.sizes[d], self.strides[d] end
+   return o
+end
+function DT:zero() if self.n > 0 then check(C.vf_zero(hipnn.ctx, self.ptr, self.n * self.elemSize)) end; return self end
+function DT:fill(v)
+   assert(self.elemSize == 4)
+   self:zero()
+   check(C.vf_scale_shift(hipnn.ctx, ffi.cast('float*', self.ptr), 0, v, self.n))
+   self.hostValue = v
+   return self
+end
+function DT:hostScalar() return assert(self.hostValue, 'label tensors are filled on the host side first (label:fill)') end
+function DT:copy(src)          -- from a host torch.FloatTensor (contiguous, same element order) or another device tensor
+   if getmetatable(src) == DT then
+      check(C.vf_axpby(hipnn.ctx, 1, ffi.cast('const float*', src.ptr), 0, ffi.cast('float*', self.ptr), self.n))
+   else
+      local h = src:float():contiguous()
+      check(C.vf_memcpy_h2d(hipnn.ctx, self.ptr, h:data(), self.n * self.elemSize))
+   end
+   return self
+end
+function DT:float()            -- to a host torch.FloatTensor in this tensor's PHYSICAL order
+   local h = torch.FloatTensor(self.n)
+   check(C.vf_memcpy_d2h(hipnn.ctx, h:data(), self.ptr, self.n * 4))
+   return h
+end
+function hipnn.resizeNHWC(t, B, Cc, H, W)     -- logical B x C x H x W over [B][H][W][C]
+   if t and getmetatable(t) == DT and t.n == B * Cc * H * W and t.sizes[2] == Cc and t.sizes[3] == H then return t end
+   return hipnn.Tensor(B, H, W, Cc):permute(1, 4, 2, 3)
+end
+function hipnn.resizeLike(t, like)
+   if t and getmetatable(t) == DT and t.n == like.n then t.sizes, t.strides = like.sizes, like.strides; return t end
+   local o = newTensor(4, like.n)
+   o.sizes, o.strides = like.sizes, like.strides
+   return o
+end
+-- NCHW host tensor (B x C x H x W, contiguous) -> device channels-last, and back
+function hipnn.toNHWC(host)
+   local B, Cc, H, W = host:size(1), host:size(2), host:size(3), host:size(4)
+   local stage = hipnn.Tensor(B * Cc * H * W):copy(host)
+   local out = hipnn.resizeNHWC(nil, B, Cc, H, W)
+   check(C.vf_nchw_to_nhwc(hipnn.ctx, fptr(stage), fptr(out), B, Cc, H, W))
+   return out
+end
+function hipnn.toNCHW(dev)
+   local B, Cc, H, W = dev:size(1), dev:size(2), dev:size(3), dev:size(4)
+   local stage = hipnn.Tensor(B * Cc * H * W)
+   check(C.vf_nhwc_to_nchw(hipnn.ctx, fptr(dev), fptr(stage), B, Cc, H, W))
+   return stage:float():view(B, Cc, H, W)
+end
+-- copy an nn (NCHW-contiguous) 4-D weight into a channels-last parameter: dim 1 plays the batch role
+function hipnn.copyParameterNCHW(dst, src)
+   local h = src:float():contiguous()
+   local stage = hipnn.Tensor(h:nElement()):copy(h)
+   check(C.vf_nchw_to_nhwc(hipnn.ctx, fptr(stage), fptr(dst), h:size(1), h:size(2), h:size(3), h:size(4)))
+end
 
 ---------------------------------------------------------------------------------------------------------------
 -- util.hip(net): the backend swap.  Same walk as util.cudnn (util.lua:108-125): recurse into containers, replace by
@@ -131,6 +421,10 @@ local REPLACE = {
    ['nn.SpatialConvolution'] = function(l) return hipnn.SpatialConvolution(l.nInputPlane, l.nOutputPlane, l.kW, l.kH, l.dW, l.dH, l.padW, l.padH) end,
    ['nn.SpatialFullConvolution'] = function(l) return hipnn.SpatialFullConvolution(l.nInputPlane, l.nOutputPlane, l.kW, l.kH, l.dW, l.dH, l.padW, l.padH) end,
    ['nn.SpatialBatchNormalization'] = function(l) return hipnn.SpatialBatchNormalization(l.running_mean:size(1), l.eps, l.momentum, l.affine) end,
+   ['nn.LeakyReLU'] = function(l) return hipnn.LeakyReLU(l.negval, l.inplace) end,
+   ['nn.ReLU'] = function(l) return hipnn.ReLU(l.inplace) end,
+   ['nn.Tanh'] = function(l) return hipnn.Tanh() end,
+   ['nn.Sigmoid'] = function(l) return hipnn.Sigmoid() end,
 }
 local function recursiveHip(net)
    for k, l in ipairs(net.modules) do
@@ -138,14 +432,17 @@ local function recursiveHip(net)
       local make = REPLACE[torch.type(l)]
       if make then
          local new = make(l)
-         hipnn.copyParameterNCHW(new.weight, l.weight)
-         new.bias:copy(l.bias)
+         if l.weight then
+            if l.weight:dim() == 4 then hipnn.copyParameterNCHW(new.weight, l.weight) else new.weight:copy(l.weight) end
+            new.bias:copy(l.bias)
+         end
          if l.running_mean then new.running_mean:copy(l.running_mean); new.running_var:copy(l.running_var) end
+         new.train = l.train
          net.modules[k] = new
       end
    end
 end
-function hipnn.convert(net) recursiveHip(net); return net end
+function hipnn.convert(net) recursiveHip(net); return hipnn.fuse(net) end
 
 -- optim.adam(opfunc, x, state) with the fused device update (vf_adam_step); state.t lives on the device.
 function hipnn.adam(opfunc, x, state)
