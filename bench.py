@@ -166,6 +166,18 @@ def main():
             roofline["isolated"] = dict(achieved=round(iach, 2), frac=round(iach / PEAK_F32_MFMA_TFLOPS, 4),
                                         avg_launch_us=round(iavg * 1e3, 2),
                                         note="same kernel with nothing else on the chip (single stream; bench.py --no-overlap)")
+        # HBM bytes per launch from the PMC counters: collected in their own rocprofv3 passes (scripts/pmc_bench_traffic.sh,
+        # committed under profiles/) — counters cannot be read from inside this run
+        try:
+            import glob
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic.json")))[-1]
+            pmc = json.load(open(pmc_file))["kernels"].get(name.replace("_parity", ""))
+            if pmc is not None and args.workload == "center" and args.batch == 64:
+                roofline["traffic"] = int(pmc["hbm_MB_per_launch"] * 1e6)
+                roofline["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)"
+                roofline["traffic_source"] = os.path.relpath(pmc_file, ROOT)
+        except (IndexError, OSError, KeyError, ValueError):
+            pass
         kernels = {k: dict(launches_per_step=v["launches"] / nprof, ms_per_step=round(v["ms"] / nprof, 4),
                            tflops=(round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] > 0 and v["ms"] > 0 else None),
                            gbs=(round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] > 0 and v["ms"] > 0 else None))

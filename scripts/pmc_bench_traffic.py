@@ -1,0 +1,47 @@
+"""Fold the two rocprofv3 --pmc passes of scripts/pmc_bench_traffic.sh into bytes per launch per kernel."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+# rocprof kernel name -> the name bench.py's kernel table uses
+def bench_name(k):
+    m = re.match(r"void k_wgrad<(\d+), \w+, \w+>", k)
+    if m:
+        return "wgrad_%sx128" % m.group(1)
+    m = re.match(r"void k_igemm<(\d+), (\d+), \d+, \d+, (\w+), (\d)>", k)
+    if m:
+        return "igemm_%sx%s_%s_v%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4))
+    m = re.match(r"(?:void )?(k_[a-z0-9_]+)", k)
+    return m.group(1) if m else k
+
+acc = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = sorted(glob.glob(os.path.join(src, counter, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if not files:
+        raise SystemExit("no counter_collection.csv under %s/%s" % (src, counter))
+    with open(files[-1]) as fh:
+        for row in csv.DictReader(fh):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = bench_name(row["Kernel_Name"])
+            e = acc.setdefault(name, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+            e[counter][0] += float(row["Counter_Value"])
+            e[counter][1] += 1
+out = {}
+for name, e in sorted(acc.items()):
+    nf, nw = e["FETCH_SIZE"][1], e["WRITE_SIZE"][1]
+    if not nf or not nw:
+        continue
+    fetch_kib, write_kib = e["FETCH_SIZE"][0] / nf, e["WRITE_SIZE"][0] / nw
+    out[name] = dict(launches_counted=nf, FETCH_SIZE_KiB_per_launch=round(fetch_kib, 1), WRITE_SIZE_KiB_per_launch=round(write_kib, 1),
+                     hbm_read_MB_per_launch_x2=round(2 * fetch_kib * 1024 / 1e6, 2), hbm_write_MB_per_launch=round(write_kib * 1024 / 1e6, 2),
+                     hbm_MB_per_launch=round((2 * fetch_kib + write_kib) * 1024 / 1e6, 2))
+json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graph --no-overlap --steps 2 "
+                    "--warmup 1`; averages over every launch of the kernel in that run; FETCH_SIZE x2 (gfx950 correction, "
+                    "MI355X_MICROARCH.md); kernels keyed as in bench.py's kernel table",
+               kernels=out), open(dst, "w"), indent=1)
+print(json.dumps({k: v["hbm_MB_per_launch"] for k, v in out.items()}, indent=1))
