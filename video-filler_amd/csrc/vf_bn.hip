@@ -22,7 +22,7 @@ struct BnGeom {
   int rows_per_block;
 };
 
-static BnGeom bn_geom(int64_t npix, int C) {
+static BnGeom bn_geom(int64_t npix, int C, int target_blocks = 2048) {
   BnGeom g;
   const int C4 = C / 4;
   int cq = 1;
@@ -32,12 +32,23 @@ static BnGeom bn_geom(int64_t npix, int C) {
   g.gy = (int)vf_cdiv(C4, cq);
   // HBM-bound: aim at ~2048 blocks (8 per CU) so enough 16-byte loads are in flight; a block walks whole
   // multiples of its rp row lanes
-  const int64_t gx_target = std::max<int64_t>(1, 2048 / g.gy);
+  const int64_t gx_target = std::max<int64_t>(1, target_blocks / g.gy);
   int64_t rpb = std::max<int64_t>(g.rp, vf_cdiv(npix, gx_target));
   rpb = vf_cdiv(rpb, g.rp) * g.rp;
   g.rows_per_block = (int)rpb;
   g.gx = (int)vf_cdiv(npix, rpb);
   return g;
+}
+
+// Reduction kernels write one partial row per block and a second stage walks those rows column by column: fewer,
+// fatter blocks keep that second stage short (2048 rows made it the longest of BatchNorm's three launches).
+static int bn_stat_blocks(int64_t npix, int C, int bytes_per_block) {
+  static const int forced = getenv("VF_BN_STAT_BLOCKS") ? atoi(getenv("VF_BN_STAT_BLOCKS")) : 0;
+  if (forced > 0) return forced;
+  // measured (scripts/bench_bn.py sweep, gpurun_out/bn_sweep.log): one block per 32 KB of a tensor read once (forward
+  // statistics, bias gradients), per 16 KB of a tensor read beside two others (backward), between 128 and 512 blocks
+  const int64_t b = npix * C * 4 / bytes_per_block;
+  return (int)std::min<int64_t>(512, std::max<int64_t>(128, b));
 }
 
 // ---- forward statistics: partial[slab][2][C] (double)
@@ -348,7 +359,7 @@ int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C,
   double* part = (double*)vf_ws_ptr(ctx);
   int nslab;
   if (C % 4 == 0 && (((uintptr_t)g) & 15) == 0) {
-    const BnGeom ge = bn_geom(P, C);
+    const BnGeom ge = bn_geom(P, C, bn_stat_blocks(P, C, 32768));
     nslab = ge.gx;
     VF_REQUIRE((size_t)(nslab + 1) * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for bias-grad partials");
     hipLaunchKernelGGL(k_colsum4, dim3(ge.gx, ge.gy), dim3(256), 0, ctx->stream, g, part, P, C, ge.cq, ge.rows_per_block);
@@ -368,7 +379,7 @@ int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C,
 
 VF_API int vf_bn_stats(vf_ctx* ctx, const float* x, const float* shift, double* sums, int64_t npix, int C) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
-  const BnGeom g = bn_geom(npix, C);
+  const BnGeom g = bn_geom(npix, C, bn_stat_blocks(npix, C, 32768));
   VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
   VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C);
   hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, shift, (double*)vf_ws_ptr(ctx), npix, C, g.cq,
@@ -400,7 +411,7 @@ VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* g
                            float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
                            int64_t npix, int C, float momentum, float eps, int act, float slope) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
-  const BnGeom g = bn_geom(npix, C);
+  const BnGeom g = bn_geom(npix, C, bn_stat_blocks(npix, C, 32768));
   VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
   {
     VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C);
@@ -432,7 +443,7 @@ VF_API int vf_bn_bwd_stats(vf_ctx* ctx, const float* x, const float* y_act, cons
                            double* sums, int64_t npix, int C, int act, float slope) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "fused activation backward needs the activated output");
-  const BnGeom g = bn_geom(npix, C);
+  const BnGeom g = bn_geom(npix, C, bn_stat_blocks(npix, C, 16384));
   VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
   VfProf prof(ctx, "bn_bwd_stats", 0.0, 4.0 * (double)npix * C * (act != VF_ACT_NONE ? 3 : 2));
   hipLaunchKernelGGL(k_bn_bwd_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, save_mean, (double*)vf_ws_ptr(ctx),
