@@ -122,6 +122,19 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # per-step distribution (median and p10/p90 over >= 100 iterations): a separate pass after the timed
+    # region, one event pair per step on the launch stream, nothing synchronises inside it
+    step_stats = None
+    if rank == 0 and world == 1:
+        nd = 100
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nd + 1)]
+        evs[0].record()
+        for i in range(nd):
+            run()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nd))
+        step_stats = dict(n=nd, p10=round(ts[nd // 10], 4), p50=round(ts[nd // 2], 4), p90=round(ts[(9 * nd) // 10], 4))
     losses = tr.losses()
 
     # ---- instrumented pass: per-kernel HIP-event timing of the same workload (eager launches)
@@ -166,6 +179,13 @@ def main():
             roofline["isolated"] = dict(achieved=round(iach, 2), frac=round(iach / PEAK_F32_MFMA_TFLOPS, 4),
                                         avg_launch_us=round(iavg * 1e3, 2),
                                         note="same kernel with nothing else on the chip (single stream; bench.py --no-overlap)")
+        # whole-step view: every MFMA kernel's algorithmic FLOPs over the measured step time (streams overlap, so
+        # per-kernel durations under-state what the chip as a whole sustains)
+        mfma_flops = sum(v["flops"] for v in kernels.values()) / nprof
+        step_s = dt / args.steps
+        roofline["whole_step"] = dict(mfma_gflop_per_step=round(mfma_flops / 1e9, 1), tflops=round(mfma_flops / step_s / 1e12, 2),
+                                      frac=round(mfma_flops / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                      note="all MFMA kernels' algorithmic FLOPs / ms_per_step (includes every non-MFMA kernel's time)")
         # HBM bytes per launch from the PMC counters: collected in their own rocprofv3 passes (scripts/pmc_bench_traffic.sh,
         # committed under profiles/) — counters cannot be read from inside this run
         try:
@@ -203,6 +223,19 @@ def main():
         cdt = time.perf_counter() - c0
         cpu = dict(value=round(cb / cdt, 3), unit="images/s", cores=1, kind="port",
                    sample="1 full iteration (fDx+Adam+fGx+Adam) of the same nets at batchSize=%d, %.1f s" % (cb, cdt))
+        # second row (SURVEY 8(d) ii): the same iteration with OpenMP over all host cores the box gives this process
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        if ncores > 1:
+            O.set_num_threads(ncores)
+            c0 = time.perf_counter()
+            ref.step()
+            cdt2 = time.perf_counter() - c0
+            O.set_num_threads(1)
+            cpu["all_cores"] = dict(value=round(cb / cdt2, 3), unit="images/s", cores=ncores,
+                                    sample="the same iteration, OpenMP over %d threads, %.1f s" % (ncores, cdt2))
 
     if rank == 0:
         n_img = world * args.batch * args.steps
@@ -223,6 +256,7 @@ def main():
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "step_ms": step_stats,
             "losses": losses,
             "kernels": kernels,
         }

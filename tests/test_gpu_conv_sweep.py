@@ -1,0 +1,84 @@
+"""Seeded random sweep of conv / full-conv shapes against the oracle: ragged batches, channel counts that miss every
+vector width and tile multiple (3, 6, 27, 33, 100, 130 ...), Cout = 1, both geometries the reference builds
+(4x4 stride 2 pad 1; 4x4 stride 1 pad 0 bottleneck), every pass, accumulate and overwrite.  Plus the argument checks
+of the C-ABI (the reference's THNN raises on the same misuse)."""
+import numpy as np
+import pytest
+
+from helpers import assert_close, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cin = [3, 6, 12, 16, 20, 27, 32, 48, 64, 100, 132]
+    cout = [1, 3, 12, 16, 27, 33, 64, 96, 130]
+    out = []
+    while len(out) < n:
+        full = bool(rng.integers(0, 2))
+        B, Ci, Co = int(rng.integers(1, 10)), int(rng.choice(cin)), int(rng.choice(cout))
+        if rng.random() < 0.25:
+            H, s, p = (1 if full else 4), 1, 0            # bottleneck geometry
+        else:
+            H, s, p = int(rng.choice([2, 4, 8, 16, 32] if full else [4, 8, 16, 32])), 2, 1
+        if B * max(Ci, Co) * (H * (2 if full else 1)) ** 2 > 3_000_000:
+            continue
+        out.append((full, B, Ci, H, Co, s, p))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(48, 20261003))
+def test_random_shapes(case, oracle, hipb):
+    full, B, Cin, H, Cout, s, p = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    r = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    ref = (oracle.SpatialFullConvolution if full else oracle.SpatialConvolution)(Cin, Cout, 4, 4, s, s, p, p)
+    ref.weight[...] = r(*ref.weight.shape) * 0.05
+    ref.bias[...] = r(Cout)
+    x = r(B, Cin, H, H)
+    y = ref.forward(x)
+    gy = r(*y.shape)
+    ref.gradWeight[...] = r(*ref.weight.shape)
+    ref.gradBias[...] = r(Cout)
+    gw0, gb0 = ref.gradWeight.copy(), ref.gradBias.copy()
+    ref.backward(x, gy)
+    fwd, bwd_d, bwd_w = ((hipb.deconv2d_fwd, hipb.deconv2d_bwd_data, hipb.deconv2d_bwd_weight) if full else
+                         (hipb.conv2d_fwd, hipb.conv2d_bwd_data, hipb.conv2d_bwd_weight))
+    dx, dw, db = to_dev(x, hipb), to_dev(ref.weight, hipb), to_dev(ref.bias, hipb)
+    dy = hipb.empty_act(*y.shape)
+    fwd(dx, dw, db, dy, 4, s, p)
+    assert_close(to_np(dy), y, TOL, "fwd %s" % (case,))
+    dgy, dgx = to_dev(gy, hipb), hipb.empty_act(*x.shape)
+    bwd_d(dgy, dw, dgx, 4, s, p)
+    assert_close(to_np(dgx), ref.gradInput, TOL, "bwd_data %s" % (case,))
+    dgw, dgb = to_dev(gw0, hipb), to_dev(gb0, hipb)
+    bwd_w(dx, dgy, dgw, dgb, 4, s, p, 1.0)
+    assert_close(to_np(dgw), ref.gradWeight, TOL, "bwd_weight(beta=1) %s" % (case,))
+    assert_close(to_np(dgb), ref.gradBias, TOL, "bias grad %s" % (case,))
+    bwd_w(dx, dgy, dgw, dgb, 4, s, p, 0.0)
+    assert_close(to_np(dgw), ref.gradWeight - gw0, 2 * TOL, "bwd_weight(beta=0) %s" % (case,))
+    assert_close(to_np(dgb), ref.gradBias - gb0, 2 * TOL, "bias grad(beta=0) %s" % (case,))
+
+
+def test_c_abi_rejects_what_the_reference_never_builds(hipb):
+    """k = 4 only, (stride, pad) in {(2,1), (1,0)}, power-of-two maps: anything else returns an error (never a wrong
+    result or a fault)."""
+    x = hipb.empty_act(2, 16, 8, 8)
+    w = hipb.empty(32, 4, 4, 16).permute(0, 3, 1, 2)
+    b = hipb.zeros(32)
+    y = hipb.empty_act(2, 32, 4, 4)
+    with pytest.raises(RuntimeError):
+        hipb.conv2d_fwd(x, w, b, y, 3, 2, 1)              # 3x3 kernel
+    with pytest.raises(RuntimeError):
+        hipb.conv2d_fwd(x, w, b, y, 4, 2, 0)              # stride 2 without pad 1
+    with pytest.raises(RuntimeError):
+        hipb.conv2d_fwd(x, w, b, y, 4, 3, 1)              # stride 3
+    x6 = hipb.empty_act(2, 16, 6, 6)                      # 6x6 map: not a power of two
+    with pytest.raises(RuntimeError):
+        hipb.conv2d_fwd(x6, w, b, hipb.empty_act(2, 32, 3, 3), 4, 2, 1)
+    bn_x = hipb.empty_act(2, 6, 4, 4)                     # BatchNorm over a channel count that is not a multiple of 4
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        hipb.bn_stats(bn_x, None, hipb.zeros(12, dtype=__import__("torch").float64))

@@ -1017,8 +1017,9 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   const int64_t blocks = (int64_t)gx * gy;
   const int64_t total = (int64_t)Nu * ntaps * Cv;
   int ksplit = 1;
-  if (blocks < 384 && g.nk >= 16) {
-    ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(512, blocks));
+  static const int tune_wg_blocks = getenv("VF_WGRAD_BLOCKS") ? atoi(getenv("VF_WGRAD_BLOCKS")) : 512;
+  if (blocks < tune_wg_blocks * 3 / 4 && g.nk >= 16) {
+    ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(tune_wg_blocks, blocks));
     while (ksplit > 1 && (size_t)ksplit * total * sizeof(float) > vf_ws_avail(ctx)) --ksplit;
     if (ksplit < 1) ksplit = 1;
     const int steps = (int)vf_cdiv(g.nk, ksplit);
