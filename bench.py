@@ -228,6 +228,7 @@ def main():
             ncores = len(os.sched_getaffinity(0))
         except AttributeError:
             ncores = os.cpu_count() or 1
+        ncores = min(ncores, 16)      # a one-GPU box's CPU share (more threads than that oversubscribe: 256 ran 5x SLOWER)
         if ncores > 1:
             O.set_num_threads(ncores)
             c0 = time.perf_counter()
@@ -235,7 +236,7 @@ def main():
             cdt2 = time.perf_counter() - c0
             O.set_num_threads(1)
             cpu["all_cores"] = dict(value=round(cb / cdt2, 3), unit="images/s", cores=ncores,
-                                    sample="the same iteration, OpenMP over %d threads, %.1f s" % (ncores, cdt2))
+                                    sample="the same iteration, OpenMP over %d threads (the one-GPU box's CPU share), %.1f s" % (ncores, cdt2))
 
     if rank == 0:
         n_img = world * args.batch * args.steps
