@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--sync-bn", action="store_true", help="N>1: all-reduce BatchNorm sums (big-batch parity mode)")
     ap.add_argument("--force-dist", action="store_true", help="N=1: run the data-parallel path (RCCL init + all-reduce) anyway")
+    ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep G's gradient exchange and Adam(G) inside the iteration "
+                    "(default: they run behind the next iteration's netD real pass)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no dW || dX, no netG-fwd || netD-real overlap)")
     args = ap.parse_args()
 
@@ -91,10 +93,13 @@ def main():
     dp = world > 1 or args.force_dist
     tr.force_comm = args.force_dist
     use_graph = not args.no_graph and not (dp and args.sync_bn)
+    pipelined = dp and not args.no_pipeline and not args.sync_bn
     if dp:
         if use_graph:
-            tr.capture_phased(warmup=max(args.warmup, 2))
-        run = tr.step_phased
+            tr.capture_phased(warmup=max(args.warmup, 2), pipelined=pipelined)
+        else:
+            tr._pipelined = pipelined
+        run = tr.step_pipelined if pipelined else tr.step_phased
         for _ in range(max(args.warmup, 10) if use_graph else args.warmup):
             run()
     elif use_graph:
@@ -253,7 +258,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl, "global_batch": world * args.batch, "launch": ("hipGraph x4 + bucketed RCCL all-reduce between (G tail bucket overlaps the encoder backward)" if dp else "hipGraph") if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
+            "config": {"workload": wl, "global_batch": world * args.batch, "launch": (("hipGraph x4 + bucketed RCCL all-reduce between; " + ("G buckets in flight during the encoder backward and the next iteration's netD real pass" if pipelined else "G tail bucket in flight during the encoder backward")) if dp else "hipGraph") if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -184,8 +184,9 @@ def test_graph_replay_matches_eager(oracle, hipb):
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k]))
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("kind", ["center", "vid"])
-def test_phased_dp_step_over_rccl_matches_plain_step(kind, oracle, hipb):
+def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hipb):
     """The data-parallel iteration (4 HIP graphs with RCCL all-reduce-average between them, G's gradient in two
     buckets, the tail one in flight during the encoder's backward) on a world of ONE rank must walk exactly the
     trajectory of the plain loop body: averaging over one rank is the identity."""
@@ -210,9 +211,12 @@ def test_phased_dp_step_over_rccl_matches_plain_step(kind, oracle, hipb):
     b.force_comm = True
     for _ in range(5):
         a.step()
-    b.capture_phased(warmup=3)
-    b.step_phased()
-    b.step_phased()
+    # pipelined: G's exchange and Adam(G) run behind the NEXT iteration's netD real pass; flush() completes the last one
+    b.capture_phased(warmup=3, pipelined=pipelined)
+    step = b.step_pipelined if pipelined else b.step_phased
+    step()
+    step()
+    b.flush()
     torch.cuda.synchronize()
     assert torch.equal(b.parametersG, a.parametersG)
     assert torch.equal(b.parametersD, a.parametersD)

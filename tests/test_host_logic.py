@@ -215,7 +215,7 @@ def _dp_worker(rank, world, port, kind, out_dir):
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
     vb2.set_backend(OracleBackend())
     B = 4
-    if kind == "center":
+    if kind.startswith("center"):
         opt = dict(SMALL, wtl2=0.999, overlapPred=4, smooth=True)   # smooth nets: see tests/test_gpu_trainers.py
         full_batch = torch.from_numpy(O.synth_center_batch(B, np.random.default_rng(77)))
         mk = lambda w, r, s: CenterTrainer(opt, seed=11, world=w, rank=r, sync_bn=s)
@@ -229,13 +229,19 @@ def _dp_worker(rank, world, port, kind, out_dir):
     per = B // world
     # "vid" runs the phased step (A | all-reduce D | B | all-reduce G | C) that bench.py uses for N > 1;
     # "center" runs the plain loop body with the exchange inside the closures.  Both must equal the big batch.
-    dp_step = tr.step_phased if kind == "vid" else tr.step
+    # "*_pipe" runs the pipelined step (G's exchange and Adam deferred behind the next iteration's netD real pass).
+    if kind.endswith("_pipe"):
+        tr._pipelined = True
+        dp_step = tr.step_pipelined
+    else:
+        dp_step = tr.step_phased if kind == "vid" else tr.step
     feed(tr, rank * per, (rank + 1) * per)
     dp_step()
     g1 = tr.gradParametersG.numpy().copy()      # after ONE iteration: gradients are comparable at fp32 precision
     rm1 = [m.running_mean.numpy().copy() for m in tr.netG.leaves() if hasattr(m, "running_mean")]
     feed(tr, rank * per, (rank + 1) * per)
     dp_step()
+    tr.flush()                                  # pipelined: the last iteration's Adam(G) is still pending
     res = dict(pG=tr.parametersG.numpy().copy(), pD=tr.parametersD.numpy().copy(), gG=g1, rm=rm1)
     if rank == 0:
         one = mk(1, 0, False)                 # the single-device big batch the shards must reproduce
@@ -260,9 +266,9 @@ def _dp_worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["center", "vid"])
+@pytest.mark.parametrize("kind", ["center", "vid", "center_pipe", "vid_pipe"])
 def test_data_parallel_world2_equals_big_batch(kind, tmp_path):
-    port = 29500 + (os.getpid() % 2000) + (7 if kind == "vid" else 0)
+    port = 29500 + (os.getpid() % 2000) + 7 * ["center", "vid", "center_pipe", "vid_pipe"].index(kind)
     mp.spawn(_dp_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
     pG, pD, gG, rm = np.load(str(tmp_path / "ok.npy"))
     assert float(np.load(str(tmp_path / "same.npy"))[0]) == 1.0, "replicas diverged across ranks"

@@ -153,6 +153,9 @@ class _TrainerBase:
         self._defer_comm = False
         self._split_g = None
         self._g_mid = None
+        self._pipelined = False      # data-parallel step with G's exchange + Adam deferred into the next iteration
+        self._inflight = []          # async all-reduce handles of G's gradient buckets
+        self._gen = None
         self.force_comm = False      # run the exchange even at world == 1 (exercises the DP path on one GPU)
         self.defer_adam_g = False
         self._pending_g = False
@@ -166,6 +169,11 @@ class _TrainerBase:
         leaves the exchange to the step (`_defer_comm`)."""
         if self._comm_on() and not self._defer_comm:
             get_backend().all_reduce_avg(flat, self.world, self.group)
+
+    def fDx(self, x):
+        for _ in self._fDx_gen():
+            pass
+        return self.errD, self.gradParametersD
 
     def _backward_G(self, df_dg):
         """netG:backward(input_ctx, df_dg) + the exchange of its gradients.  In a phased step only the part of the
@@ -198,12 +206,19 @@ class _TrainerBase:
             optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
             self._pending_g = False
 
+    def _wait_inflight(self):
+        for h in self._inflight:
+            if h is not None:
+                h.wait()
+        self._inflight = []
+
     def flush(self):
         """Apply a deferred Adam(G).  A captured graph always begins with that update, so after a flush the graph
         must not be replayed again (capture anew instead)."""
         if self._pending_g:
+            self._wait_inflight()
             self._apply_pending_g()
-            if self._graph is not None and self.defer_adam_g:
+            if (self._graph is not None and self.defer_adam_g) or (self._graphs is not None and self._pipelined):
                 self._graph_stale = True
 
     # -- the same iteration cut at the gradient exchanges (data parallel):
@@ -250,6 +265,44 @@ class _TrainerBase:
                 h.wait()
         pc()
 
+    # -- pipelined data-parallel iteration: G's exchange and Adam move into the NEXT iteration, behind netD's real pass
+    #    A1: netD real pass | wait G buckets (i-1) | A2: Adam(G) (i-1), netG forward, netD fake pass | all-reduce D |
+    #    B: Adam(D), fGx down to the bottleneck | all-reduce G tail (async) ∥ B2: encoder backward | all-reduce G head (async)
+    # The 262 MB tail bucket is then on the wire during the encoder backward AND the next iteration's netD real pass
+    # (neither reads generator state).  Same arithmetic on every buffer in the same order as step_phased();
+    # flush() completes the last iteration (waits, applies Adam(G)).
+    def _phase_a1(self):
+        self._defer_comm = True
+        self._gen = self._fDx_gen()
+        next(self._gen)
+
+    def _phase_a2(self):
+        for _ in self._gen:
+            pass
+        self._gen = None
+        self._defer_comm = False
+
+    def step_pipelined(self):
+        B = get_backend()
+        assert self._pipelined, "call capture_phased(pipelined=True) or set _pipelined before the first step"
+        pa1, pa2, pb, pb2 = ([g.replay for g in self._graphs] if self._graphs is not None
+                             else [self._phase_a1, self._phase_a2, self._phase_b, self._phase_b2])
+        assert not self._graph_stale, "flush() was called: the captured graphs would apply Adam(G) twice; capture again"
+        _, off = self.netG.bucket_split()
+        gG = self.gradParametersG
+        pa1()
+        self._wait_inflight()
+        pa2()
+        if self._graphs is not None:
+            self._pending_g = False            # the replayed A2 applied it
+        B.all_reduce_avg(self.gradParametersD, self.world, self.group)
+        pb()
+        h_tail = B.all_reduce_avg(gG[off:], self.world, self.group, async_op=True)
+        pb2()
+        h_head = B.all_reduce_avg(gG[:off], self.world, self.group, async_op=True) if off > 0 else None
+        self._inflight = [h_tail, h_head]
+        self._pending_g = True
+
     # -- HIP graph of one whole iteration (single-GPU): zero launch gaps, no host work per step
     def capture(self, warmup=3, defer_adam_g=False):
         assert not self._comm_on(), "one graph covers the single-device iteration; use capture_phased() for DP"
@@ -270,16 +323,23 @@ class _TrainerBase:
         self._pending_g = self.defer_adam_g      # the graph leaves the last iteration's Adam(G) pending
         return g
 
-    def capture_phased(self, warmup=3):
-        """Four graphs (phases A, B, B2, C) with the RCCL all-reduces launched between them.  SyncBN puts
-        collectives inside the phases, so it runs eagerly instead."""
+    def capture_phased(self, warmup=3, pipelined=False):
+        """Four graphs (phases A, B, B2, C — or A1, A2, B, B2 when pipelined) with the RCCL all-reduces launched between
+        them.  SyncBN puts collectives inside the phases, so it runs eagerly instead."""
         B = get_backend()
-        for _ in range(warmup):
-            self.step_phased()
+        self._pipelined = bool(pipelined)
+        step = self.step_pipelined if pipelined else self.step_phased
+        for _ in range(max(warmup, 1)):
+            step()
         torch.cuda.synchronize()
+        if pipelined:
+            self._wait_inflight()            # the captured A2 starts with the pending Adam(G)
+            phases = (self._phase_a1, self._phase_a2, self._phase_b, self._phase_b2)
+        else:
+            phases = (self._phase_a, self._phase_b, self._phase_b2, self._phase_c)
         graphs = []
         pool = None
-        for phase in (self._phase_a, self._phase_b, self._phase_b2, self._phase_c):
+        for phase in phases:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
                 B.use_current_stream()
@@ -288,6 +348,12 @@ class _TrainerBase:
             pool = g.pool()
             graphs.append(g)
         self._graphs = tuple(graphs)
+        self._graph_stale = False
+        if pipelined:
+            # the capture recorded (did not execute) one iteration: G's gradients of the last warm-up step are still
+            # pending and the next replay of A2 applies them
+            self._pending_g = True
+            self._inflight = []
         return self._graphs
 
     def replay(self):
@@ -327,15 +393,19 @@ class CenterTrainer(_TrainerBase):
             self.input_center = torch.empty_like(self._real_center)
             self.input_real_center = torch.empty_like(self._real_center)
 
-    def fDx(self, x):
+    def _fDx_gen(self):
+        """fDx as a generator that yields once, at the point where the generator net's parameters are first needed:
+        everything before it (netD's real pass) is independent of netG, so a pipelined data-parallel step lets the
+        previous iteration's gradient exchange run until there (`_TrainerBase.step_pipelined`)."""
         B, o = get_backend(), self.opt
+        early_g = self.side_g is not None and not self._pipelined
         self.netD.zeroConvBiases()
         if not self._pending_g:
             self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
         # netG's forward does not depend on netD's real pass: issue it on a side stream (same arithmetic)
         fake = None
-        if self.side_g is not None:
+        if early_g:
             with self.side_g.on():
                 if self._pending_g:               # deferred Adam(G) of the previous iteration, then the bias sweep
                     self._apply_pending_g()
@@ -350,8 +420,12 @@ class CenterTrainer(_TrainerBase):
         errD_real = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
         self.netD.backward(self.input_center, df_do, need_input_grad=not self.skip_dead_grads)
+        yield "generator parameters needed"
         # train with fake
         if fake is None:
+            if self._pending_g:
+                self._apply_pending_g()
+                self.netG.zeroConvBiases()
             fake = self.netG.forward(self.input_ctx)
         else:
             self.side_g.join()
@@ -363,7 +437,6 @@ class CenterTrainer(_TrainerBase):
         self.netD.backward(self.input_center, df_do, need_input_grad=not self.skip_dead_grads)
         self.errD = errD_real + errD_fake
         self._allreduce_avg(self.gradParametersD)
-        return self.errD, self.gradParametersD
 
     def fGx(self, x):
         B, o = get_backend(), self.opt
@@ -424,8 +497,9 @@ class VidTrainer(_TrainerBase):
             self.input_mask = torch.empty_like(self._real_mask)
             self.input_inpainted = torch.empty_like(self._real_full)
 
-    def fDx(self, x):
+    def _fDx_gen(self):
         B, o = get_backend(), self.opt
+        early_g = self.side_g is not None and not self._pipelined
         self.netD.zeroConvBiases()
         if not self._pending_g:
             self.netG.zeroConvBiases()
@@ -435,7 +509,7 @@ class VidTrainer(_TrainerBase):
             B.copy(self.input_real, self._real_full)
         B.copy(self.input_mask, self._real_mask)
         fake = None
-        if self.side_g is not None:            # netG forward beside netD's real pass (independent work)
+        if early_g:                            # netG forward beside netD's real pass (independent work)
             with self.side_g.on():
                 if self._pending_g:
                     self._apply_pending_g()
@@ -446,7 +520,11 @@ class VidTrainer(_TrainerBase):
         errD_real = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
         self.netD.backward(self.input_real, df_do, need_input_grad=not self.skip_dead_grads)
+        yield "generator parameters needed"
         if fake is None:
+            if self._pending_g:
+                self._apply_pending_g()
+                self.netG.zeroConvBiases()
             fake = self.netG.forward(self.input_ctx)
         else:
             self.side_g.join()
@@ -461,7 +539,6 @@ class VidTrainer(_TrainerBase):
         self.netD.backward(self.input_inpainted, df_do, need_input_grad=not self.skip_dead_grads)
         self.errD = errD_real + errD_fake
         self._allreduce_avg(self.gradParametersD)
-        return self.errD, self.gradParametersD
 
     def fGx(self, x):
         B, o = get_backend(), self.opt
