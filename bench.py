@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="N=1: run the data-parallel path (RCCL init + all-reduce) anyway")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep G's gradient exchange and Adam(G) inside the iteration "
                     "(default: they run behind the next iteration's netD real pass)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control "
+                    "flow with several ranks on ONE GPU (not a measurement)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no dW || dX, no netG-fwd || netD-real overlap)")
     args = ap.parse_args()
 
@@ -58,11 +61,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from video_filler_amd.backend import get_backend
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
@@ -151,6 +159,14 @@ def main():
         # shares the chip with).  Eager launches so that each one can carry its own start/stop events.
         tr._graphs = None
         tr.force_comm = False
+        # rank 0 runs this pass ALONE: no collective may be reached from here on (the other ranks are waiting in the
+        # final barrier), so the trainer becomes a single-device one
+        tr._pipelined = False
+        tr.world = 1
+        for net in (tr.netG, tr.netD):
+            for m in net.leaves():
+                if hasattr(m, "sync_world"):
+                    m.sync_world, m.sync_group = 1, None
         B.prof_begin()
         for _ in range(nprof):
             tr.step()
@@ -271,6 +287,8 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if world > 1 or args.force_dist:
+        if world > 1:
+            dist.barrier()          # ranks > 0 wait here while rank 0 runs its instrumented pass and the CPU baseline
         dist.destroy_process_group()
 
 
