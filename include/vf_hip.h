@@ -67,6 +67,11 @@ int vf_conv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx, 
                        int Cin, int Cout, int k, int stride, int pad);
 /* accGradParameters(scale = 1).  gw = beta*gw + dW ; gb = beta*gb + db (gb may be NULL).
  * beta = 1 is Torch's accumulate; beta = 0 overwrites (saves the gradParameters:zero() pass). */
+/* updateGradInput of a conv whose INPUT is the in-place activated output of the module before it (train.lua:89-91:
+ * conv -> LeakyReLU(0.2, true) -> conv): gx = (W^T * gy) .* act'(x_act), i.e. this conv's updateGradInput and the
+ * nn.LeakyReLU:updateGradInput pass over the same tensor in one epilogue.  x_act is this conv's own input. */
+int vf_conv2d_bwd_data_act(vf_ctx* ctx, const float* gy, const float* w, float* gx, const float* x_act, int act,
+                           float slope, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 int vf_conv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H,
                          int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 

@@ -108,6 +108,10 @@ class OracleBackend:
         m = self._conv_mod(O.SpatialFullConvolution if full else O.SpatialConvolution, w, k, stride, pad, full)
         _put(gx, m.updateGradInput(np.empty(tuple(gx.shape), np.float32), _np(gy)))
 
+    def conv2d_bwd_data_act(self, gy, w, gx, x_act, act, slope, k, stride, pad):
+        self.conv2d_bwd_data(gy, w, gx, k, stride, pad)
+        _put(gx, _act_grad(_np(x_act), _np(gx), act, slope))
+
     def conv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta, full=False):
         m = self._conv_mod(O.SpatialFullConvolution if full else O.SpatialConvolution, gw, k, stride, pad, full)
         m.gradWeight = np.zeros(tuple(gw.shape), np.float32)

@@ -338,3 +338,23 @@ def test_batchnorm_fused_entry_points(shape, act, oracle, hipb):
     assert_close(to_np(dgx), ref.gradInput, 5e-5, "bn fused gradInput")
     assert_close(to_np(gg), ref.gradWeight, 2e-5, "bn fused gradWeight")
     assert_close(to_np(gb), ref.gradBias, 2e-5, "bn fused gradBias")
+
+
+@pytest.mark.parametrize("case", [(2, 64, 16, 64, "lrelu"), (3, 16, 8, 32, "relu"), (64, 64, 64, 64, "lrelu"), (5, 64, 4, 128, "lrelu"),
+                                  (2, 12, 16, 32, "lrelu")])
+def test_conv_bwd_data_with_input_activation_backward(case, oracle, hipb):
+    """vf_conv2d_bwd_data_act: gx = (W^T gy) .* act'(x) in the epilogue (direct, split-K and thin-output paths) equals the
+    two passes of the reference (SpatialConvolution:updateGradInput, then LeakyReLU:updateGradInput)."""
+    B, Cin, H, Cout, act = case
+    rng = np.random.default_rng(B * 131 + Cin)
+    ref = oracle.SpatialConvolution(Cin, Cout, 4, 4, 2, 2, 1, 1)
+    ref.weight[...] = _rand(rng, *ref.weight.shape) * 0.05
+    x = _rand(rng, B, Cin, H, H)
+    x = np.where(x > 0, x, 0.2 * x if act == "lrelu" else 0.0).astype(np.float32)      # an activated tensor
+    gy = _rand(rng, B, Cout, H // 2, H // 2)
+    ref.forward(x)
+    gx = ref.updateGradInput(x, gy)
+    want = np.where(x > 0, gx, gx * np.float32(0.2) if act == "lrelu" else np.float32(0))
+    dgx = hipb.empty_act(*x.shape)
+    hipb.conv2d_bwd_data_act(to_dev(gy, hipb), to_dev(ref.weight, hipb), dgx, to_dev(x, hipb), act, 0.2, 4, 2, 1)
+    assert_close(to_np(dgx), want, TOL, "bwd_data_act %s" % (case,))

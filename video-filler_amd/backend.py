@@ -119,6 +119,12 @@ class HipBackend:
         B, Cin, H, W = gx.shape
         self._c("vf_conv2d_bwd_data", _ptr(gy), _ptr(w), _ptr(gx), B, H, W, Cin, w.shape[0], k, stride, pad)
 
+    def conv2d_bwd_data_act(self, gy, w, gx, x_act, act, slope, k, stride, pad):
+        """conv data-gradient with the backward of the in-place activation that produced this conv's input."""
+        B, Cin, H, W = gx.shape
+        self._c("vf_conv2d_bwd_data_act", _ptr(gy), _ptr(w), _ptr(gx), _ptr(x_act), ACT[act], slope, B, H, W, Cin,
+                w.shape[0], k, stride, pad)
+
     def conv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta):
         B, Cin, H, W = x.shape
         self._c("vf_conv2d_bwd_weight", _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), B, H, W, Cin, gw.shape[0], k, stride,

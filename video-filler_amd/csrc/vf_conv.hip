@@ -75,6 +75,9 @@ struct IGemm {
   long long* stamps;               // timing experiments only: 8 stamp slots per block (VF_IGEMM_STAMPS=<file>)
   int act;
   float slope;
+  const float* dmask;              // optional: out = act'(dmask[same index]) * out — the backward of the in-place activation
+  int dact;                        // that produced this pass's output tensor's forward twin (nn.LeakyReLU:updateGradInput)
+  float dslope;
 };
 
 // V = 2: 16-byte loads for A and B (C % 16 == 0);  V = 1: 16-byte A, scalar B (k-major B with N % 4 != 0);
@@ -426,7 +429,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
         const int n = n0 + wn + nt * 32 + lr;
         if (n < p.N) {
           float v = acc[mt][nt][r];
-          if (fin) v = vf_act_apply(v + bv[nt], p.act, p.slope);
+          if (fin) {
+            v = vf_act_apply(v + bv[nt], p.act, p.slope);
+            if (p.dmask) v = vf_act_grad(p.dmask[pix * p.N + n], v, p.dact, p.dslope);
+          }
           out[pix * p.N + n] = v;
         }
       }
@@ -441,19 +447,24 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 
 // y = act(sum_s slab[s] + bias)  or  dst = beta*dst + sum_s slab[s]  (wgrad).  Scalar form (any total).
 __global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ dst, const float* __restrict__ bias,
-                              int64_t total, int N, int ksplit, int act, float slope, float beta) {
+                              int64_t total, int N, int ksplit, int act, float slope, float beta,
+                              const float* __restrict__ dmask = nullptr, int dact = 0, float dslope = 0.f) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < ksplit; ++k) s += slab[(int64_t)k * total + i];
     if (bias) s += bias[i % N];
     if (beta != 0.f) s += beta * dst[i];
-    dst[i] = vf_act_apply(s, act, slope);
+    s = vf_act_apply(s, act, slope);
+    if (dmask) s = vf_act_grad(dmask[i], s, dact, dslope);
+    dst[i] = s;
   }
 }
 // 16-byte form: 64 float4 columns x 4 split lanes per block; lanes are combined in a fixed order.
 __global__ __launch_bounds__(256) void k_slab_reduce4(const float* __restrict__ slab, float* __restrict__ dst,
                                                       const float* __restrict__ bias, int64_t total4, int N, int ksplit,
-                                                      int act, float slope, float beta) {
+                                                      int act, float slope, float beta,
+                                                      const float* __restrict__ dmask = nullptr, int dact = 0,
+                                                      float dslope = 0.f) {
   const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int64_t i4 = (int64_t)blockIdx.x * 64 + tx;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -473,18 +484,25 @@ __global__ __launch_bounds__(256) void k_slab_reduce4(const float* __restrict__ 
       if (bias) v += bias[(i4 * 4 + e) % N];
       t[e] = vf_act_apply(v, act, slope);
     }
+    if (dmask) {
+      const f32x4 m = ((const f32x4*)dmask)[i4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = vf_act_grad(m[e], t[e], dact, dslope);
+    }
     ((f32x4*)dst)[i4] = t;
   }
 }
 static int launch_slab_reduce(vf_ctx* ctx, const float* slab, float* dst, const float* bias, int64_t total, int N, int ksplit,
-                              int act, float slope, float beta) {
-  if (total % 4 == 0 && ((((uintptr_t)slab) | ((uintptr_t)dst)) & 15) == 0 && ksplit > 0) {
+                              int act, float slope, float beta, const float* dmask = nullptr, int dact = 0,
+                              float dslope = 0.f) {
+  if (total % 4 == 0 && ((((uintptr_t)slab) | ((uintptr_t)dst) | ((uintptr_t)dmask)) & 15) == 0 && ksplit > 0) {
     const int64_t total4 = total / 4;
     hipLaunchKernelGGL(k_slab_reduce4, dim3((int)vf_cdiv(total4, 64)), dim3(256), 0, ctx->stream, slab, dst, bias, total4, N,
-                       ksplit, act, slope, beta);
+                       ksplit, act, slope, beta, dmask, dact, dslope);
   } else {
     const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, slab, dst, bias, total, N, ksplit, act, slope, beta);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, slab, dst, bias, total, N, ksplit, act, slope, beta,
+                       dmask, dact, dslope);
   }
   VF_LAUNCH_CHECK();
   return 0;
@@ -688,35 +706,62 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
 __global__ __launch_bounds__(256) void k_dot_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                  const float* __restrict__ bias, float* __restrict__ y, int K, int act,
                                                  float slope) {
+  // one block per sample: 16-byte loads, four independent partial sums per thread, wave shuffle tree, 4 waves via LDS
   const int b = blockIdx.x;
-  float s = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) s += x[(int64_t)b * K + k] * w[k];
-  __shared__ float red[256];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  const float* xb = x + (int64_t)b * K;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if ((K & 3) == 0) {
+    for (int k = 4 * threadIdx.x; k < K; k += 1024) {
+      const f32x4 xv = *(const f32x4*)(xb + k), wv = *(const f32x4*)(w + k);
+      acc[0] += xv[0] * wv[0];
+      acc[1] += xv[1] * wv[1];
+      acc[2] += xv[2] * wv[2];
+      acc[3] += xv[3] * wv[3];
+    }
+  } else {
+    for (int k = threadIdx.x; k < K; k += 256) acc[0] += xb[k] * w[k];
   }
-  if (threadIdx.x == 0) y[b] = vf_act_apply(red[0] + (bias ? bias[0] : 0.f), act, slope);
+  float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) y[b] = vf_act_apply(((red[0] + red[1]) + (red[2] + red[3])) + (bias ? bias[0] : 0.f), act, slope);
 }
 __global__ void k_dot_bwd_data(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int B,
                                int K) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < (int64_t)B * K) gx[i] = gy[i / K] * w[i % K];
 }
-__global__ void k_dot_bwd_weight(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gw,
-                                 float* __restrict__ gb, int B, int K, float beta) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// gw[k] = beta*gw[k] + sum_b gy[b]*x[b][k]: a block owns 64 columns; its 4 waves take every 4th sample (coalesced
+// 256-byte rows), partials meet in LDS in a fixed order.  (One thread per column walking all B samples was a
+// 64-deep dependent load chain on 32 blocks: 19 us for 2 MB.)
+__global__ __launch_bounds__(256) void k_dot_bwd_weight(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        float* __restrict__ gw, float* __restrict__ gb, int B, int K,
+                                                        float beta) {
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
   if (k < K) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += gy[b] * x[(int64_t)b * K + k];
-    gw[k] = (beta != 0.f ? beta * gw[k] : 0.f) + s;
+    int b = grp;
+    for (; b + 4 < B; b += 8) {
+      s0 += gy[b] * x[(int64_t)b * K + k];
+      s1 += gy[b + 4] * x[(int64_t)(b + 4) * K + k];
+    }
+    for (; b < B; b += 4) s0 += gy[b] * x[(int64_t)b * K + k];
   }
-  if (gb && k == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += gy[b];
-    gb[0] = (beta != 0.f ? beta * gb[0] : 0.f) + s;
+  __shared__ float red[4][64];
+  red[grp][lane] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && k < K) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    gw[k] = (beta != 0.f ? beta * gw[k] : 0.f) + t;
+  }
+  if (gb && blockIdx.x == 0 && threadIdx.x == 0) {
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += gy[b];
+    gb[0] = (beta != 0.f ? beta * gb[0] : 0.f) + t;
   }
 }
 
@@ -868,7 +913,7 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   }
   if (ksplit > 1) {
     VfProf prof(ctx, "slab_reduce_igemm", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
-    return launch_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, 0.f);
+    return launch_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, 0.f, g.dmask, g.dact, g.dslope);
   }
   return 0;
 }
@@ -914,11 +959,14 @@ static int conv_like_fwd(vf_ctx* ctx, const float* A, const float* w, const floa
 
 // Generic "transposed" pass: Y[b,oh,ow,n] = sum_{kh,kw,c : oh = 2i-1+kh ...} A[b,i,j,c] * Wt[c][kh][kw][n]
 // (conv data-grad: A = gy, c = Cout, n = Cin;  full-conv forward: A = x, c = Cin_full, n = Cout_full.)
+extern "C" int vf_act_bwd(vf_ctx* ctx, const float* y, const float* gy, float* gx, int64_t n, int act, float slope);
 static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const float* bias, float* Y, int B, int Hi, int Wi,
-                         int C, int N, int stride, int pad, int act, float slope) {
+                         int C, int N, int stride, int pad, int act, float slope, const float* dmask = nullptr, int dact = 0,
+                         float dslope = 0.f) {
   IGemm g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.Wt = w; g.bias = bias; g.Y = Y;
+  g.dmask = dmask; g.dact = dact; g.dslope = dslope;
   g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
   g.wsN = 1; g.wsC = 16 * N; g.wsTap = N;
   g.act = act; g.slope = slope;
@@ -950,6 +998,7 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
       hipLaunchKernelGGL(k_col2im4x4, dim3((unsigned)vf_cdiv(total, 256)), dim3(256), 0, ctx->stream, (const float*)cols, bias, Y,
                          B, vf_ilog2(Hi), vf_ilog2(Wi), N, act, slope);
       VF_LAUNCH_CHECK();
+      if (dmask) return vf_act_bwd(ctx, dmask, Y, Y, total, dact, dslope);      // thin path: one more pass
       return 0;
     }
   }
@@ -976,6 +1025,7 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
     g.out_elems = (int64_t)B * 16 * N;
     vecB = ((16 * N) % 4 == 0) && aligned16(w);
   }
+  VF_REQUIRE(!(dmask && bias), "activation-backward epilogue is for data-gradient passes (no bias)");
   const float* real_bias = bias;
   const int real_act = act;
   if (stride == 1 && bias) {  // bias index = column % N: apply bias + activation in a pointwise pass
@@ -1085,16 +1135,28 @@ VF_API int vf_conv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, floa
   return conv_like_bwd(ctx, gy, w, nullptr, gx, B, Ho, Wo, Cout, Cin, stride, pad, VF_ACT_NONE, 0.f);
 }
 
+VF_API int vf_conv2d_bwd_data_act(vf_ctx* ctx, const float* gy, const float* w, float* gx, const float* x_act, int act,
+                                  float slope, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad) {
+  if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
+  VF_REQUIRE(x_act != nullptr && (act == VF_ACT_LRELU || act == VF_ACT_RELU),
+             "vf_conv2d_bwd_data_act: needs the activated input and a (leaky) ReLU");
+  VF_REQUIRE(stride == 2, "vf_conv2d_bwd_data_act: only the stride-2 layers follow a bare conv + activation pair");
+  const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
+  return conv_like_bwd(ctx, gy, w, nullptr, gx, B, Ho, Wo, Cout, Cin, stride, pad, VF_ACT_NONE, 0.f, x_act, act, slope);
+}
+
 VF_API int vf_conv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W,
                                 int Cin, int Cout, int k, int stride, int pad, float beta) {
   if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   if (Cout == 1 && stride == 1 && H == 4 && W == 4) {
-    hipLaunchKernelGGL(k_dot_bwd_weight, dim3((int)vf_cdiv(16 * Cin, 256)), dim3(256), 0, ctx->stream, x, gy, gw, gb, B,
+    hipLaunchKernelGGL(k_dot_bwd_weight, dim3((int)vf_cdiv(16 * Cin, 64)), dim3(256), 0, ctx->stream, x, gy, gw, gb, B,
                        16 * Cin, beta);
     VF_LAUNCH_CHECK();
     return 0;
   }
+  // (tried: the bias gradient as a by-product of this kernel's own gy fragments — the waves that carried it made
+  //  their blocks the slowest of every launch: +0.25 ms per step against the 0.19 ms of the separate column sums)
   if (int rc = wgrad(ctx, gy, x, gw, B, Ho, Wo, Cout, H, W, Cin, stride, pad, beta)) return rc;
   if (gb) return bias_grad(ctx, gy, gb, (int64_t)B * Ho * Wo, Cout, beta);
   return 0;

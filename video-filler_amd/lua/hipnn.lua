@@ -37,6 +37,7 @@ int vf_nchw_to_nhwc(vf_ctx* ctx, const float* src, float* dst, int B, int C, int
 int vf_nhwc_to_nchw(vf_ctx* ctx, const float* src, float* dst, int B, int C, int H, int W);
 int vf_conv2d_fwd(vf_ctx*, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int act, float slope);
 int vf_conv2d_bwd_data(vf_ctx*, const float* gy, const float* w, float* gx, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad);
+int vf_conv2d_bwd_data_act(vf_ctx*, const float* gy, const float* w, float* gx, const float* x_act, int act, float slope, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad);
 int vf_conv2d_bwd_weight(vf_ctx*, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 int vf_deconv2d_fwd(vf_ctx*, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int act, float slope);
 int vf_deconv2d_bwd_data(vf_ctx*, const float* gy, const float* w, float* gx, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad);

@@ -146,9 +146,15 @@ class SpatialConvolution(Module):
         fn(input, self.weight, self.bias, y, self.kH, self.dH, self.padH, act, slope)
         return y
 
-    def updateGradInput(self, input, gradOutput):
+    def updateGradInput(self, input, gradOutput, in_act=None):
+        """in_act = (act, slope): `input` is the in-place activated output of the previous module; its
+        updateGradInput (gx .* act'(input)) is applied in this pass's epilogue instead of in a pass of its own."""
         gx = self._buf("gradInput", *input.shape)
-        fn = get_backend().deconv2d_bwd_data if self._is_full else get_backend().conv2d_bwd_data
+        B = get_backend()
+        if in_act is not None:
+            B.conv2d_bwd_data_act(to_nhwc(gradOutput), self.weight, gx, input, in_act[0], in_act[1], self.kH, self.dH, self.padH)
+            return gx
+        fn = B.deconv2d_bwd_data if self._is_full else B.conv2d_bwd_data
         fn(to_nhwc(gradOutput), self.weight, gx, self.kH, self.dH, self.padH)
         return gx
 
@@ -350,6 +356,7 @@ class Sequential(Module):
         self._plan = None
         self._flat = None
         self.side = None      # optional side backend (backend.fork()): weight gradients overlap the data-grad chain
+        self._act_done_at = -1
 
     def add(self, m):
         self.modules.append(m)
@@ -410,6 +417,7 @@ class Sequential(Module):
         g = gradOutput
         used_side = False
         hi = len(plan) if hi is None else hi
+        act_done = self._act_done_at == hi if hi < len(plan) else False
         for idx in range(hi - 1, lo - 1, -1):
             m, a = plan[idx]
             x = input if idx == 0 else plan[idx - 1][0].output
@@ -422,21 +430,34 @@ class Sequential(Module):
                     g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, m.output)
             else:
                 if a is not None:
-                    B.act_bwd(m.output, g, g, a.act, a.slope)   # in place on the incoming gradient
+                    if not act_done:
+                        B.act_bwd(m.output, g, g, a.act, a.slope)   # in place on the incoming gradient
                     a.gradInput = g
+                # the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this
+                # module's data-gradient epilogue (x IS that activated output)
+                in_act = None
+                if (self.fuse and want_gx and idx > 0 and type(m) is SpatialConvolution and m.dH == 2 and hasattr(B, "conv2d_bwd_data_act")):
+                    pm, pa = plan[idx - 1]
+                    if pa is not None and pa.act in ("lrelu", "relu") and not isinstance(pm, SpatialBatchNormalization):
+                        in_act = (pa.act, pa.slope)
+                upd = (lambda: m.updateGradInput(x, g, in_act)) if in_act is not None else (lambda: m.updateGradInput(x, g))
                 if want_gp and self.side is not None and m.parameters():
                     # dW/db only read x and g; nothing on the main stream writes either before the join below
                     with self.side.on():
                         m.accGradParameters(x, g, 1)
                     used_side = True
-                    gin = m.updateGradInput(x, g) if want_gx else None
+                    gin = upd() if want_gx else None
                 else:
-                    gin = m.updateGradInput(x, g) if want_gx else None
+                    gin = upd() if want_gx else None
                     if want_gp:
                         m.accGradParameters(x, g, 1)
                 g = gin
+                act_done = in_act is not None
+                continue
+            act_done = False
         if used_side:
             self.side.join()
+        self._act_done_at = lo if act_done else -1       # a partial walk resumes at `lo` (backward_range)
         if lo == 0:
             self.gradInput = g
         return g
