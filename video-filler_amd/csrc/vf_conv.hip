@@ -851,6 +851,8 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
       }
     }
     t = cand[pick];
+    // (tried: 256 x 64 tiles — four 64x64 wave tiles stacked in M, one block per CU — for the N = 64 layers: 153 us
+    //  against 125 us for E2's data-gradient; one wave per SIMD does not cover its own LDS/global latency)
   }
   static const int tune_split_blocks = getenv("VF_SPLIT_BLOCKS") ? atoi(getenv("VF_SPLIT_BLOCKS")) : 512;
   const int gm = (int)vf_cdiv(g.M, t.bm), gn = (int)vf_cdiv(g.N, t.bn);
