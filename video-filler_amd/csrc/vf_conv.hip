@@ -844,6 +844,9 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     int pick = 2;
     for (int i = 0; i < 3; ++i) {
       if (cand[i].bn > 64 && g.N <= 64) continue;
+      // a short K loop (<= 8 steps: the 64-channel transposed passes) leaves a 128-row block mostly prologue and
+      // epilogue; four 64x64 blocks per CU cover each other's ends better (E2 data-gradient: 122 -> 112 us)
+      if (g.parity && g.nk <= 8 && cand[i].bm > 64) continue;
       const int64_t blocks = vf_cdiv(g.M, cand[i].bm) * vf_cdiv(g.N, cand[i].bn) * zpar;
       if (blocks >= tune_min_blocks) {
         pick = i;
