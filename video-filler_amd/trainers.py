@@ -314,7 +314,7 @@ class _TrainerBase:
             self.step()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             B.use_current_stream()
             self.step()
         B.use_current_stream()
@@ -341,7 +341,7 @@ class _TrainerBase:
         pool = None
         for phase in phases:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):   # RCCL's watchdog thread may poll events meanwhile
                 B.use_current_stream()
                 phase()
             B.use_current_stream()
