@@ -82,3 +82,19 @@ def test_c_abi_rejects_what_the_reference_never_builds(hipb):
     bn_x = hipb.empty_act(2, 6, 4, 4)                     # BatchNorm over a channel count that is not a multiple of 4
     with pytest.raises(RuntimeError, match="multiple of 4"):
         hipb.bn_stats(bn_x, None, hipb.zeros(12, dtype=__import__("torch").float64))
+
+
+def test_c_abi_rejects_empty_and_oversized_batches(hipb):
+    """B = 0 is an error (THNN raises on empty tensors too); operands beyond the 2 GiB range of the hardware buffer
+    descriptors the gathers rely on are refused before anything is launched (dimensions only: no such tensor is allocated)."""
+    from video_filler_amd.backend import ACT, _ptr
+    x = hipb.empty_act(1, 64, 8, 8)
+    w = hipb.empty(64, 4, 4, 64).permute(0, 3, 1, 2)
+    b = hipb.zeros(64)
+    y = hipb.empty_act(1, 64, 4, 4)
+    with pytest.raises(RuntimeError, match="bad sizes"):
+        hipb._c("vf_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), 0, 8, 8, 64, 64, 4, 2, 1, ACT["none"], 0.0)
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        hipb._c("vf_conv2d_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), 4096, 128, 128, 64, 64, 4, 2, 1, ACT["none"], 0.0)
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        hipb._c("vf_conv2d_bwd_weight", _ptr(x), _ptr(y), _ptr(w), None, 4096, 128, 128, 64, 64, 4, 2, 1, 0.0)
