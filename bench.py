@@ -23,6 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 peak (the opt-in --mfma bf16 mode prices against this)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -44,6 +45,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control "
                     "flow with several ranks on ONE GPU (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--mfma", default="f32", choices=["f32", "bf16"], help="matrix-core operand precision; bf16 is an opt-in "
+                    "mode with its own tolerance (tests/test_gpu_bf16.py) — NOT the headline configuration")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no dW || dX, no netG-fwd || netD-real overlap)")
     args = ap.parse_args()
 
@@ -76,6 +79,10 @@ def main():
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
 
     B = get_backend()
+    global PEAK_F32_MFMA_TFLOPS
+    if args.mfma != "f32":
+        B.set_mfma_mode(args.mfma)
+        PEAK_F32_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS      # the roofline of this run is the bf16 matrix pipe
     gen = torch.Generator().manual_seed(1234 + rank)
     if args.workload == "center":
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, wtl2=0.999, overlapPred=4)
@@ -272,7 +279,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.mfma == "f32" else "bf16 MFMA operands, f32 accumulate/BN/criteria/Adam (opt-in mode)",
             "data": "synthetic",
             "config": {"workload": wl, "global_batch": world * args.batch, "launch": (("hipGraph x4 + bucketed RCCL all-reduce between; " + ("G buckets in flight during the encoder backward and the next iteration's netD real pass" if pipelined else "G tail bucket in flight during the encoder backward")) if dp else "hipGraph") if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},

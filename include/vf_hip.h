@@ -41,6 +41,11 @@ int vf_version(void);
 /* cutorch.setDevice(opt.gpu) (train.lua:249).  stream = hipStream_t or NULL for the null stream. */
 int vf_ctx_create(vf_ctx** out, int device, void* stream);
 int vf_ctx_destroy(vf_ctx* ctx);
+/* Matrix-core operand precision of the conv / full-conv passes of this context.  0 (default): fp32 operands,
+ * v_mfma_f32_32x32x2_f32 — the reference's arithmetic.  1: operands rounded to bf16 (round-to-nearest-even) on their way
+ * into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation; activations, weights, BatchNorm, criteria and Adam stay fp32 in
+ * HBM.  Opt-in: results then carry bf16 operand rounding (~2^-9 relative; tests/test_gpu_bf16.py states the tolerance). */
+int vf_ctx_set_mfma_mode(vf_ctx* ctx, int mode);
 int vf_ctx_set_stream(vf_ctx* ctx, void* stream);
 /* scratch for split-K slabs and reduction partials; caller-owned, >= vf_workspace_bytes_hint(). */
 int vf_ctx_set_workspace(vf_ctx* ctx, void* ptr, size_t bytes);

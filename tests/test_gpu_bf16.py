@@ -1,0 +1,130 @@
+"""bf16-operand matrix-core mode (vf_ctx_set_mfma_mode(ctx, 1)): opt-in, never the default.
+
+Stated tolerance: the operands of every conv / full-conv pass are rounded to bf16 (round-to-nearest-even) on their way
+into LDS; products and sums are fp32.  So (a) against the oracle fed the SAME bf16-rounded operands the result is
+fp32-exact up to summation order (2e-5 of the max-norm, as for the fp32 path), and (b) against the oracle on the
+unrounded operands it differs by operand rounding, 2^-9 relative per operand: bounded here by 1e-2 of the max-norm.
+Bias, BatchNorm, activations, criteria and Adam are untouched fp32."""
+import numpy as np
+import pytest
+
+from helpers import assert_close, to_dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+@pytest.fixture()
+def bf16_backend(hipb):
+    hipb.set_mfma_mode("bf16")
+    yield hipb
+    hipb.set_mfma_mode("f32")
+
+
+CASES = [  # (full, B, Cin, H, Cout, stride, pad)
+    (False, 2, 64, 16, 64, 2, 1), (False, 3, 16, 8, 32, 2, 1), (False, 5, 64, 4, 128, 2, 1), (False, 2, 128, 4, 100, 1, 0),
+    (False, 2, 3, 16, 64, 2, 1), (False, 1, 48, 8, 64, 2, 1), (False, 64, 64, 32, 128, 2, 1),
+    (True, 2, 100, 1, 128, 1, 0), (True, 2, 128, 4, 64, 2, 1), (True, 2, 64, 8, 3, 2, 1), (True, 5, 16, 2, 16, 2, 1),
+    (True, 64, 256, 8, 128, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16_operand_mode(case, oracle, bf16_backend):
+    hipb = bf16_backend
+    full, B, Cin, H, Cout, s, p = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    r = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    mk = oracle.SpatialFullConvolution if full else oracle.SpatialConvolution
+    w, bias, x = r(*mk(Cin, Cout, 4, 4, s, s, p, p).weight.shape) * 0.05, r(Cout), r(B, Cin, H, H)
+
+    def ref_passes(xx, ww, gy_fn):
+        m = mk(Cin, Cout, 4, 4, s, s, p, p)
+        m.weight[...] = ww
+        m.bias[...] = bias
+        y = np.array(m.forward(xx), copy=True)
+        gy = gy_fn(y.shape)
+        return m, y, gy
+
+    gy_holder = {}
+
+    def gy_fn(shape):
+        if "gy" not in gy_holder:
+            gy_holder["gy"] = r(*shape)
+        return gy_holder["gy"]
+
+    # exact-operand reference
+    m_exact, y_exact, gy = ref_passes(x, w, gy_fn)
+    m_exact.gradWeight[...] = 0
+    m_exact.gradBias[...] = 0
+    m_exact.backward(x, gy)
+    # rounded-operand reference: each pass rounds exactly the two operands the kernel stages
+    xr, wr, gyr = bf16_round(x), bf16_round(w), bf16_round(gy)
+    m_f, y_r, _ = ref_passes(xr, wr, gy_fn)
+    m_d = mk(Cin, Cout, 4, 4, s, s, p, p)
+    m_d.weight[...] = wr
+    m_d.forward(xr)
+    gx_r = np.array(m_d.updateGradInput(xr, gyr), copy=True)
+    m_w = mk(Cin, Cout, 4, 4, s, s, p, p)
+    m_w.weight[...] = wr
+    m_w.forward(xr)
+    m_w.gradWeight[...] = 0
+    m_w.gradBias[...] = 0
+    m_w.accGradParameters(xr, gyr)
+
+    fwd, bwd_d, bwd_w = ((hipb.deconv2d_fwd, hipb.deconv2d_bwd_data, hipb.deconv2d_bwd_weight) if full else
+                         (hipb.conv2d_fwd, hipb.conv2d_bwd_data, hipb.conv2d_bwd_weight))
+    dx, dw, db, dgy = to_dev(x, hipb), to_dev(w, hipb), to_dev(bias, hipb), to_dev(gy, hipb)
+    dy = hipb.empty_act(*y_exact.shape)
+    fwd(dx, dw, db, dy, 4, s, p)
+    assert_close(to_np(dy), y_r, 3e-5, "bf16 fwd vs rounded-operand oracle %s" % (case,))
+    assert_close(to_np(dy), y_exact, 1e-2, "bf16 fwd vs exact oracle %s" % (case,))
+    dgx = hipb.empty_act(*x.shape)
+    bwd_d(dgy, dw, dgx, 4, s, p)
+    assert_close(to_np(dgx), gx_r, 3e-5, "bf16 bwd_data vs rounded %s" % (case,))
+    assert_close(to_np(dgx), m_exact.gradInput, 1e-2, "bf16 bwd_data vs exact %s" % (case,))
+    dgw, dgb = hipb.zeros(*w.shape).contiguous(memory_format=__import__("torch").channels_last), hipb.zeros(Cout)
+    dgw = to_dev(np.zeros_like(w), hipb)
+    bwd_w(dx, dgy, dgw, dgb, 4, s, p, 0.0)
+    assert_close(to_np(dgw), m_w.gradWeight, 3e-5, "bf16 bwd_weight vs rounded %s" % (case,))
+    assert_close(to_np(dgw), m_exact.gradWeight, 1e-2, "bf16 bwd_weight vs exact %s" % (case,))
+    assert_close(to_np(dgb), m_exact.gradBias, 2e-5, "bias gradient stays fp32 %s" % (case,))
+
+
+def test_mode_is_opt_in_and_per_context(hipb):
+    assert hipb.mfma_mode == "f32"
+    with pytest.raises(RuntimeError):
+        from video_filler_amd import _lib
+        _lib.check(hipb.lib.vf_ctx_set_mfma_mode(hipb.ctx, 7))
+    side = hipb.fork(workspace_bytes=8 << 20)
+    hipb.set_mfma_mode("bf16")
+    assert side.mfma_mode == "bf16"
+    hipb.set_mfma_mode("f32")
+    assert side.mfma_mode == "f32" and hipb.mfma_mode == "f32"
+
+
+def test_bf16_training_iteration_tracks_fp32(oracle, bf16_backend):
+    """One full iteration of the train.lua closures in bf16-operand mode stays within operand-rounding distance of the
+    fp32 oracle: losses within 2e-2 relative, gradients within 5e-2 of their max-norm (smooth nets)."""
+    import torch
+    from video_filler_amd.trainers import CenterTrainer
+    from test_gpu_trainers import _load
+    opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4, smooth=True)
+    ref = oracle.CenterTrainer(opt, np.random.default_rng(1))
+    tr = CenterTrainer(opt, seed=3)
+    _load(tr, ref)
+    batch = oracle.synth_center_batch(4, np.random.default_rng(9))
+    ref.set_batch(batch)
+    tr.set_batch(torch.from_numpy(batch))
+    ref.step()
+    tr.step()
+    got = tr.losses()
+    for k in ("errD", "errG", "errG_l2"):
+        assert abs(got[k] - getattr(ref, k)) < 2e-2 * max(1.0, abs(getattr(ref, k))), (k, got[k], getattr(ref, k))
+    gG = tr.netG.reference_flat(grads=True).cpu().numpy()
+    assert np.abs(gG - ref.gradParametersG).max() < 5e-2 * np.abs(ref.gradParametersG).max()

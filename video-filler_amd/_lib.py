@@ -18,6 +18,7 @@ SIGNATURES = {
     "vf_version": (i32, []),
     "vf_ctx_create": (i32, [C.POINTER(vp), i32, vp]),
     "vf_ctx_destroy": (i32, [vp]),
+    "vf_ctx_set_mfma_mode": (i32, [vp, i32]),
     "vf_ctx_set_stream": (i32, [vp, vp]),
     "vf_ctx_set_workspace": (i32, [vp, vp, sz]),
     "vf_workspace_bytes_hint": (sz, []),

@@ -47,6 +47,16 @@ class HipBackend:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.vf_ctx_set_workspace(self.ctx, _ptr(self.workspace), nbytes))
         self.use_current_stream()
+        self._forks = []
+        self.mfma_mode = "f32"
+
+    def set_mfma_mode(self, mode):
+        """'f32' (default: the reference's arithmetic) or 'bf16' (operands rounded to bf16 in LDS, fp32 accumulation —
+        opt-in, its own tolerance).  Applies to this backend and the side backends forked from it."""
+        code = {"f32": 0, "bf16": 1}[mode]
+        for b in [self] + list(self._forks):
+            _lib.check(self.lib.vf_ctx_set_mfma_mode(b.ctx, code))
+            b.mfma_mode = mode
 
     # ---- plumbing
     def use_current_stream(self):
@@ -68,6 +78,10 @@ class HipBackend:
         side.stream = torch.cuda.Stream(device=self.device)
         _lib.check(self.lib.vf_ctx_set_stream(side.ctx, C.c_void_p(side.stream.cuda_stream)))
         side.parent = self
+        side._forks = []
+        side.mfma_mode = self.mfma_mode
+        _lib.check(self.lib.vf_ctx_set_mfma_mode(side.ctx, {"f32": 0, "bf16": 1}[self.mfma_mode]))
+        self._forks.append(side)
         return side
 
     def on(self):

@@ -18,6 +18,7 @@ struct vf_ctx {
   void* ws;         // caller-owned scratch (split-K slabs, reduction partials)
   size_t ws_bytes;
   size_t ws_front;  // bytes at the front of ws currently held by an im2col / column buffer (thin-channel passes)
+  int mfma_bf16;    // 0: fp32 operands (v_mfma_f32_32x32x2_f32, default); 1: operands rounded to bf16 in LDS
 };
 
 static inline char* vf_ws_ptr(vf_ctx* c) { return (char*)c->ws + c->ws_front; }

@@ -27,6 +27,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // Buffer loads with hardware range checking: an offset past num_records returns 0, so padding taps, ragged
 // tile edges and split-K tails need neither a branch nor a select — the loads stay in flight across the MFMAs.
@@ -39,6 +41,21 @@ __device__ __forceinline__ f32x4 vf_bload4(__amdgpu_buffer_rsrc_t r, unsigned by
 }
 __device__ __forceinline__ float vf_bload1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+// bf16 MFMA operand (32 rows x 16 k, 8 consecutive k per lane) out of a K-MAJOR bf16 tile [k][LD] in LDS, with gfx950's
+// transposing read: per 16-lane group ds_read_b64_tr_b16 takes a 4(k) x 16(column) block and hands lane i column i's four
+// k values, so tiles whose pieces arrive as "4 consecutive columns at one k" are stored with one 8-byte write and need
+// no transposing pass.  Lane l ends up with column col0 + l%32 and k = k0 + 8*(l/32) .. +7, the 32x32x16 operand map.
+// LD (bf16 elements) = columns + 32 keeps the four k rows of a block on disjoint bank quarters.  EXEC must be full.
+template <int LD>
+__device__ __forceinline__ bf16x8 vf_tr_frag(const __bf16* tile, int col0, int k0, int lane) {
+  const int grp = lane >> 4, i = lane & 15;
+  const __bf16* a = tile + (k0 + 8 * (grp >> 1) + (i >> 2)) * LD + col0 + 16 * (grp & 1) + 4 * (i & 3);
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * LD));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // XCD-aware block order.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its
@@ -82,7 +99,11 @@ struct IGemm {
 
 // V = 2: 16-byte loads for A and B (C % 16 == 0);  V = 1: 16-byte A, scalar B (k-major B with N % 4 != 0);
 // V = 0: scalar loads with a flattened (tap, c) K index (first/last layers: C = 3, 12, 27 ...).
-template <int BM, int BN, int WM, int WN, bool BKM, int V>
+// BF = true: bf16-operand mode (opt-in, vf_ctx_set_mfma_mode): the fp32 pieces are rounded to bf16 (RNE) on their way
+// into LDS, both operands sit there row-major [row][k] (80-byte rows: conflict-free ds_read_b128), and the products run
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Everything outside the LDS tile (addresses, loads, epilogue,
+// split-K) is shared with the fp32 path.
+template <int BM, int BN, int WM, int WN, bool BKM, int V, bool BF = false>
 __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   // One K step = 32 = two 16-wide chunks; each chunk has its own (tap, c0), so any C % 16 == 0 vectorises.
   constexpr int BK = 32, LDA = BK + 4;
@@ -94,7 +115,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   constexpr int B_CH = (BN * 8 + 255) / 256;
   constexpr int A_SZ = BM * LDA;
   constexpr int B_SZ = BKM ? BK * LDB : BN * LDB;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+  constexpr int LDH = BK + 8;                          // bf16 elements per LDS row (BF)
+  constexpr int LDN = BN + 32;                         // k-major bf16 B tile (BF && BKM): [k][LDN], transposing reads
+  constexpr int AH_SZ = BM * LDH, BH_SZ = BKM ? BK * LDN : BN * LDH;    // bf16 elements per buffer (BF)
+  constexpr int SMEM_F = BF ? (2 * (AH_SZ + BH_SZ) + 1) / 2 : 2 * (A_SZ + B_SZ);
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
@@ -316,6 +341,25 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   };
 
   auto store_piece = [&](int buf, int pc) {
+    if constexpr (BF) {
+      __bf16* Ah = (__bf16*)smem + buf * (AH_SZ + BH_SZ);
+      __bf16* Bh = Ah + AH_SZ;
+      if (pc < A_CH) {
+        const int i = pc, id = tid + 256 * i;
+        if (256 * i + 255 < BM * 8 || id < BM * 8) *(bf16x4*)(Ah + (id >> 3) * LDH + 4 * kq) = __builtin_convertvector(ra[i], bf16x4);
+      } else {
+        const int i = pc - A_CH, id = tid + 256 * i;
+        if (256 * i + 255 < BN * 8 || id < BN * 8) {
+          if constexpr (!BKM) {
+            *(bf16x4*)(Bh + (id >> 3) * LDH + 4 * kq) = __builtin_convertvector(rb[i], bf16x4);
+          } else {      // the piece holds 4 consecutive n at one k: stored as it comes, transposed by the reads
+            const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
+            *(bf16x4*)(Bh + kk * LDN + 4 * nq) = __builtin_convertvector(rb[i], bf16x4);
+          }
+        }
+      }
+      return;
+    }
     float* As = smem + buf * (A_SZ + B_SZ);
     float* Bs = As + A_SZ;
     if (pc < A_CH) {
@@ -354,6 +398,35 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   }
   __syncthreads();
   if (p.stamps && tid == 0) p.stamps[8 * blockIdx.x + 1] = wall_clock64();
+  if constexpr (BF) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const __bf16* Ah = (const __bf16*)smem + buf * (AH_SZ + BH_SZ);
+      const __bf16* Bh = Ah + AH_SZ;
+      begin_tile(kt + 1, kt + 1 < kt1);
+#pragma unroll
+      for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc);
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {
+        bf16x8 a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(Ah + (wm + mt * 32 + lr) * LDH + 16 * g + 8 * lh);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (!BKM)
+            b[nt] = *(const bf16x8*)(Bh + (wn + nt * 32 + lr) * LDH + 16 * g + 8 * lh);
+          else
+            b[nt] = vf_tr_frag<LDN>(Bh, wn + nt * 32, 16 * g, lane);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
+      store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
   constexpr int NPC = A_CH + B_CH;             // operand pieces per K step
   constexpr int NMF = 4 * MT * NT;             // MFMAs per 8-wide sub-step
   constexpr int SLOTS = (BK / 8) * NMF;        // MFMA slots per K step
@@ -405,6 +478,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     __syncthreads();
   }
 
+  }
   if (p.stamps && tid == 0) p.stamps[8 * blockIdx.x + 2] = wall_clock64();
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
@@ -525,9 +599,11 @@ struct WGrad {
 };
 
 // BM over n (64 or 128); BN = 128 columns (tap,c).  VU / VV: 16-byte loads legal for U / V.
-template <int BM, bool VU, bool VV>
+// BF: bf16-operand mode — U and V go into LDS as k-major bf16 tiles (one 8-byte store per piece), the fragments come
+// out through the transposing read (vf_tr_frag) and the products run on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+template <int BM, bool VU, bool VV, bool BF = false>
 __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
-  constexpr int BN = 128, BK = 16;
+  constexpr int BN = 128, BK = BF ? 32 : 16;      // bf16 mode: two 16-deep MFMA groups per barrier
   constexpr int LDU = BM + 4, LDV = BN + 4;
   constexpr int WN = BM == 128 ? 64 : 32;
   constexpr int NT = WN / 32;
@@ -535,7 +611,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   constexpr int U_CH = (BK * BM / 4) / 256;  // 2 (BM=128) or 1 (BM=64)
   constexpr int V_CH = (BK * BN / 4) / 256;  // 2
   constexpr int U_SZ = BK * LDU, V_SZ = BK * LDV;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (U_SZ + V_SZ)];
+  constexpr int LDMU = BM + 32, LDMV = BN + 32;        // bf16 elements per k row (BF): k-major tiles, transposing reads
+  constexpr int UH_SZ = BK * LDMU, VH_SZ = BK * LDMV;
+  constexpr int SMEM_F = BF ? (2 * (UH_SZ + VH_SZ) + 1) / 2 : 2 * (U_SZ + V_SZ);
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
@@ -605,6 +684,18 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
     }
   };
   auto store_piece = [&](int buf, int pc) {
+    if constexpr (BF) {
+      __bf16* Uh = (__bf16*)smem + buf * (UH_SZ + VH_SZ);
+      __bf16* Vh = Uh + UH_SZ;
+      if (pc < U_CH) {
+        const int k = ukk + pc * (1024 / BM);
+        *(bf16x4*)(Uh + k * LDMU + 4 * uq) = __builtin_convertvector(ru[pc], bf16x4);
+      } else {
+        const int i = pc - U_CH, k = (tid >> 5) + 8 * i;
+        *(bf16x4*)(Vh + k * LDMV + 4 * cq) = __builtin_convertvector(rv[i], bf16x4);
+      }
+      return;
+    }
     float* Us = smem + buf * (U_SZ + V_SZ);
     float* Vs = Us + U_SZ;
     if (pc < U_CH) {
@@ -638,6 +729,30 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
     store_tile(0);
   }
   __syncthreads();
+  if constexpr (BF) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      const __bf16* Uh = (const __bf16*)smem + buf * (UH_SZ + VH_SZ);
+      const __bf16* Vh = Uh + UH_SZ;
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) load_piece(kt + 1, pc, more);
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {
+        bf16x8 a[2], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt] = vf_tr_frag<LDMU>(Uh, wm + mt * 32, 16 * g, lane);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = vf_tr_frag<LDMV>(Vh, wn + nt * 32, 16 * g, lane);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
+      store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
   constexpr int NMF = 4 * 2 * NT;              // MFMAs per 8-wide sub-step
   constexpr int SLOTS = 2 * NMF;               // MFMA slots per K step (BK = 16)
   static_assert(2 * NPC <= SLOTS, "loads and LDS writes of one K step must fit between its MFMAs");
@@ -680,6 +795,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
     __syncthreads();
   }
 
+  }
   const int64_t total = (int64_t)p.Nu * Ncols;
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * total : p.dW;
 #pragma unroll
@@ -800,22 +916,29 @@ __global__ __launch_bounds__(256) void k_col2im4x4(const float* __restrict__ col
 // ================================================================================================ host
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-template <int BM, int BN, int WM, int WN>
-static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
+template <int BM, int BN, int WM, int WN, bool BF>
+static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
   dim3 block(256);
   if (!bkm) {
     if (v == 2)
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, BF>), grid, block, g);
     else
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 0>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 0, BF>), grid, block, g);
   } else {
     if (v == 2)
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 2>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 2, BF>), grid, block, g);
     else if (v == 1)
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 1>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 1, BF>), grid, block, g);
     else
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 0>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 0, BF>), grid, block, g);
   }
+}
+template <int BM, int BN, int WM, int WN>
+static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
+  if (ctx->mfma_bf16)
+    launch_igemm_tile_m<BM, BN, WM, WN, true>(ctx, g, grid, bkm, v, name, flops);
+  else
+    launch_igemm_tile_m<BM, BN, WM, WN, false>(ctx, g, grid, bkm, v, name, flops);
 }
 
 // vecA / vecB: 16-byte loads legal for the A / B operand
@@ -889,7 +1012,8 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     if (stamp_dump) VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   char pname[64];
-  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "");
+  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "",
+           ctx->mfma_bf16 ? "_bf16" : "");
   {
     const double fl = 2.0 * (double)g.M * g.N * Ktot * zpar;
     if (t.bm == 256)
@@ -1059,7 +1183,7 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.Nu = Nu; g.Cv = Cv; g.Hv = Hv; g.Wv = Wv;
   g.stride = stride; g.pad = pad;
   g.ntaps = ntaps;
-  g.nk = (int)vf_cdiv(g.P, 16);
+  g.nk = (int)vf_cdiv(g.P, ctx->mfma_bf16 ? 32 : 16);      // K steps of the kernel's BK
   VF_REQUIRE((int64_t)g.P * Nu < ((int64_t)1 << 29) && (int64_t)B * Hv * Wv * Cv < ((int64_t)1 << 29),
              "operand exceeds the 2 GiB buffer-descriptor range");
   g.u_bytes = (unsigned)((int64_t)g.P * Nu * 4);
@@ -1085,23 +1209,25 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.gx = gx; g.gy = gy; g.gz = ksplit;
   dim3 grid((unsigned)gx * gy * ksplit), block(256);
   {
-    const char* wname = BM == 128 ? "wgrad_128x128" : "wgrad_64x128";
+    const bool bf = ctx->mfma_bf16 != 0;
+    const char* wname = BM == 128 ? (bf ? "wgrad_128x128_bf16" : "wgrad_128x128") : (bf ? "wgrad_64x128_bf16" : "wgrad_64x128");
     const double wfl = 2.0 * (double)g.P * Nu * (double)ntaps * Cv;
-#define VF_WG(BM_)                                                                                  \
+#define VF_WG(BM_, BF_)                                                                              \
   do {                                                                                              \
     if (vecU && vecV)                                                                               \
-      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, true, true>), grid, block, g);            \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, true, true, BF_>), grid, block, g);       \
     else if (vecU)                                                                                  \
-      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, true, false>), grid, block, g);           \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, true, false, BF_>), grid, block, g);      \
     else if (vecV)                                                                                  \
-      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, false, true>), grid, block, g);           \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, false, true, BF_>), grid, block, g);      \
     else                                                                                            \
-      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, false, false>), grid, block, g);          \
+      VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, false, false, BF_>), grid, block, g);     \
   } while (0)
-    if (BM == 128)
-      VF_WG(128);
-    else
-      VF_WG(64);
+    if (BM == 128) {
+      if (bf) VF_WG(128, true); else VF_WG(128, false);
+    } else {
+      if (bf) VF_WG(64, true); else VF_WG(64, false);
+    }
 #undef VF_WG
   }
   VF_LAUNCH_CHECK();

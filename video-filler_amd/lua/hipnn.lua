@@ -24,6 +24,7 @@ typedef struct vf_ctx vf_ctx;
 const char* vf_last_error(void);
 int vf_ctx_create(vf_ctx** out, int device, void* stream);
 int vf_ctx_destroy(vf_ctx* ctx);
+int vf_ctx_set_mfma_mode(vf_ctx* ctx, int mode);
 int vf_ctx_set_workspace(vf_ctx* ctx, void* ptr, size_t bytes);
 size_t vf_workspace_bytes_hint(void);
 int vf_stream_synchronize(vf_ctx* ctx);
