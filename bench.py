@@ -45,8 +45,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control "
                     "flow with several ranks on ONE GPU (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--mfma", default="f32", choices=["f32", "bf16"], help="matrix-core operand precision; bf16 is an opt-in "
-                    "mode with its own tolerance (tests/test_gpu_bf16.py) — NOT the headline configuration")
+    ap.add_argument("--mfma", default="f32_3xbf16", choices=["f32_3xbf16", "f32", "bf16"],
+                    help="how conv products are formed: f32_3xbf16 (default; fp32 operands split exactly into 3 bf16 planes, 6 "
+                    "cross terms on the bf16 pipe, fp32 accumulate: fp32-grade), f32 (native f32 MFMA), bf16 (operands rounded: "
+                    "opt-in, its own tolerance, not a headline configuration)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no dW || dX, no netG-fwd || netD-real overlap)")
     args = ap.parse_args()
 
@@ -80,8 +82,8 @@ def main():
 
     B = get_backend()
     global PEAK_F32_MFMA_TFLOPS
-    if args.mfma != "f32":
-        B.set_mfma_mode(args.mfma)
+    B.set_mfma_mode(args.mfma)
+    if args.mfma == "bf16":
         PEAK_F32_MFMA_TFLOPS = PEAK_BF16_MFMA_TFLOPS      # the roofline of this run is the bf16 matrix pipe
     gen = torch.Generator().manual_seed(1234 + rank)
     if args.workload == "center":
@@ -279,9 +281,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.mfma == "f32" else "bf16 MFMA operands, f32 accumulate/BN/criteria/Adam (opt-in mode)",
+            "dtype": {"f32": "f32", "f32_3xbf16": "f32",
+                      "bf16": "bf16 MFMA operands, f32 accumulate/BN/criteria/Adam (opt-in mode)"}[args.mfma],
             "data": "synthetic",
             "config": {"workload": wl, "global_batch": world * args.batch, "launch": (("hipGraph x4 + bucketed RCCL all-reduce between; " + ("G buckets in flight during the encoder backward and the next iteration's netD real pass" if pipelined else "G tail bucket in flight during the encoder backward")) if dp else "hipGraph") if use_graph else "eager", "streams": 1 if args.no_overlap else 3,
+                       "mfma": {"f32_3xbf16": "fp32 operands split exactly into 3 bf16 planes, 6 cross terms on v_mfma_f32_32x32x16_bf16, "
+                                              "f32 accumulate (fp32-grade: same parity tolerances as native)",
+                                "f32": "native v_mfma_f32_32x32x2_f32", "bf16": "operands rounded to bf16"}[args.mfma],
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,
             "cpu_baseline": cpu,

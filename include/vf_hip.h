@@ -41,10 +41,15 @@ int vf_version(void);
 /* cutorch.setDevice(opt.gpu) (train.lua:249).  stream = hipStream_t or NULL for the null stream. */
 int vf_ctx_create(vf_ctx** out, int device, void* stream);
 int vf_ctx_destroy(vf_ctx* ctx);
-/* Matrix-core operand precision of the conv / full-conv passes of this context.  0 (default): fp32 operands,
- * v_mfma_f32_32x32x2_f32 — the reference's arithmetic.  1: operands rounded to bf16 (round-to-nearest-even) on their way
- * into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation; activations, weights, BatchNorm, criteria and Adam stay fp32 in
- * HBM.  Opt-in: results then carry bf16 operand rounding (~2^-9 relative; tests/test_gpu_bf16.py states the tolerance). */
+/* How the conv / full-conv passes of this context form their products (inputs, outputs and accumulators are fp32 in
+ * every mode; activations, weights, BatchNorm, criteria and Adam stay fp32 in HBM):
+ *   3 (default): fp32-grade on the bf16 matrix pipe — every fp32 operand element is split EXACTLY into three bf16 planes
+ *      (x = hi + mid + lo: 3 x 8 bits = the 24-bit significand) on its way into LDS and the six largest cross terms run
+ *      on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped terms are below 2^-24 of a product, i.e.
+ *      one fp32 rounding.  Passes the fp32 parity tolerances unchanged (tests/test_gpu_bf16.py and the whole -m gpu
+ *      suite); 1.1-1.4x faster than mode 0 because the bf16 pipe is 16x the f32 one.
+ *   0: native fp32 operands, v_mfma_f32_32x32x2_f32 (an fmaf chain, bit for bit).
+ *   1: operands ROUNDED to bf16 (round-to-nearest-even), one product term — opt-in, ~2^-9 relative operand rounding. */
 int vf_ctx_set_mfma_mode(vf_ctx* ctx, int mode);
 int vf_ctx_set_stream(vf_ctx* ctx, void* stream);
 /* scratch for split-K slabs and reduction partials; caller-owned, >= vf_workspace_bytes_hint(). */

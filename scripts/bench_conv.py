@@ -10,8 +10,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(os.environ.get("REPS", "5"))
 only = os.environ.get("ONLY", "")
 hb = get_backend()
-if os.environ.get("MFMA", "f32") != "f32":
-    hb.set_mfma_mode(os.environ["MFMA"])      # opt-in bf16-operand mode (not the default path)
+if os.environ.get("MFMA"):
+    hb.set_mfma_mode(os.environ["MFMA"])      # f32_3xbf16 (default) | f32 (native) | bf16 (opt-in)
 # (name, Cin, H, Cout, stride, pad, full)
 LAYERS = [("E1", 3, 128, 64, 2, 1, 0), ("E2", 64, 64, 64, 2, 1, 0), ("E3", 64, 32, 128, 2, 1, 0), ("E4", 128, 16, 256, 2, 1, 0),
           ("E5", 256, 8, 512, 2, 1, 0), ("E6", 512, 4, 4000, 1, 0, 0), ("D1", 4000, 1, 512, 1, 0, 1), ("D2", 512, 4, 256, 2, 1, 1),

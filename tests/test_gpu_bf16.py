@@ -1,4 +1,5 @@
-"""bf16-operand matrix-core mode (vf_ctx_set_mfma_mode(ctx, 1)): opt-in, never the default.
+"""The three matrix-core modes of vf_ctx_set_mfma_mode: 3 = fp32 operands as three exact bf16 planes (default, fp32-grade),
+0 = native f32 MFMA, 1 = bf16-rounded operands (opt-in, never the default).  First the opt-in mode:
 
 Stated tolerance: the operands of every conv / full-conv pass are rounded to bf16 (round-to-nearest-even) on their way
 into LDS; products and sums are fp32.  So (a) against the oracle fed the SAME bf16-rounded operands the result is
@@ -21,9 +22,10 @@ def bf16_round(a):
 
 @pytest.fixture()
 def bf16_backend(hipb):
+    prev = hipb.mfma_mode
     hipb.set_mfma_mode("bf16")
     yield hipb
-    hipb.set_mfma_mode("f32")
+    hipb.set_mfma_mode(prev)
 
 
 CASES = [  # (full, B, Cin, H, Cout, stride, pad)
@@ -96,16 +98,55 @@ def test_bf16_operand_mode(case, oracle, bf16_backend):
     assert_close(to_np(dgb), m_exact.gradBias, 2e-5, "bias gradient stays fp32 %s" % (case,))
 
 
-def test_mode_is_opt_in_and_per_context(hipb):
-    assert hipb.mfma_mode == "f32"
+def test_mode_is_per_context_and_validated(hipb):
+    from video_filler_amd import _lib
+    from video_filler_amd.backend import DEFAULT_MFMA_MODE
+    prev = hipb.mfma_mode
+    assert DEFAULT_MFMA_MODE == "f32_3xbf16"
     with pytest.raises(RuntimeError):
-        from video_filler_amd import _lib
         _lib.check(hipb.lib.vf_ctx_set_mfma_mode(hipb.ctx, 7))
     side = hipb.fork(workspace_bytes=8 << 20)
+    assert side.mfma_mode == prev
     hipb.set_mfma_mode("bf16")
     assert side.mfma_mode == "bf16"
+    hipb.set_mfma_mode(prev)
+    assert side.mfma_mode == prev and hipb.mfma_mode == prev
+
+
+@pytest.fixture()
+def native_backend(hipb):
+    prev = hipb.mfma_mode
     hipb.set_mfma_mode("f32")
-    assert side.mfma_mode == "f32" and hipb.mfma_mode == "f32"
+    yield hipb
+    hipb.set_mfma_mode(prev)
+
+
+@pytest.mark.parametrize("case", CASES[:7])
+def test_native_f32_mfma_mode_still_matches(case, oracle, native_backend):
+    """Mode 0 (v_mfma_f32_32x32x2_f32) stays available and correct at the same tolerance."""
+    hipb = native_backend
+    full, B, Cin, H, Cout, s, p = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    r = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    m = oracle.SpatialConvolution(Cin, Cout, 4, 4, s, s, p, p)
+    m.weight[...] = r(*m.weight.shape) * 0.05
+    m.bias[...] = r(Cout)
+    x = r(B, Cin, H, H)
+    y = np.array(m.forward(x), copy=True)
+    gy = r(*y.shape)
+    m.gradWeight[...] = 0
+    m.gradBias[...] = 0
+    m.backward(x, gy)
+    dx, dw, db, dgy = to_dev(x, hipb), to_dev(m.weight, hipb), to_dev(m.bias, hipb), to_dev(gy, hipb)
+    dy = hipb.empty_act(*y.shape)
+    hipb.conv2d_fwd(dx, dw, db, dy, 4, s, p)
+    assert_close(to_np(dy), y, 2e-5, "native fwd %s" % (case,))
+    dgx = hipb.empty_act(*x.shape)
+    hipb.conv2d_bwd_data(dgy, dw, dgx, 4, s, p)
+    assert_close(to_np(dgx), m.gradInput, 2e-5, "native bwd_data %s" % (case,))
+    dgw, dgb = to_dev(np.zeros_like(m.weight), hipb), hipb.zeros(Cout)
+    hipb.conv2d_bwd_weight(dx, dgy, dgw, dgb, 4, s, p, 0.0)
+    assert_close(to_np(dgw), m.gradWeight, 2e-5, "native bwd_weight %s" % (case,))
 
 
 def test_bf16_training_iteration_tracks_fp32(oracle, bf16_backend):
@@ -128,3 +169,66 @@ def test_bf16_training_iteration_tracks_fp32(oracle, bf16_backend):
         assert abs(got[k] - getattr(ref, k)) < 2e-2 * max(1.0, abs(getattr(ref, k))), (k, got[k], getattr(ref, k))
     gG = tr.netG.reference_flat(grads=True).cpu().numpy()
     assert np.abs(gG - ref.gradParametersG).max() < 5e-2 * np.abs(ref.gradParametersG).max()
+
+
+@pytest.fixture()
+def x3_backend(hipb):
+    prev = hipb.mfma_mode
+    hipb.set_mfma_mode("f32_3xbf16")
+    yield hipb
+    hipb.set_mfma_mode(prev)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_three_plane_split_is_fp32_grade(case, oracle, x3_backend):
+    """Mode 3: every fp32 operand is split EXACTLY into three bf16 planes (3 x 8 = 24 significand bits) and the six
+    largest cross terms are accumulated in fp32 on the bf16 matrix pipe.  Stated tolerance: the fp32 path's own
+    (2e-5 of the max-norm against the exact oracle) — no operand rounding is left."""
+    hipb = x3_backend
+    full, B, Cin, H, Cout, s, p = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    r = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    m = (oracle.SpatialFullConvolution if full else oracle.SpatialConvolution)(Cin, Cout, 4, 4, s, s, p, p)
+    m.weight[...] = r(*m.weight.shape) * 0.05
+    m.bias[...] = r(Cout)
+    x = r(B, Cin, H, H)
+    y = np.array(m.forward(x), copy=True)
+    gy = r(*y.shape)
+    m.gradWeight[...] = 0
+    m.gradBias[...] = 0
+    m.backward(x, gy)
+    fwd, bwd_d, bwd_w = ((hipb.deconv2d_fwd, hipb.deconv2d_bwd_data, hipb.deconv2d_bwd_weight) if full else
+                         (hipb.conv2d_fwd, hipb.conv2d_bwd_data, hipb.conv2d_bwd_weight))
+    dx, dw, db, dgy = to_dev(x, hipb), to_dev(m.weight, hipb), to_dev(m.bias, hipb), to_dev(gy, hipb)
+    dy = hipb.empty_act(*y.shape)
+    fwd(dx, dw, db, dy, 4, s, p)
+    assert_close(to_np(dy), y, 2e-5, "x3 fwd %s" % (case,))
+    dgx = hipb.empty_act(*x.shape)
+    bwd_d(dgy, dw, dgx, 4, s, p)
+    assert_close(to_np(dgx), m.gradInput, 2e-5, "x3 bwd_data %s" % (case,))
+    dgw, dgb = to_dev(np.zeros_like(m.weight), hipb), hipb.zeros(Cout)
+    bwd_w(dx, dgy, dgw, dgb, 4, s, p, 0.0)
+    assert_close(to_np(dgw), m.gradWeight, 2e-5, "x3 bwd_weight %s" % (case,))
+
+
+def test_three_plane_training_iteration_matches_fp32_tolerances(oracle, x3_backend):
+    """The whole train.lua iteration in mode 3 passes the fp32 path's end-to-end tolerances (smooth nets: losses 2e-5,
+    gradients 1e-4 of the max-norm)."""
+    import torch
+    from video_filler_amd.trainers import CenterTrainer
+    from test_gpu_trainers import _load
+    opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4, smooth=True)
+    ref = oracle.CenterTrainer(opt, np.random.default_rng(1))
+    tr = CenterTrainer(opt, seed=3)
+    _load(tr, ref)
+    batch = oracle.synth_center_batch(4, np.random.default_rng(9))
+    ref.set_batch(batch)
+    tr.set_batch(torch.from_numpy(batch))
+    ref.step()
+    tr.step()
+    got = tr.losses()
+    for k in ("errD", "errG", "errG_l2"):
+        assert abs(got[k] - getattr(ref, k)) < 2e-5 * max(1.0, abs(getattr(ref, k))), (k, got[k], getattr(ref, k))
+    for net, want in ((tr.netG, ref.gradParametersG), (tr.netD, ref.gradParametersD)):
+        g = net.reference_flat(grads=True).cpu().numpy()
+        assert np.abs(g - want).max() < 1e-4 * np.abs(want).max()

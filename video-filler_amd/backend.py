@@ -6,12 +6,15 @@ the same methods through `set_backend` to exercise host logic on CPU (tests/orac
 itself never constructs anything else and never falls back.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
 
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
+MFMA_MODES = {"f32": 0, "bf16": 1, "f32_3xbf16": 3}
+DEFAULT_MFMA_MODE = "f32_3xbf16"
 
 
 def _ptr(t):
@@ -48,12 +51,19 @@ class HipBackend:
         _lib.check(self.lib.vf_ctx_set_workspace(self.ctx, _ptr(self.workspace), nbytes))
         self.use_current_stream()
         self._forks = []
-        self.mfma_mode = "f32"
+        self.mfma_mode = DEFAULT_MFMA_MODE       # what vf_ctx_create starts in
+        mode = os.environ.get("VF_MFMA_MODE", DEFAULT_MFMA_MODE)
+        if mode != self.mfma_mode:
+            self.set_mfma_mode(mode)
 
     def set_mfma_mode(self, mode):
-        """'f32' (default: the reference's arithmetic) or 'bf16' (operands rounded to bf16 in LDS, fp32 accumulation —
-        opt-in, its own tolerance).  Applies to this backend and the side backends forked from it."""
-        code = {"f32": 0, "bf16": 1}[mode]
+        """How the conv / full-conv products are formed (vf_ctx_set_mfma_mode):
+          'f32_3xbf16' (default) fp32 operands split EXACTLY into three bf16 planes, six cross terms on the bf16 matrix
+                       pipe, fp32 accumulation — fp32-grade results (same tolerances as 'f32'), 1.1-1.4x faster;
+          'f32'        native v_mfma_f32_32x32x2_f32;
+          'bf16'       operands ROUNDED to bf16 (opt-in, 1e-2 tolerance).
+        Applies to this backend and the side backends forked from it."""
+        code = MFMA_MODES[mode]
         for b in [self] + list(self._forks):
             _lib.check(self.lib.vf_ctx_set_mfma_mode(b.ctx, code))
             b.mfma_mode = mode
@@ -80,7 +90,7 @@ class HipBackend:
         side.parent = self
         side._forks = []
         side.mfma_mode = self.mfma_mode
-        _lib.check(self.lib.vf_ctx_set_mfma_mode(side.ctx, {"f32": 0, "bf16": 1}[self.mfma_mode]))
+        _lib.check(self.lib.vf_ctx_set_mfma_mode(side.ctx, MFMA_MODES[self.mfma_mode]))
         self._forks.append(side)
         return side
 

@@ -99,11 +99,14 @@ struct IGemm {
 
 // V = 2: 16-byte loads for A and B (C % 16 == 0);  V = 1: 16-byte A, scalar B (k-major B with N % 4 != 0);
 // V = 0: scalar loads with a flattened (tap, c) K index (first/last layers: C = 3, 12, 27 ...).
-// BF = true: bf16-operand mode (opt-in, vf_ctx_set_mfma_mode): the fp32 pieces are rounded to bf16 (RNE) on their way
-// into LDS, both operands sit there row-major [row][k] (80-byte rows: conflict-free ds_read_b128), and the products run
-// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Everything outside the LDS tile (addresses, loads, epilogue,
-// split-K) is shared with the fp32 path.
-template <int BM, int BN, int WM, int WN, bool BKM, int V, bool BF = false>
+// BF = 1: bf16-operand mode (opt-in, vf_ctx_set_mfma_mode): the fp32 pieces are rounded to bf16 (RNE) on their way
+// into LDS (row-major [row][k], 80-byte rows: conflict-free ds_read_b128; k-major operands: vf_tr_frag) and the
+// products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// BF = 3: fp32-grade products on the bf16 pipe: every operand element is split EXACTLY into three bf16 planes
+// (x = hi + mid + lo: 3 x 8 = the 24 significand bits of an fp32) and the six largest cross terms are accumulated —
+// what is dropped (mid*lo, lo*mid, lo*lo) is below 2^-24 of the product, the size of one fp32 rounding.
+// Everything outside the LDS tile (addresses, loads, epilogue, split-K) is shared with the fp32 path.
+template <int BM, int BN, int WM, int WN, bool BKM, int V, int BF = 0>
 __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   // One K step = 32 = two 16-wide chunks; each chunk has its own (tap, c0), so any C % 16 == 0 vectorises.
   constexpr int BK = 32, LDA = BK + 4;
@@ -118,7 +121,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   constexpr int LDH = BK + 8;                          // bf16 elements per LDS row (BF)
   constexpr int LDN = BN + 32;                         // k-major bf16 B tile (BF && BKM): [k][LDN], transposing reads
   constexpr int AH_SZ = BM * LDH, BH_SZ = BKM ? BK * LDN : BN * LDH;    // bf16 elements per buffer (BF)
-  constexpr int SMEM_F = BF ? (2 * (AH_SZ + BH_SZ) + 1) / 2 : 2 * (A_SZ + B_SZ);
+  constexpr int NP = BF > 0 ? BF : 1;                  // bf16 planes per operand
+  constexpr int NBUF = BF == 3 ? 1 : 2;                // three planes: single-buffered LDS (capacity), loads still run ahead
+  constexpr int PL_SZ = AH_SZ + BH_SZ;                 // one plane of (A, B), bf16 elements
+  constexpr int SMEM_F = BF ? (NBUF * NP * PL_SZ + 1) / 2 : 2 * (A_SZ + B_SZ);
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,19 +348,35 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 
   auto store_piece = [&](int buf, int pc) {
     if constexpr (BF) {
-      __bf16* Ah = (__bf16*)smem + buf * (AH_SZ + BH_SZ);
-      __bf16* Bh = Ah + AH_SZ;
+      // plane 0 = bf16(v); plane q+1 = bf16(v - what the planes before it hold): the subtraction is exact in fp32
+      __bf16* base = (__bf16*)smem + buf * (NP * PL_SZ);
       if (pc < A_CH) {
         const int i = pc, id = tid + 256 * i;
-        if (256 * i + 255 < BM * 8 || id < BM * 8) *(bf16x4*)(Ah + (id >> 3) * LDH + 4 * kq) = __builtin_convertvector(ra[i], bf16x4);
+        if (256 * i + 255 < BM * 8 || id < BM * 8) {
+          f32x4 v = ra[i];
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            const bf16x4 h = __builtin_convertvector(v, bf16x4);
+            *(bf16x4*)(base + q * PL_SZ + (id >> 3) * LDH + 4 * kq) = h;
+            if (q + 1 < NP) v -= __builtin_convertvector(h, f32x4);
+          }
+        }
       } else {
         const int i = pc - A_CH, id = tid + 256 * i;
         if (256 * i + 255 < BN * 8 || id < BN * 8) {
+          f32x4 v = rb[i];
+          int off;
           if constexpr (!BKM) {
-            *(bf16x4*)(Bh + (id >> 3) * LDH + 4 * kq) = __builtin_convertvector(rb[i], bf16x4);
+            off = (id >> 3) * LDH + 4 * kq;
           } else {      // the piece holds 4 consecutive n at one k: stored as it comes, transposed by the reads
             const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
-            *(bf16x4*)(Bh + kk * LDN + 4 * nq) = __builtin_convertvector(rb[i], bf16x4);
+            off = kk * LDN + 4 * nq;
+          }
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            const bf16x4 h = __builtin_convertvector(v, bf16x4);
+            *(bf16x4*)(base + q * PL_SZ + AH_SZ + off) = h;
+            if (q + 1 < NP) v -= __builtin_convertvector(h, f32x4);
           }
         }
       }
@@ -400,30 +422,44 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   if (p.stamps && tid == 0) p.stamps[8 * blockIdx.x + 1] = wall_clock64();
   if constexpr (BF) {
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int buf = (kt - kt0) & 1;
-      const __bf16* Ah = (const __bf16*)smem + buf * (AH_SZ + BH_SZ);
-      const __bf16* Bh = Ah + AH_SZ;
+      const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
+      const __bf16* base = (const __bf16*)smem + buf * (NP * PL_SZ);
       begin_tile(kt + 1, kt + 1 < kt1);
 #pragma unroll
       for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc);
 #pragma unroll
       for (int g = 0; g < BK / 16; ++g) {
-        bf16x8 a[MT], b[NT];
+        bf16x8 a[NP][MT], b[NP][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const bf16x8*)(Ah + (wm + mt * 32 + lr) * LDH + 16 * g + 8 * lh);
+        for (int q = 0; q < NP; ++q) {
+          const __bf16* Ah = base + q * PL_SZ;
+          const __bf16* Bh = Ah + AH_SZ;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          if constexpr (!BKM)
-            b[nt] = *(const bf16x8*)(Bh + (wn + nt * 32 + lr) * LDH + 16 * g + 8 * lh);
-          else
-            b[nt] = vf_tr_frag<LDN>(Bh, wn + nt * 32, 16 * g, lane);
+          for (int mt = 0; mt < MT; ++mt) a[q][mt] = *(const bf16x8*)(Ah + (wm + mt * 32 + lr) * LDH + 16 * g + 8 * lh);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (!BKM)
+              b[q][nt] = *(const bf16x8*)(Bh + (wn + nt * 32 + lr) * LDH + 16 * g + 8 * lh);
+            else
+              b[q][nt] = vf_tr_frag<LDN>(Bh, wn + nt * 32, 16 * g, lane);
+          }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (NP == 3) {      // smallest terms first
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mt], b[1][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[2][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[1][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+            }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+          }
       }
-      store_tile(buf ^ 1);
+      if constexpr (NBUF == 1) __syncthreads();       // everyone has read the tile before it is overwritten
+      store_tile(NBUF == 2 ? (buf ^ 1) : 0);
       __syncthreads();
     }
   } else {
@@ -601,7 +637,7 @@ struct WGrad {
 // BM over n (64 or 128); BN = 128 columns (tap,c).  VU / VV: 16-byte loads legal for U / V.
 // BF: bf16-operand mode — U and V go into LDS as k-major bf16 tiles (one 8-byte store per piece), the fragments come
 // out through the transposing read (vf_tr_frag) and the products run on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
-template <int BM, bool VU, bool VV, bool BF = false>
+template <int BM, bool VU, bool VV, int BF = 0>
 __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   constexpr int BN = 128, BK = BF ? 32 : 16;      // bf16 mode: two 16-deep MFMA groups per barrier
   constexpr int LDU = BM + 4, LDV = BN + 4;
@@ -613,7 +649,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   constexpr int U_SZ = BK * LDU, V_SZ = BK * LDV;
   constexpr int LDMU = BM + 32, LDMV = BN + 32;        // bf16 elements per k row (BF): k-major tiles, transposing reads
   constexpr int UH_SZ = BK * LDMU, VH_SZ = BK * LDMV;
-  constexpr int SMEM_F = BF ? (2 * (UH_SZ + VH_SZ) + 1) / 2 : 2 * (U_SZ + V_SZ);
+  constexpr int NP = BF > 0 ? BF : 1;                  // bf16 planes per operand (3: exact split of the fp32 operands)
+  constexpr int NBUF = BF == 3 ? 1 : 2;
+  constexpr int PL_SZ = UH_SZ + VH_SZ;
+  constexpr int SMEM_F = BF ? (NBUF * NP * PL_SZ + 1) / 2 : 2 * (U_SZ + V_SZ);
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -685,14 +724,22 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   };
   auto store_piece = [&](int buf, int pc) {
     if constexpr (BF) {
-      __bf16* Uh = (__bf16*)smem + buf * (UH_SZ + VH_SZ);
-      __bf16* Vh = Uh + UH_SZ;
+      __bf16* base = (__bf16*)smem + buf * (NP * PL_SZ);
+      f32x4 v;
+      int off;
       if (pc < U_CH) {
-        const int k = ukk + pc * (1024 / BM);
-        *(bf16x4*)(Uh + k * LDMU + 4 * uq) = __builtin_convertvector(ru[pc], bf16x4);
+        v = ru[pc];
+        off = (ukk + pc * (1024 / BM)) * LDMU + 4 * uq;
       } else {
-        const int i = pc - U_CH, k = (tid >> 5) + 8 * i;
-        *(bf16x4*)(Vh + k * LDMV + 4 * cq) = __builtin_convertvector(rv[i], bf16x4);
+        const int i = pc - U_CH;
+        v = rv[i];
+        off = UH_SZ + ((tid >> 5) + 8 * i) * LDMV + 4 * cq;
+      }
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+        *(bf16x4*)(base + q * PL_SZ + off) = h;
+        if (q + 1 < NP) v -= __builtin_convertvector(h, f32x4);
       }
       return;
     }
@@ -731,25 +778,39 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
   __syncthreads();
   if constexpr (BF) {
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int buf = (kt - kt0) & 1;
+      const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
       const bool more = kt + 1 < kt1;
-      const __bf16* Uh = (const __bf16*)smem + buf * (UH_SZ + VH_SZ);
-      const __bf16* Vh = Uh + UH_SZ;
+      const __bf16* base = (const __bf16*)smem + buf * (NP * PL_SZ);
 #pragma unroll
       for (int pc = 0; pc < NPC; ++pc) load_piece(kt + 1, pc, more);
 #pragma unroll
       for (int g = 0; g < BK / 16; ++g) {
-        bf16x8 a[2], b[NT];
+        bf16x8 a[NP][2], b[NP][NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) a[mt] = vf_tr_frag<LDMU>(Uh, wm + mt * 32, 16 * g, lane);
+        for (int q = 0; q < NP; ++q) {
+          const __bf16* Uh = base + q * PL_SZ;
+          const __bf16* Vh = Uh + UH_SZ;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = vf_tr_frag<LDMV>(Vh, wn + nt * 32, 16 * g, lane);
+          for (int mt = 0; mt < 2; ++mt) a[q][mt] = vf_tr_frag<LDMU>(Uh, wm + mt * 32, 16 * g, lane);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b[q][nt] = vf_tr_frag<LDMV>(Vh, wn + nt * 32, 16 * g, lane);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (NP == 3) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mt], b[1][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[2][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[1][nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+            }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
+          }
       }
-      store_tile(buf ^ 1);
+      if constexpr (NBUF == 1) __syncthreads();
+      store_tile(NBUF == 2 ? (buf ^ 1) : 0);
       __syncthreads();
     }
   } else {
@@ -916,7 +977,7 @@ __global__ __launch_bounds__(256) void k_col2im4x4(const float* __restrict__ col
 // ================================================================================================ host
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-template <int BM, int BN, int WM, int WN, bool BF>
+template <int BM, int BN, int WM, int WN, int BF>
 static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
   dim3 block(256);
   if (!bkm) {
@@ -935,10 +996,12 @@ static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm
 }
 template <int BM, int BN, int WM, int WN>
 static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
-  if (ctx->mfma_bf16)
-    launch_igemm_tile_m<BM, BN, WM, WN, true>(ctx, g, grid, bkm, v, name, flops);
+  if (ctx->mfma_bf16 == 3)
+    launch_igemm_tile_m<BM, BN, WM, WN, 3>(ctx, g, grid, bkm, v, name, flops);
+  else if (ctx->mfma_bf16 == 1)
+    launch_igemm_tile_m<BM, BN, WM, WN, 1>(ctx, g, grid, bkm, v, name, flops);
   else
-    launch_igemm_tile_m<BM, BN, WM, WN, false>(ctx, g, grid, bkm, v, name, flops);
+    launch_igemm_tile_m<BM, BN, WM, WN, 0>(ctx, g, grid, bkm, v, name, flops);
 }
 
 // vecA / vecB: 16-byte loads legal for the A / B operand
@@ -1013,7 +1076,7 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   }
   char pname[64];
   snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "",
-           ctx->mfma_bf16 ? "_bf16" : "");
+           ctx->mfma_bf16 == 3 ? "_bf16x3" : (ctx->mfma_bf16 ? "_bf16" : ""));
   {
     const double fl = 2.0 * (double)g.M * g.N * Ktot * zpar;
     if (t.bm == 256)
@@ -1209,8 +1272,9 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.gx = gx; g.gy = gy; g.gz = ksplit;
   dim3 grid((unsigned)gx * gy * ksplit), block(256);
   {
-    const bool bf = ctx->mfma_bf16 != 0;
-    const char* wname = BM == 128 ? (bf ? "wgrad_128x128_bf16" : "wgrad_128x128") : (bf ? "wgrad_64x128_bf16" : "wgrad_64x128");
+    const int bf = ctx->mfma_bf16;
+    const char* wname = BM == 128 ? (bf == 3 ? "wgrad_128x128_bf16x3" : bf ? "wgrad_128x128_bf16" : "wgrad_128x128")
+                                  : (bf == 3 ? "wgrad_64x128_bf16x3" : bf ? "wgrad_64x128_bf16" : "wgrad_64x128");
     const double wfl = 2.0 * (double)g.P * Nu * (double)ntaps * Cv;
 #define VF_WG(BM_, BF_)                                                                              \
   do {                                                                                              \
@@ -1224,9 +1288,9 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
       VF_LAUNCH_TIMED(ctx, wname, wfl, 0.0, (k_wgrad<BM_, false, false, BF_>), grid, block, g);     \
   } while (0)
     if (BM == 128) {
-      if (bf) VF_WG(128, true); else VF_WG(128, false);
+      if (bf == 3) VF_WG(128, 3); else if (bf) VF_WG(128, 1); else VF_WG(128, 0);
     } else {
-      if (bf) VF_WG(64, true); else VF_WG(64, false);
+      if (bf == 3) VF_WG(64, 3); else if (bf) VF_WG(64, 1); else VF_WG(64, 0);
     }
 #undef VF_WG
   }

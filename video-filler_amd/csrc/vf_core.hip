@@ -33,7 +33,7 @@ VF_API int vf_ctx_create(vf_ctx** out, int device, void* stream) {
   c->ws = nullptr;
   c->ws_bytes = 0;
   c->ws_front = 0;
-  c->mfma_bf16 = 0;
+  c->mfma_bf16 = 3;      // fp32 operands as three exact bf16 planes (see vf_ctx_set_mfma_mode)
   *out = c;
   return 0;
 }
@@ -42,7 +42,8 @@ VF_API int vf_ctx_destroy(vf_ctx* ctx) {
   return 0;
 }
 VF_API int vf_ctx_set_mfma_mode(vf_ctx* ctx, int mode) {
-  VF_REQUIRE(mode == 0 || mode == 1, "vf_ctx_set_mfma_mode: 0 = fp32 operands, 1 = bf16 operands (got %d)", mode);
+  VF_REQUIRE(mode == 0 || mode == 1 || mode == 3,
+             "vf_ctx_set_mfma_mode: 0 = fp32 operands, 1 = bf16 operands, 3 = fp32 operands as three bf16 planes (got %d)", mode);
   ctx->mfma_bf16 = mode;
   return 0;
 }
