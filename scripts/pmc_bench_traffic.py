@@ -9,12 +9,14 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 # rocprof kernel name -> the name bench.py's kernel table uses
 def bench_name(k):
-    m = re.match(r"void k_wgrad<(\d+), \w+, \w+>", k)
+    suf = {"0": "", "1": "_bf16", "3": "_bf16x3"}
+    m = re.match(r"void k_wgrad<(\d+), \w+, \w+(?:, (\d))?>", k)
     if m:
-        return "wgrad_%sx128" % m.group(1)
-    m = re.match(r"void k_igemm<(\d+), (\d+), \d+, \d+, (\w+), (\d)>", k)
+        return "wgrad_%sx128%s" % (m.group(1), suf.get(m.group(2) or "0", ""))
+    m = re.match(r"void k_igemm<(\d+), (\d+), \d+, \d+, (\w+), (\d)(?:, (\d))?>", k)
     if m:
-        return "igemm_%sx%s_%s_v%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4))
+        return "igemm_%sx%s_%s_v%s%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4),
+                                        suf.get(m.group(5) or "0", ""))
     m = re.match(r"(?:void )?(k_[a-z0-9_]+)", k)
     return m.group(1) if m else k
 
