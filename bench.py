@@ -4,7 +4,8 @@
 Workload (BASELINE.json configs[1]): train.lua nets with the README `inpaintCenter` recipe
 (nBottleneck=4000, wtl2=0.999, overlapPred=4, fineSize=128), batchSize=64 per GPU, synthetic U[-1,1] images
 resident in HBM.  A step = fDx + Adam(D) + fGx + Adam(G) (train.lua:421-424): netG 1 fwd + 1 bwd, netD 2 fwd +
-2 bwd + 1 data-grad pass, BCE/MSE criteria, two fused Adam passes.  Arithmetic is fp32 end to end (f32 MFMA).
+2 bwd + 1 data-grad pass, BCE/MSE criteria, two fused Adam passes.  Tensors and accumulators are fp32; conv products come from an exact
+3-plane bf16 split of the fp32 operands on the bf16 matrix pipe by default (--mfma f32 = native f32 MFMA).
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
