@@ -255,6 +255,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   unsigned t_dA = 0;
   bool t_okq = false;
   int t_kt = 0;
+  int s_dy[4], s_dx[4], s_c[4], s_w[4];     // scalar path (V = 0): per-step decomposition of this thread's k
+  bool s_kok[4];
   auto begin_tile = [&](int kt, bool live) {
     t_kt = kt;
     if constexpr (V >= 1) {
@@ -267,6 +269,20 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
       t_okq = kh ? tc1.ok : tc0.ok;
     } else {
       t_okq = live;
+      // scalar path: the (tap, c) decomposition of this thread's four k depends on the step only, not on the row —
+      // done once here instead of once per row and element (a runtime division each; the 3-channel first layer
+      // spent most of its time on them)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = kt * BK + 4 * kq + j;
+        const int tap = k / p.C, c = k - tap * p.C;
+        const int th = tap / p.TW, tw = tap - th * p.TW;
+        s_dy[j] = th * p.ty;
+        s_dx[j] = tw * p.tx;
+        s_c[j] = c;
+        s_kok[j] = live && k < Ktot;
+        s_w[j] = tap_index(tap) * p.wsTap + c * p.wsC;
+      }
     }
   };
   auto load_piece = [&](int pc) {
@@ -305,12 +321,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int k = kt * BK + 4 * kq + j;
-          const int tap = k / p.C, c = k - tap * p.C;
-          const int th = tap / p.TW, tw = tap - th * p.TW;
-          const int iy = a_iy0[i] + th * p.ty, ix = a_ix0[i] + tw * p.tx;
-          const bool ok = t_okq && a_ok[i] && k < Ktot && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-          v[j] = vf_bload1(rsA, ok ? 4u * (unsigned)(a_boff[i] + (iy * p.Wi + ix) * p.C + c) : VF_OOB);
+          const int iy = a_iy0[i] + s_dy[j], ix = a_ix0[i] + s_dx[j];
+          const bool ok = s_kok[j] && a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+          v[j] = vf_bload1(rsA, ok ? 4u * (unsigned)(a_boff[i] + (iy * p.Wi + ix) * p.C + s_c[j]) : VF_OOB);
         }
         ra[i] = v;
       } else {
@@ -321,11 +334,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           const int n = n0 + (id >> 3);
           const bool okn = t_okq && id < BN * 8 && n < p.N;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int k = kt * BK + 4 * kq + j;
-            const int tap = k / p.C, c = k - tap * p.C;
-            v[j] = vf_bload1(rsW, (okn && k < Ktot) ? 4u * (unsigned)(n * p.wsN + tap_index(tap) * p.wsTap + c * p.wsC) : VF_OOB);
-          }
+          for (int j = 0; j < 4; ++j)
+            v[j] = vf_bload1(rsW, (okn && s_kok[j]) ? 4u * (unsigned)(n * p.wsN + s_w[j]) : VF_OOB);
         } else {
           const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
           const int n = n0 + 4 * nq;
