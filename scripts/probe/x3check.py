@@ -6,7 +6,7 @@ import video_filler_amd
 from video_filler_amd.backend import get_backend
 from helpers import to_dev, to_np, rel_err
 hb = get_backend()
-for mode in ("f32", "bf16x3", "bf16"):
+for mode in ("f32", "f32_3xbf16", "bf16"):
     hb.set_mfma_mode(mode)
     errs = []
     for (full, B, Cin, H, Cout, s, p) in [(False, 4, 64, 16, 64, 2, 1), (False, 2, 128, 4, 100, 1, 0), (True, 2, 128, 4, 64, 2, 1), (False, 8, 256, 8, 512, 2, 1), (True, 4, 512, 4, 256, 2, 1)]:

@@ -58,6 +58,30 @@ __device__ __forceinline__ bf16x8 vf_tr_frag(const __bf16* tile, int col0, int k
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// Exact three-way split of four fp32 values into bf16 planes by TRUNCATION (mode 3): plane q holds the top 16 bits of the
+// running residual, the residual loses exactly those bits (v - float(top16(v)) is exact), and after two steps at most 8
+// significant bits are left, so hi + mid + lo == v bit for bit.  No conversion instruction is needed: a v_perm_b32
+// packs the top halves of two residuals into one bf16x2 word (6 perms + 8 ands + 8 subs per four elements; the
+// round-to-nearest form through v_cvt_pk_bf16_f32 cost 30).
+struct VfPlanes3 { uint2 p[3]; };
+__device__ __forceinline__ VfPlanes3 vf_split3(f32x4 v) {
+  VfPlanes3 o;
+  float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1), u2 = __float_as_uint(r2), u3 = __float_as_uint(r3);
+    o.p[q].x = __builtin_amdgcn_perm(u1, u0, 0x07060302u);      // (u1 & 0xffff0000) | (u0 >> 16)
+    o.p[q].y = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+    if (q < 2) {
+      r0 -= __uint_as_float(u0 & 0xffff0000u);
+      r1 -= __uint_as_float(u1 & 0xffff0000u);
+      r2 -= __uint_as_float(u2 & 0xffff0000u);
+      r3 -= __uint_as_float(u3 & 0xffff0000u);
+    }
+  }
+  return o;
+}
+
 // XCD-aware block order.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its
 // own 4 MiB L2), so neighbouring tiles — which share input halos (k_igemm) or the whole gathered operand (k_wgrad's
 // column tiles) — land on different L2s and every one of them fetches the shared rows from the fabric again
@@ -358,17 +382,18 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 
   auto store_piece = [&](int buf, int pc) {
     if constexpr (BF) {
-      // plane 0 = bf16(v); plane q+1 = bf16(v - what the planes before it hold): the subtraction is exact in fp32
+      // mode 3: plane q = top 16 bits of the residual after the planes before it (vf_split3); mode 1: bf16(v), RNE
       __bf16* base = (__bf16*)smem + buf * (NP * PL_SZ);
       if (pc < A_CH) {
         const int i = pc, id = tid + 256 * i;
         if (256 * i + 255 < BM * 8 || id < BM * 8) {
-          f32x4 v = ra[i];
+          __bf16* dst = base + (id >> 3) * LDH + 4 * kq;
+          if constexpr (NP == 3) {
+            const VfPlanes3 s3 = vf_split3(ra[i]);
 #pragma unroll
-          for (int q = 0; q < NP; ++q) {
-            const bf16x4 h = __builtin_convertvector(v, bf16x4);
-            *(bf16x4*)(base + q * PL_SZ + (id >> 3) * LDH + 4 * kq) = h;
-            if (q + 1 < NP) v -= __builtin_convertvector(h, f32x4);
+            for (int q = 0; q < 3; ++q) *(uint2*)(dst + q * PL_SZ) = s3.p[q];
+          } else {
+            *(bf16x4*)dst = __builtin_convertvector(ra[i], bf16x4);
           }
         }
       } else {
@@ -382,11 +407,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
             const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
             off = kk * LDN + 4 * nq;
           }
+          __bf16* dst = base + AH_SZ + off;
+          if constexpr (NP == 3) {
+            const VfPlanes3 s3 = vf_split3(v);
 #pragma unroll
-          for (int q = 0; q < NP; ++q) {
-            const bf16x4 h = __builtin_convertvector(v, bf16x4);
-            *(bf16x4*)(base + q * PL_SZ + AH_SZ + off) = h;
-            if (q + 1 < NP) v -= __builtin_convertvector(h, f32x4);
+            for (int q = 0; q < 3; ++q) *(uint2*)(dst + q * PL_SZ) = s3.p[q];
+          } else {
+            *(bf16x4*)dst = __builtin_convertvector(v, bf16x4);
           }
         }
       }
@@ -745,11 +772,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
         v = rv[i];
         off = UH_SZ + ((tid >> 5) + 8 * i) * LDMV + 4 * cq;
       }
+      if constexpr (NP == 3) {
+        const VfPlanes3 s3 = vf_split3(v);
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const bf16x4 h = __builtin_convertvector(v, bf16x4);
-        *(bf16x4*)(base + q * PL_SZ + off) = h;
-        if (q + 1 < NP) v -= __builtin_convertvector(h, f32x4);
+        for (int q = 0; q < 3; ++q) *(uint2*)(base + q * PL_SZ + off) = s3.p[q];
+      } else {
+        *(bf16x4*)(base + off) = __builtin_convertvector(v, bf16x4);
       }
       return;
     }
