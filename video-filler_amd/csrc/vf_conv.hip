@@ -1064,7 +1064,10 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     t = {64, 128};
   } else {
     const Tile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
-    static const int tune_min_blocks = getenv("VF_TILE_MIN_BLOCKS") ? atoi(getenv("VF_TILE_MIN_BLOCKS")) : 512;
+    // mode 3's single-buffered three-plane tiles hide their two barriers per K step with co-resident blocks: they want
+    // twice the blocks (measured: +2 % per step at 1024 and above)
+    static const int env_min_blocks = getenv("VF_TILE_MIN_BLOCKS") ? atoi(getenv("VF_TILE_MIN_BLOCKS")) : 0;
+    const int tune_min_blocks = env_min_blocks ? env_min_blocks : (ctx->mfma_bf16 == 3 ? 1024 : 512);
     int pick = 2;
     for (int i = 0; i < 3; ++i) {
       if (cand[i].bn > 64 && g.N <= 64) continue;
