@@ -192,6 +192,16 @@ int vf_tiles_gather(vf_ctx* ctx, const float* full, float* tiles, int groups, in
 int vf_tiles_scatter(vf_ctx* ctx, const float* tiles, float* out, int groups, int nc, int H, int W, int fs,
                      const unsigned char* vflip);
 
+/* ---- every conv bias gradient of one backward walk in two launches ----------------------------------------------
+ * gradBias = sum over pixels of gradOutput (THNN accGradParameters) is not needed before optim.adam, and each layer's
+ * gradOutput stays in its module's buffer until the walk ends, so the column sums of all layers run as ONE stage-1 and
+ * ONE stage-2 launch.  desc_dev: DEVICE array of n 64-byte descriptors
+ *   { const float* g; float* gb; double* part; int64 P; int32 C, cq, rows_per_block, gx, gy, blk1_off, blk2_off; float beta }
+ * (g: [P][C] gradOutput, C % 4 == 0, 16-byte aligned; part: gx*C doubles of scratch; geometry from vf_bias_grad_plan;
+ * blk1_off / blk2_off: running sums of gx*gy / ceil(C/4) over the layers).  gb = beta*gb + column sums. */
+int vf_bias_grad_plan(int64_t P, int C, int* cq, int* rows_per_block, int* gx, int* gy);
+int vf_bias_grad_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks1, int blocks2);
+
 /* ---- per-kernel timers (the reference has three torch.Timers, train.lua:241-243; these are finer) ----
  * Between vf_prof_begin and vf_prof_end every kernel launch of the library is bracketed by HIP events on the
  * context's stream.  vf_prof_end synchronises and aggregates per kernel name; vf_prof_get reads entry i:

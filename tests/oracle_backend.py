@@ -108,6 +108,10 @@ class OracleBackend:
         m = self._conv_mod(O.SpatialFullConvolution if full else O.SpatialConvolution, w, k, stride, pad, full)
         _put(gx, m.updateGradInput(np.empty(tuple(gx.shape), np.float32), _np(gy)))
 
+    def bias_grad_multi(self, items):
+        for g, gb, beta in items:
+            _put(gb, np.float32(beta) * _np(gb) + _np(g).sum(axis=(0, 2, 3), dtype=np.float64).astype(np.float32))
+
     def conv2d_bwd_data_act(self, gy, w, gx, x_act, act, slope, k, stride, pad):
         self.conv2d_bwd_data(gy, w, gx, k, stride, pad)
         _put(gx, _act_grad(_np(x_act), _np(gx), act, slope))

@@ -13,6 +13,9 @@ import torch
 from . import _lib
 
 ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
+# struct VfColsumDesc of csrc/vf_bn.hip (64 bytes)
+COLSUM_DESC = [("g", "<u8"), ("gb", "<u8"), ("part", "<u8"), ("P", "<i8"), ("C", "<i4"), ("cq", "<i4"), ("rows_per_block", "<i4"),
+               ("gx", "<i4"), ("gy", "<i4"), ("blk1_off", "<i4"), ("blk2_off", "<i4"), ("beta", "<f4")]
 MFMA_MODES = {"f32": 0, "bf16": 1, "f32_3xbf16": 3}
 DEFAULT_MFMA_MODE = "f32_3xbf16"
 
@@ -148,6 +151,38 @@ class HipBackend:
         B, Cin, H, W = gx.shape
         self._c("vf_conv2d_bwd_data_act", _ptr(gy), _ptr(w), _ptr(gx), _ptr(x_act), ACT[act], slope, B, H, W, Cin,
                 w.shape[0], k, stride, pad)
+
+    # ---- all conv bias gradients of one backward walk in two launches (vf_bias_grad_multi)
+    def bias_grad_multi(self, items):
+        """items: [(gradOutput B x C x H x W channels-last, gradBias [C], beta)], C % 4 == 0.  The descriptor table is built
+        once per combination of buffers and betas and kept on the device (the same walk recurs every iteration)."""
+        import numpy as np
+        if not items:
+            return
+        key = tuple((g.data_ptr(), gb.data_ptr(), g.numel(), gb.numel(), float(beta)) for g, gb, beta in items)
+        cache = self.__dict__.setdefault("_colsum_plans", {})
+        plan = cache.get(key)
+        if plan is None:
+            desc = np.zeros(len(items), dtype=COLSUM_DESC)
+            ws = self.workspace.data_ptr()
+            off, b1, b2 = 0, 0, 0
+            for i, (g, gb, beta) in enumerate(items):
+                Cc = gb.numel()
+                P = g.numel() // Cc
+                assert Cc % 4 == 0 and g.data_ptr() % 16 == 0 and is_nhwc(g)
+                geo = [C.c_int() for _ in range(4)]
+                _lib.check(self.lib.vf_bias_grad_plan(P, Cc, *[C.byref(v) for v in geo]))
+                cq, rpb, gx, gy = [v.value for v in geo]
+                desc[i] = (g.data_ptr(), gb.data_ptr(), ws + off, P, Cc, cq, rpb, gx, gy, b1, b2, beta)
+                off += (gx * Cc * 8 + 255) // 256 * 256
+                b1 += gx * gy
+                b2 += (Cc + 3) // 4
+            assert off <= self.workspace.numel(), "workspace too small for the bias-gradient partials"
+            dev = torch.from_numpy(desc.view(np.uint8).copy()).to(self.device)
+            plan = (dev, len(items), b1, b2)
+            cache[key] = plan
+        dev, n, b1, b2 = plan
+        self._c("vf_bias_grad_multi", _ptr(dev), n, b1, b2)
 
     def conv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta):
         B, Cin, H, W = x.shape

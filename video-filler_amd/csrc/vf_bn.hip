@@ -344,6 +344,72 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// ---- every conv bias gradient of one backward walk in TWO launches (instead of two per layer): the column sums are
+// not needed before Adam, and each layer's gradOutput lives in its module's own buffer until the walk is over.  The
+// host builds the descriptor table once per (buffers, betas) combination and keeps it on the device.
+struct VfColsumDesc {      // mirrored by video-filler_amd/backend.py (COLSUM_DESC); 64 bytes
+  const float* g;          // [P][C] gradOutput
+  float* gb;               // [C]   gradBias:  gb = beta*gb + column sums
+  double* part;            // [gx][C] scratch partials
+  int64_t P;
+  int C, cq, rows_per_block, gx, gy;
+  int blk1_off, blk2_off;  // first block of this layer in stage 1 / stage 2
+  float beta;
+};
+static_assert(sizeof(VfColsumDesc) == 64, "descriptor layout is shared with the host mirror");
+
+__device__ __forceinline__ int vf_find_layer(const VfColsumDesc* __restrict__ d, int n, int blk, bool stage2) {
+  int l = 0;
+  while (l + 1 < n && blk >= (stage2 ? d[l + 1].blk2_off : d[l + 1].blk1_off)) ++l;
+  return l;
+}
+__global__ __launch_bounds__(256) void k_colsum4_multi(const VfColsumDesc* __restrict__ d, int n) {
+  const int l = vf_find_layer(d, n, blockIdx.x, false);
+  const VfColsumDesc L = d[l];
+  const int local = blockIdx.x - L.blk1_off;
+  const int bx = local % L.gx, by = local / L.gx;
+  const int rp = 256 / L.cq;
+  const int tx = threadIdx.x % L.cq, ty = threadIdx.x / L.cq;
+  const int c4 = by * L.cq + tx;
+  const int C4 = L.C >> 2;
+  const int64_t r0 = (int64_t)bx * L.rows_per_block, r1 = min(L.P, r0 + L.rows_per_block);
+  f32x4 s = {0, 0, 0, 0};
+  if (c4 < C4)
+    for (int64_t r = r0 + ty; r < r1; r += rp) s += *(const f32x4*)(L.g + r * L.C + 4 * c4);
+  __shared__ f32x4 red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (ty == 0 && c4 < C4) {
+    double a[4] = {0, 0, 0, 0};
+    for (int j = 0; j < rp; ++j) {
+      const f32x4 u = red[j * L.cq + tx];
+      for (int e = 0; e < 4; ++e) a[e] += (double)u[e];
+    }
+    double* o = L.part + (int64_t)bx * L.C;
+    for (int e = 0; e < 4; ++e) o[4 * c4 + e] = a[e];
+  }
+}
+__global__ __launch_bounds__(256) void k_reduce_bias_multi(const VfColsumDesc* __restrict__ d, int n) {
+  const int l = vf_find_layer(d, n, blockIdx.x, true);
+  const VfColsumDesc L = d[l];
+  const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int col = (blockIdx.x - L.blk2_off) * 4 + slot;
+  double s0 = 0, s1 = 0;
+  if (col < L.C) {
+    const double* p = L.part + col;
+    int k = lane;
+    for (; k + 64 < L.gx; k += 128) {
+      s0 += p[(int64_t)k * L.C];
+      s1 += p[(int64_t)(k + 64) * L.C];
+    }
+    for (; k < L.gx; k += 64) s0 += p[(int64_t)k * L.C];
+  }
+  double t = s0 + s1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (lane == 0 && col < L.C) L.gb[col] = (L.beta != 0.f ? L.beta * L.gb[col] : 0.f) + (float)t;
+}
+
 // ================================================================================================ host
 static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C) {
   hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4)), dim3(256), 0, ctx->stream,
@@ -471,4 +537,21 @@ VF_API int vf_bn_bwd(vf_ctx* ctx, const float* x, const float* y_act, const floa
   if (int rc = vf_bn_bwd_stats(ctx, x, y_act, gy, save_mean, sums, npix, C, act, slope)) return rc;
   return vf_bn_bwd_apply(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix, npix, C, act, slope,
                          pbeta);
+}
+
+// ---- all bias gradients of a backward walk (see VfColsumDesc)
+VF_API int vf_bias_grad_plan(int64_t P, int C, int* cq, int* rows_per_block, int* gx, int* gy) {
+  VF_REQUIRE(P > 0 && C > 0 && C % 4 == 0, "vf_bias_grad_plan: C must be a positive multiple of 4 (got %d)", C);
+  const BnGeom g = bn_geom(P, C, bn_stat_blocks(P, C, 32768));
+  *cq = g.cq; *rows_per_block = g.rows_per_block; *gx = g.gx; *gy = g.gy;
+  return 0;
+}
+VF_API int vf_bias_grad_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks1, int blocks2) {
+  VF_REQUIRE(desc_dev != nullptr && n > 0 && blocks1 > 0 && blocks2 > 0, "vf_bias_grad_multi: empty plan");
+  VfProf prof(ctx, "bias_grad_multi", 0.0, 0.0);
+  hipLaunchKernelGGL(k_colsum4_multi, dim3(blocks1), dim3(256), 0, ctx->stream, (const VfColsumDesc*)desc_dev, n);
+  VF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_bias_multi, dim3(blocks2), dim3(256), 0, ctx->stream, (const VfColsumDesc*)desc_dev, n);
+  VF_LAUNCH_CHECK();
+  return 0;
 }

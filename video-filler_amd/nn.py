@@ -158,12 +158,19 @@ class SpatialConvolution(Module):
         fn(to_nhwc(gradOutput), self.weight, gx, self.kH, self.dH, self.padH)
         return gx
 
-    def accGradParameters(self, input, gradOutput, scale=1):
+    def accGradParameters(self, input, gradOutput, scale=1, defer_bias=None):
+        """defer_bias: a list the container flushes at the end of its backward walk — gradBias (the column sums of
+        gradOutput) is then computed for all layers in two launches (backend.bias_grad_multi) instead of two each."""
         assert scale == 1, "the reference always uses scale = 1"
         beta = 0.0 if self._fresh else 1.0
         self._fresh = False
         fn = get_backend().deconv2d_bwd_weight if self._is_full else get_backend().conv2d_bwd_weight
-        fn(to_nhwc(input), to_nhwc(gradOutput), self.gradWeight, self.gradBias, self.kH, self.dH, self.padH, beta)
+        go = to_nhwc(gradOutput)
+        gb = self.gradBias
+        if defer_bias is not None and self.nOutputPlane % 4 == 0 and go.data_ptr() % 16 == 0:
+            defer_bias.append((go, self.gradBias, beta))
+            gb = None
+        fn(to_nhwc(input), go, self.gradWeight, gb, self.kH, self.dH, self.padH, beta)
 
     def parameters(self):
         return [self.weight, self.bias], [self.gradWeight, self.gradBias]
@@ -345,6 +352,9 @@ class View(Module):
 
 
 # ---------------------------------------------------------------------------------------------- container
+_NO_DEFER_BIAS = bool(__import__("os").environ.get("VF_NO_DEFER_BIAS"))      # A/B switch (timing experiments)
+
+
 class Sequential(Module):
     _type = "nn.Sequential"
 
@@ -416,6 +426,7 @@ class Sequential(Module):
         B = get_backend()
         g = gradOutput
         used_side = False
+        deferred = [] if (want_gp and self.fuse and hasattr(B, "bias_grad_multi") and not _NO_DEFER_BIAS) else None
         hi = len(plan) if hi is None else hi
         act_done = self._act_done_at == hi if hi < len(plan) else False
         for idx in range(hi - 1, lo - 1, -1):
@@ -444,23 +455,32 @@ class Sequential(Module):
                 if want_gp and self.side is not None and m.parameters():
                     # dW/db only read x and g; nothing on the main stream writes either before the join below
                     with self.side.on():
-                        m.accGradParameters(x, g, 1)
+                        self._acc(m, x, g, deferred)
                     used_side = True
                     gin = upd() if want_gx else None
                 else:
                     gin = upd() if want_gx else None
                     if want_gp:
-                        m.accGradParameters(x, g, 1)
+                        self._acc(m, x, g, deferred)
                 g = gin
                 act_done = in_act is not None
                 continue
             act_done = False
+        if deferred:
+            B.bias_grad_multi(deferred)      # every deferred gradBias of this walk: two launches
         if used_side:
             self.side.join()
         self._act_done_at = lo if act_done else -1       # a partial walk resumes at `lo` (backward_range)
         if lo == 0:
             self.gradInput = g
         return g
+
+    @staticmethod
+    def _acc(m, x, g, deferred):
+        if deferred is not None and isinstance(m, SpatialConvolution):
+            m.accGradParameters(x, g, 1, deferred)
+        else:
+            m.accGradParameters(x, g, 1)
 
     def bucket_split(self, frac=0.9):
         """(plan index k, flat offset): the shortest tail plan[k:] of the backward order's head that owns at least
