@@ -192,6 +192,16 @@ int vf_tiles_gather(vf_ctx* ctx, const float* full, float* tiles, int groups, in
 int vf_tiles_scatter(vf_ctx* ctx, const float* tiles, float* out, int groups, int nc, int H, int W, int fs,
                      const unsigned char* vflip);
 
+/* ---- every weight gradient of one backward walk in one launch -----------------------------------------------------
+ * Between vf_wgrad_group_begin and vf_wgrad_group_end, vf_conv2d_bwd_weight / vf_deconv2d_bwd_weight calls on this
+ * context are RECORDED (the 16-byte-vectorised ones; others still launch at once) and the group — one grouped GEMM
+ * launch per tile family plus one grouped split-K reduce — runs at _end.  Valid because accGradParameters of a layer
+ * reads only that layer's input and gradOutput, which the nn protocol keeps in the modules' buffers until the walk is
+ * over; the caller must not overwrite them, nor read gradWeight, before _end.  The workspace must hold the split-K
+ * slabs of all recorded layers at once (vf_workspace_bytes_hint); if it does not, the group is flushed early. */
+int vf_wgrad_group_begin(vf_ctx* ctx);
+int vf_wgrad_group_end(vf_ctx* ctx);
+
 /* ---- every conv bias gradient of one backward walk in two launches ----------------------------------------------
  * gradBias = sum over pixels of gradOutput (THNN accGradParameters) is not needed before optim.adam, and each layer's
  * gradOutput stays in its module's buffer until the walk ends, so the column sums of all layers run as ONE stage-1 and

@@ -152,6 +152,13 @@ class HipBackend:
         self._c("vf_conv2d_bwd_data_act", _ptr(gy), _ptr(w), _ptr(gx), _ptr(x_act), ACT[act], slope, B, H, W, Cin,
                 w.shape[0], k, stride, pad)
 
+    # ---- all weight gradients of one backward walk in one launch (vf_wgrad_group_begin / _end)
+    def wgrad_group_begin(self):
+        self._c("vf_wgrad_group_begin")
+
+    def wgrad_group_end(self):
+        self._c("vf_wgrad_group_end")
+
     # ---- all conv bias gradients of one backward walk in two launches (vf_bias_grad_multi)
     def bias_grad_multi(self, items):
         """items: [(gradOutput B x C x H x W channels-last, gradBias [C], beta)], C % 4 == 0.  The descriptor table is built

@@ -18,8 +18,11 @@ struct vf_ctx {
   void* ws;         // caller-owned scratch (split-K slabs, reduction partials)
   size_t ws_bytes;
   size_t ws_front;  // bytes at the front of ws currently held by an im2col / column buffer (thin-channel passes)
-  int mfma_bf16;    // 0: fp32 operands (v_mfma_f32_32x32x2_f32, default); 1: operands rounded to bf16 in LDS
+  int mfma_bf16;    // 0: native f32 MFMA; 1: operands rounded to bf16; 3 (default): exact three-plane bf16 split
+  int wg_active;    // a weight-gradient group is being recorded (vf_wgrad_group_begin .. _end)
+  void* wg_rec;     // the recorder (vf_conv.hip)
 };
+void vf_internal_wg_free(vf_ctx* ctx);
 
 static inline char* vf_ws_ptr(vf_ctx* c) { return (char*)c->ws + c->ws_front; }
 static inline size_t vf_ws_avail(vf_ctx* c) { return c->ws_bytes > c->ws_front ? c->ws_bytes - c->ws_front : 0; }

@@ -20,6 +20,7 @@
 // before the LDS write.  Grid.z carries output parity and split-K; split-K partial slabs are combined by
 // k_slab_reduce4 in a fixed order (deterministic; no float atomics).
 #include <algorithm>
+#include <vector>
 #include <cstdlib>
 
 #include "vf_common.h"
@@ -675,7 +676,7 @@ struct WGrad {
 // BF: bf16-operand mode — U and V go into LDS as k-major bf16 tiles (one 8-byte store per piece), the fragments come
 // out through the transposing read (vf_tr_frag) and the products run on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 template <int BM, bool VU, bool VV, int BF = 0>
-__global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
+__device__ __forceinline__ void wgrad_body(const WGrad& p, const int block_id) {
   constexpr int BN = 128, BK = BF ? 32 : 16;      // bf16 mode: two 16-deep MFMA groups per barrier
   constexpr int LDU = BM + 4, LDV = BN + 4;
   constexpr int WN = BM == 128 ? 64 : 32;
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WAVES_N) * 64, wn = (wave % WAVES_N) * WN;
-  const int lid = vf_xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int lid = vf_xcd_remap(block_id, p.gx * p.gy * p.gz);
   const int n0 = ((lid / p.gx) % p.gy) * BM, j0 = (lid % p.gx) * BN;
   const int ks = lid / (p.gx * p.gy);
   const int steps = (p.nk + p.ksplit - 1) / p.ksplit;
@@ -914,6 +915,59 @@ __global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
         }
       }
     }
+}
+
+template <int BM, bool VU, bool VV, int BF = 0>
+__global__ __launch_bounds__(256) void k_wgrad(const WGrad p) {
+  wgrad_body<BM, VU, VV, BF>(p, blockIdx.x);
+}
+
+// Every weight gradient of a backward walk in ONE launch: dW_l needs only (input_l, gradOutput_l), both of which stay in
+// their modules' buffers until the walk is over, so the GEMMs are recorded during the walk and launched together —
+// one ramp and one tail instead of one per layer (each 512-block launch is a single round of blocks), and the
+// descriptor table travels by value in the kernel arguments (no device table, nothing to keep in sync under a graph).
+#define VF_WG_GROUP_MAX 16
+struct WGradGroup {
+  int n;
+  int blk_off[VF_WG_GROUP_MAX + 1];   // multiples of 8: the XCD-aware tile order of a layer assumes blockIdx % 8 == local id % 8
+  WGrad d[VF_WG_GROUP_MAX];
+};
+static_assert(sizeof(WGradGroup) <= 3584, "kernel arguments are limited to 4 KB");
+template <int BM, bool VU, bool VV, int BF>
+__global__ __launch_bounds__(256) void k_wgrad_group(const WGradGroup G) {
+  int l = 0;
+  while (l + 1 < G.n && (int)blockIdx.x >= G.blk_off[l + 1]) ++l;
+  const int local = (int)blockIdx.x - G.blk_off[l];
+  if (local >= G.d[l].gx * G.d[l].gy * G.d[l].gz) return;      // padding blocks (uniform exit)
+  wgrad_body<BM, VU, VV, BF>(G.d[l], local);
+}
+struct SlabGroup {
+  int n;
+  int blk_off[VF_WG_GROUP_MAX + 1];
+  struct { const float* slab; float* dst; int64_t total4; int ksplit; float beta; } d[VF_WG_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void k_slab_reduce4_group(const SlabGroup G) {
+  int l = 0;
+  while (l + 1 < G.n && (int)blockIdx.x >= G.blk_off[l + 1]) ++l;
+  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int64_t i4 = (int64_t)((int)blockIdx.x - G.blk_off[l]) * 64 + tx;
+  const int64_t total4 = G.d[l].total4;
+  const int ksplit = G.d[l].ksplit;
+  const float* slab = G.d[l].slab;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < total4) {
+#pragma unroll 4
+    for (int k = sl; k < ksplit; k += 4) s += ((const f32x4*)slab)[(int64_t)k * total4 + i4];
+  }
+  __shared__ f32x4 red[4][64];
+  red[sl][tx] = s;
+  __syncthreads();
+  if (sl == 0 && i4 < total4) {
+    f32x4 t = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+    f32x4* dst = (f32x4*)G.d[l].dst;
+    if (G.d[l].beta != 0.f) t += G.d[l].beta * dst[i4];
+    dst[i4] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1277,6 +1331,113 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
 }
 
 // dW[n][kh][kw][c] = beta*dW + sum_p U[p][n] * V[b, my*s-pad+kh, mx*s-pad+kw, c]
+// ---- recorder of a weight-gradient group (see k_wgrad_group)
+struct WgRec {
+  WGrad g;
+  int bm, bf;          // tile rows (128 / 64), matrix-core mode
+  int blocks;
+  int64_t total;       // dW elements
+  double flops;
+};
+struct WgRecorder {
+  std::vector<WgRec> recs;
+  size_t ws_used = 0;
+};
+void vf_internal_wg_free(vf_ctx* ctx) {
+  delete (WgRecorder*)ctx->wg_rec;
+  ctx->wg_rec = nullptr;
+}
+template <int BM, int BF>
+static void launch_wg_group(vf_ctx* ctx, const WGradGroup& G, int blocks, const char* name, double flops) {
+  VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_wgrad_group<BM, true, true, BF>), dim3(blocks), dim3(256), G);
+}
+static int wg_flush(vf_ctx* ctx) {
+  WgRecorder* R = (WgRecorder*)ctx->wg_rec;
+  if (!R || R->recs.empty()) return 0;
+  // one launch per (tile rows, mode) family, VF_WG_GROUP_MAX layers at a time
+  for (int bm : {128, 64})
+    for (int bf : {3, 1, 0}) {
+      WGradGroup G;
+      int blocks = 0;
+      double fl = 0;
+      G.n = 0;
+      auto fire = [&]() {
+        if (G.n == 0) return;
+        G.blk_off[G.n] = blocks;
+        char name[64];
+        snprintf(name, sizeof(name), "wgrad_group_%dx128%s", bm, bf == 3 ? "_bf16x3" : (bf ? "_bf16" : ""));
+        if (bm == 128) {
+          if (bf == 3) launch_wg_group<128, 3>(ctx, G, blocks, name, fl);
+          else if (bf == 1) launch_wg_group<128, 1>(ctx, G, blocks, name, fl);
+          else launch_wg_group<128, 0>(ctx, G, blocks, name, fl);
+        } else {
+          if (bf == 3) launch_wg_group<64, 3>(ctx, G, blocks, name, fl);
+          else if (bf == 1) launch_wg_group<64, 1>(ctx, G, blocks, name, fl);
+          else launch_wg_group<64, 0>(ctx, G, blocks, name, fl);
+        }
+        G.n = 0;
+        blocks = 0;
+        fl = 0;
+      };
+      for (const WgRec& r : R->recs) {
+        if (r.bm != bm || r.bf != bf) continue;
+        G.blk_off[G.n] = blocks;
+        G.d[G.n] = r.g;
+        ++G.n;
+        blocks += (r.blocks + 7) & ~7;
+        fl += r.flops;
+        if (G.n == VF_WG_GROUP_MAX) fire();
+      }
+      fire();
+    }
+  VF_LAUNCH_CHECK();
+  // the split-K slabs of all layers: one launch per VF_WG_GROUP_MAX layers
+  {
+    SlabGroup S;
+    int blocks = 0;
+    double bytes = 0;
+    S.n = 0;
+    auto fire = [&]() {
+      if (S.n == 0) return;
+      S.blk_off[S.n] = blocks;
+      VfProf prof(ctx, "slab_reduce_wgrad_group", 0.0, bytes);
+      hipLaunchKernelGGL(k_slab_reduce4_group, dim3(blocks), dim3(256), 0, ctx->stream, S);
+      S.n = 0;
+      blocks = 0;
+      bytes = 0;
+    };
+    for (const WgRec& r : R->recs) {
+      if (r.g.ksplit <= 1) continue;
+      S.blk_off[S.n] = blocks;
+      S.d[S.n].slab = r.g.slab;
+      S.d[S.n].dst = r.g.dW;
+      S.d[S.n].total4 = r.total / 4;
+      S.d[S.n].ksplit = r.g.ksplit;
+      S.d[S.n].beta = r.g.beta;
+      ++S.n;
+      blocks += (int)vf_cdiv(r.total / 4, 64);
+      bytes += 4.0 * (double)r.total * (r.g.ksplit + 1);
+      if (S.n == VF_WG_GROUP_MAX) fire();
+    }
+    fire();
+  }
+  VF_LAUNCH_CHECK();
+  R->recs.clear();
+  R->ws_used = 0;
+  return 0;
+}
+VF_API int vf_wgrad_group_begin(vf_ctx* ctx) {
+  VF_REQUIRE(!ctx->wg_active, "vf_wgrad_group_begin: a group is already open");
+  if (!ctx->wg_rec) ctx->wg_rec = new WgRecorder();
+  ctx->wg_active = 1;
+  return 0;
+}
+VF_API int vf_wgrad_group_end(vf_ctx* ctx) {
+  VF_REQUIRE(ctx->wg_active, "vf_wgrad_group_end: no group is open");
+  ctx->wg_active = 0;
+  return wg_flush(ctx);
+}
+
 static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, int Hl, int Wl, int Nu, int Hv, int Wv,
                  int Cv, int stride, int pad, float beta, int ntaps = 16) {
   WGrad g;
@@ -1312,6 +1473,29 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
   g.gx = gx; g.gy = gy; g.gz = ksplit;
   dim3 grid((unsigned)gx * gy * ksplit), block(256);
+  if (ctx->wg_active && vecU && vecV && (ksplit == 1 || total % 4 == 0)) {
+    // recorded, not launched: the group runs at vf_wgrad_group_end.  Every recorded layer keeps its own slab region.
+    WgRecorder* R = (WgRecorder*)ctx->wg_rec;
+    const size_t need = ksplit > 1 ? (((size_t)ksplit * total * sizeof(float) + 255) & ~(size_t)255) : 0;
+    if (R->ws_used + need > vf_ws_avail(ctx)) {
+      if (int rc = wg_flush(ctx)) return rc;
+    }
+    VF_REQUIRE(need <= vf_ws_avail(ctx), "workspace too small for this layer's split-K slabs");
+    if (ksplit > 1) g.slab = (float*)(vf_ws_ptr(ctx) + R->ws_used);
+    R->ws_used += need;
+    WgRec r;
+    r.g = g;
+    r.bm = BM;
+    r.bf = ctx->mfma_bf16;
+    r.blocks = gx * gy * ksplit;
+    r.total = total;
+    r.flops = 2.0 * (double)g.P * Nu * (double)ntaps * Cv;
+    R->recs.push_back(r);
+    return 0;
+  }
+  if (ctx->wg_active) {      // a launch outside the group must not overwrite recorded slabs: finish the group first
+    if (int rc = wg_flush(ctx)) return rc;
+  }
   {
     const int bf = ctx->mfma_bf16;
     const char* wname = BM == 128 ? (bf == 3 ? "wgrad_128x128_bf16x3" : bf ? "wgrad_128x128_bf16" : "wgrad_128x128")

@@ -33,11 +33,14 @@ VF_API int vf_ctx_create(vf_ctx** out, int device, void* stream) {
   c->ws = nullptr;
   c->ws_bytes = 0;
   c->ws_front = 0;
+  c->wg_active = 0;
+  c->wg_rec = nullptr;
   c->mfma_bf16 = 3;      // fp32 operands as three exact bf16 planes (see vf_ctx_set_mfma_mode)
   *out = c;
   return 0;
 }
 VF_API int vf_ctx_destroy(vf_ctx* ctx) {
+  if (ctx) vf_internal_wg_free(ctx);
   delete ctx;
   return 0;
 }
@@ -56,7 +59,7 @@ VF_API int vf_ctx_set_workspace(vf_ctx* ctx, void* ptr, size_t bytes) {
   ctx->ws_bytes = bytes;
   return 0;
 }
-VF_API size_t vf_workspace_bytes_hint(void) { return (size_t)256 << 20; }
+VF_API size_t vf_workspace_bytes_hint(void) { return (size_t)1 << 30; }   // room for every layer's split-K slabs of a grouped launch
 VF_API int vf_stream_synchronize(vf_ctx* ctx) {
   VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return 0;

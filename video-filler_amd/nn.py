@@ -352,7 +352,8 @@ class View(Module):
 
 
 # ---------------------------------------------------------------------------------------------- container
-_NO_DEFER_BIAS = bool(__import__("os").environ.get("VF_NO_DEFER_BIAS"))      # A/B switch (timing experiments)
+_NO_DEFER_BIAS = bool(__import__("os").environ.get("VF_NO_DEFER_BIAS"))      # A/B switches (timing experiments)
+_NO_WG_GROUP = bool(__import__("os").environ.get("VF_NO_WG_GROUP"))
 
 
 class Sequential(Module):
@@ -427,6 +428,10 @@ class Sequential(Module):
         g = gradOutput
         used_side = False
         deferred = [] if (want_gp and self.fuse and hasattr(B, "bias_grad_multi") and not _NO_DEFER_BIAS) else None
+        # one stream: the weight-gradient GEMMs of the walk are recorded and launched together at its end
+        grouped = want_gp and self.fuse and self.side is None and hasattr(B, "wgrad_group_begin") and not _NO_WG_GROUP
+        if grouped:
+            B.wgrad_group_begin()
         hi = len(plan) if hi is None else hi
         act_done = self._act_done_at == hi if hi < len(plan) else False
         for idx in range(hi - 1, lo - 1, -1):
@@ -466,6 +471,8 @@ class Sequential(Module):
                 act_done = in_act is not None
                 continue
             act_done = False
+        if grouped:
+            B.wgrad_group_end()
         if deferred:
             B.bias_grad_multi(deferred)      # every deferred gradBias of this walk: two launches
         if used_side:
