@@ -224,7 +224,7 @@ def main():
         try:
             import glob
             pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic.json")))[-1]
-            pmc = json.load(open(pmc_file))["kernels"].get(name.replace("_parity", ""))
+            pmc = json.load(open(pmc_file))["kernels"].get(name)
             if pmc is not None and args.workload == "center" and args.batch == 64:
                 roofline["traffic"] = int(pmc["hbm_MB_per_launch"] * 1e6)
                 roofline["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)"

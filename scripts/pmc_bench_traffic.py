@@ -10,6 +10,9 @@ src, dst = sys.argv[1], sys.argv[2]
 # rocprof kernel name -> the name bench.py's kernel table uses
 def bench_name(k):
     suf = {"0": "", "1": "_bf16", "3": "_bf16x3"}
+    m = re.match(r"void k_wgrad_group<(\d+), \w+, \w+, (\d)>", k)
+    if m:
+        return "wgrad_group_%sx128%s" % (m.group(1), suf.get(m.group(2), ""))
     m = re.match(r"void k_wgrad<(\d+), \w+, \w+(?:, (\d))?>", k)
     if m:
         return "wgrad_%sx128%s" % (m.group(1), suf.get(m.group(2) or "0", ""))

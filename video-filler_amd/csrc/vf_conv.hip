@@ -1170,7 +1170,8 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     if (stamp_dump) VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   char pname[64];
-  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v, g.parity ? "_parity" : "",
+  // one name per kernel symbol (what rocprofv3 lists): k_igemm<bm, bn, ., ., kmajorB, v, mode>
+  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v,
            ctx->mfma_bf16 == 3 ? "_bf16x3" : (ctx->mfma_bf16 ? "_bf16" : ""));
   {
     const double fl = 2.0 * (double)g.M * g.N * Ktot * zpar;
