@@ -358,3 +358,44 @@ def test_conv_bwd_data_with_input_activation_backward(case, oracle, hipb):
     dgx = hipb.empty_act(*x.shape)
     hipb.conv2d_bwd_data_act(to_dev(gy, hipb), to_dev(ref.weight, hipb), dgx, to_dev(x, hipb), act, 0.2, 4, 2, 1)
     assert_close(to_np(dgx), want, TOL, "bwd_data_act %s" % (case,))
+
+
+def test_weight_gradient_group_equals_individual_launches(oracle, hipb):
+    """vf_wgrad_group_begin/_end: recorded weight gradients (several layers, split-K and not, conv and full-conv,
+    accumulate and overwrite) equal the per-layer launches bit for bit; an abandoned group is dropped by the next begin."""
+    import torch
+    rng = np.random.default_rng(17)
+    layers = [(False, 4, 64, 16, 128, 2, 1, 0.0), (False, 4, 128, 8, 256, 2, 1, 1.0), (True, 4, 256, 4, 128, 2, 1, 0.0),
+              (False, 4, 512, 4, 100, 1, 0, 0.0), (True, 4, 100, 1, 512, 1, 0, 1.0)]
+    args = []
+    for full, B, Cin, H, Cout, s, p, beta in layers:
+        Ho = ((H - 1) * s - 2 * p + 4) if full else ((H + 2 * p - 4) // s + 1)
+        x = to_dev(_rand(rng, B, Cin, H, H), hipb)
+        gy = to_dev(_rand(rng, B, Cout, Ho, Ho), hipb)
+        wshape = (Cin, Cout, 4, 4) if full else (Cout, Cin, 4, 4)
+        gw0 = _rand(rng, *wshape)
+        args.append((full, x, gy, gw0, s, p, beta))
+
+    def run(grouped):
+        outs = []
+        if grouped:
+            hipb.wgrad_group_begin()
+        for full, x, gy, gw0, s, p, beta in args:
+            gw = to_dev(gw0, hipb)
+            (hipb.deconv2d_bwd_weight if full else hipb.conv2d_bwd_weight)(x, gy, gw, None, 4, s, p, beta)
+            outs.append(gw)
+        if grouped:
+            hipb.wgrad_group_end()
+        torch.cuda.synchronize()
+        return [to_np(g) for g in outs]
+
+    a, b = run(False), run(True)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    # abandoned group: begin, record one layer, never end; the next begin starts clean
+    hipb.wgrad_group_begin()
+    full, x, gy, gw0, s, p, beta = args[0]
+    hipb.conv2d_bwd_weight(x, gy, to_dev(gw0, hipb), None, 4, s, p, beta)
+    c = run(True)
+    for u, v in zip(a, c):
+        np.testing.assert_array_equal(u, v)

@@ -1428,8 +1428,11 @@ static int wg_flush(vf_ctx* ctx) {
   return 0;
 }
 VF_API int vf_wgrad_group_begin(vf_ctx* ctx) {
-  VF_REQUIRE(!ctx->wg_active, "vf_wgrad_group_begin: a group is already open");
   if (!ctx->wg_rec) ctx->wg_rec = new WgRecorder();
+  if (ctx->wg_active) {      // the previous walk was abandoned before its _end (a host-side error): drop what it recorded
+    ((WgRecorder*)ctx->wg_rec)->recs.clear();
+    ((WgRecorder*)ctx->wg_rec)->ws_used = 0;
+  }
   ctx->wg_active = 1;
   return 0;
 }
