@@ -225,6 +225,38 @@ def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hi
         assert abs(la[k] - lb[k]) <= 1e-9 * max(1.0, abs(la[k]))
 
 
+@pytest.mark.parametrize("kind", ["center", "vid"])
+def test_captured_graph_sees_new_batches(kind, oracle, hipb):
+    """set_batch() after capture() writes into the buffers the graph was captured with: replaying on a new batch
+    equals eager steps on that batch (a graph that kept reading the first batch would fail this)."""
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+    rng = np.random.default_rng(31)
+    if kind == "center":
+        opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
+        mk = lambda: CenterTrainer(opt, seed=3)
+        batches = [(torch.from_numpy(oracle.synth_center_batch(4, rng)),) for _ in range(3)]
+    else:
+        opt = dict(nBottleneck=64, predLen=2)
+        mk = lambda: VidTrainer(opt, seed=3)
+        batches = [tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(4, rng, 6)) for _ in range(3)]
+    a, b = mk(), mk()
+    a.set_batch(*batches[0])
+    b.set_batch(*batches[0])
+    for _ in range(3):
+        a.step()
+    b.capture(warmup=3)
+    for bt in batches[1:]:
+        a.set_batch(*bt)
+        a.step()
+        b.set_batch(*bt)
+        b.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(b.parametersG, a.parametersG) and torch.equal(b.parametersD, a.parametersD)
+    la, lb = a.losses(), b.losses()
+    for k in ("errD", "errG", "errG_l2"):
+        assert abs(la[k] - lb[k]) <= 1e-9 * max(1.0, abs(la[k]))
+
+
 def test_netG_evaluate_mode_forward(oracle, hipb):
     """test_vid.lua:47-48,102: util.load(net); net:evaluate(); net:forward(input) — BatchNorm uses running statistics."""
     from video_filler_amd.trainers import build_netG

@@ -15,17 +15,21 @@ from .backend import get_backend, nhwc_empty
 CENTER_FILL = (117.0, 104.0, 123.0)      # train.lua:287-289
 
 
-def center_prepare(batch, overlapPred, fill=CENTER_FILL):
+def center_prepare(batch, overlapPred, fill=CENTER_FILL, out=None):
     """train.lua:284-298: (input_ctx, real_center) as channels-last device tensors from the loader's batch
-    (B x nc x fs x fs in [-1,1], host or device)."""
+    (B x nc x fs x fs in [-1,1], host or device).  out = (input_ctx, real_center): write into these existing tensors
+    (a captured HIP graph keeps reading the buffers it was captured with)."""
     B = get_backend()
     x = B.from_host(batch).float().contiguous()
     nB, nc, fs, _ = x.shape
     dev = x.device
     fillv = [2 * m / 255.0 - 1.0 for m in fill]
     fillv = (fillv * ((nc + len(fillv) - 1) // len(fillv)))[:nc]
-    ctx = nhwc_empty(nB, nc, fs, fs, dev)
-    center = nhwc_empty(nB, nc, fs // 2, fs // 2, dev)
+    if out is not None and tuple(out[0].shape) == (nB, nc, fs, fs) and tuple(out[1].shape) == (nB, nc, fs // 2, fs // 2):
+        ctx, center = out
+    else:
+        ctx = nhwc_empty(nB, nc, fs, fs, dev)
+        center = nhwc_empty(nB, nc, fs // 2, fs // 2, dev)
     B.center_prepare(x, ctx, center, B.from_host(torch.tensor(fillv, dtype=torch.float32)), overlapPred)
     return ctx, center
 

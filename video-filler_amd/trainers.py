@@ -380,18 +380,20 @@ class CenterTrainer(_TrainerBase):
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn))
         self.real_label, self.fake_label = 1, 0
-        self.input_ctx = self.input_center = self.input_real_center = None
+        self.input_ctx = self.input_center = self.input_real_center = self._real_center = None
 
     def set_batch(self, real_ctx):
         """What train.lua:284-298 does on the loader's batch (a B x nc x fineSize x fineSize tensor in [-1,1]):
         clone the centre crop, paint the hole (minus the overlap band) with the channel means, and copy to the
         device buffers input_ctx / input_center / input_real_center."""
         o = self.opt
-        self.input_ctx, self._real_center = data.center_prepare(real_ctx, o["overlapPred"])
-        real_center = self._real_center
-        if self.input_center is None or self.input_center.shape != real_center.shape:
-            self.input_center = torch.empty_like(self._real_center)
-            self.input_real_center = torch.empty_like(self._real_center)
+        # persistent device buffers: a captured graph keeps reading the tensors it was captured with, so a new batch
+        # is written INTO them.  input_center / input_real_center are views of the protocol's names onto buffers that
+        # already hold the data (the reference copies host tensors into them; here the data is on the device already)
+        prev = (self.input_ctx, self._real_center) if self.input_ctx is not None else None
+        self.input_ctx, self._real_center = data.center_prepare(real_ctx, o["overlapPred"], out=prev)
+        self.input_real_center = self._real_center
+        self.input_center = self._real_center
 
     def _fDx_gen(self):
         """fDx as a generator that yields once, at the point where the generator net's parameters are first needed:
@@ -411,10 +413,8 @@ class CenterTrainer(_TrainerBase):
                     self._apply_pending_g()
                     self.netG.zeroConvBiases()
                 fake = self.netG.forward(self.input_ctx)
-        # train with real
-        B.copy(self.input_center, self._real_center)
-        if o["wtl2"] != 0:
-            B.copy(self.input_real_center, self._real_center)
+        # train with real (input_center:copy(real_center): the centre crop already sits in a device buffer)
+        self.input_center = self._real_center
         label = self.real_label
         output = self.netD.forward(self.input_center)
         errD_real = self.criterion.forward(output, label)
@@ -429,7 +429,7 @@ class CenterTrainer(_TrainerBase):
             fake = self.netG.forward(self.input_ctx)
         else:
             self.side_g.join()
-        B.copy(self.input_center, fake)
+        self.input_center = fake               # input_center:copy(fake): netD reads the generator's output buffer
         label = self.fake_label
         output = self.netD.forward(self.input_center)
         errD_fake = self.criterion.forward(output, label)
@@ -488,14 +488,18 @@ class VidTrainer(_TrainerBase):
     def set_batch(self, real_ctx, real_full, real_mask):
         """The loader contract (datavid/dataset.lua:426): masked clip, full clip, Byte mask, all B x nc x H x W."""
         B = get_backend()
-        self._real_ctx = to_nhwc(B.from_host(real_ctx).float())
-        self._real_full = to_nhwc(B.from_host(real_full).float())
-        self._real_mask = to_nhwc(B.from_host(real_mask).float())     # input_mask:copy(real_mask): Byte -> Float
-        if self.input_inpainted is None or self.input_inpainted.shape != self._real_full.shape:
-            self.input_ctx = torch.empty_like(self._real_ctx)
-            self.input_real = torch.empty_like(self._real_full)
-            self.input_mask = torch.empty_like(self._real_mask)
-            self.input_inpainted = torch.empty_like(self._real_full)
+        new = [to_nhwc(B.from_host(t).float()) for t in (real_ctx, real_full, real_mask)]     # Byte mask -> Float (:394)
+        new = [n.clone() if (torch.is_tensor(t) and n.data_ptr() == t.data_ptr()) else n       # never adopt the caller's storage
+               for n, t in zip(new, (real_ctx, real_full, real_mask))]
+        if self.input_inpainted is not None and all(a.shape == b.shape for a, b in zip((self._real_ctx, self._real_full, self._real_mask), new)):
+            for dst, src in zip((self._real_ctx, self._real_full, self._real_mask), new):
+                dst.copy_(src)       # persistent buffers: a captured graph keeps reading them
+        else:
+            self._real_ctx, self._real_full, self._real_mask = new
+            self._inpaint_buf = torch.empty_like(self._real_full)
+        # the protocol's names, as views onto buffers that already hold the data
+        self.input_ctx, self.input_real, self.input_mask = self._real_ctx, self._real_full, self._real_mask
+        self.input_inpainted = self._inpaint_buf
 
     def _fDx_gen(self):
         B, o = get_backend(), self.opt
@@ -504,10 +508,6 @@ class VidTrainer(_TrainerBase):
         if not self._pending_g:
             self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
-        B.copy(self.input_ctx, self._real_ctx)
-        if o["wtl2"] != 0:
-            B.copy(self.input_real, self._real_full)
-        B.copy(self.input_mask, self._real_mask)
         fake = None
         if early_g:                            # netG forward beside netD's real pass (independent work)
             with self.side_g.on():
@@ -529,9 +529,10 @@ class VidTrainer(_TrainerBase):
         else:
             self.side_g.join()
         if o["weight_nomask"] == 0:                  # train_vid_weighted.lua:429-432
+            self.input_inpainted = self._inpaint_buf
             B.masked_compose(self.input_inpainted, self.input_real, fake, self.input_mask)
         else:
-            B.copy(self.input_inpainted, fake)
+            self.input_inpainted = fake        # input_inpainted:copy(fake): netD reads the generator's output buffer
         label = self.fake_label
         output = self.netD.forward(self.input_inpainted)
         errD_fake = self.criterion.forward(output, label)
