@@ -92,3 +92,23 @@ def test_lua_binding_declares_the_header_faithfully():
         assert n == h[name], "%s: %d parameters in hipnn.lua, %d in the header" % (name, n, h[name])
     called = set(re.findall(r"\bC\.(vf_[a-z0-9_]+)\s*\(", lua))
     assert called and called <= set(l), "called but not declared in the cdef: %s" % sorted(called - set(l))
+
+
+def test_descriptor_mirror_matches_the_device_struct():
+    """backend.COLSUM_DESC mirrors struct VfColsumDesc of csrc/vf_bn.hip field for field (64 bytes, no padding)."""
+    import re
+    import numpy as np
+    from video_filler_amd.backend import COLSUM_DESC
+    dt = np.dtype(COLSUM_DESC)
+    assert dt.itemsize == 64
+    src = open(os.path.join(ROOT, "video-filler_amd", "csrc", "vf_bn.hip")).read()
+    body = re.search(r"struct VfColsumDesc \{(.*?)\};", src, flags=re.S).group(1)
+    body = re.sub(r"//[^\n]*", "", body)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.sub(r"^.*[\s\*]", "", part.strip()))
+    assert names == list(dt.names), (names, dt.names)
