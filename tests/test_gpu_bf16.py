@@ -232,3 +232,21 @@ def test_three_plane_training_iteration_matches_fp32_tolerances(oracle, x3_backe
     for net, want in ((tr.netG, ref.gradParametersG), (tr.netD, ref.gradParametersD)):
         g = net.reference_flat(grads=True).cpu().numpy()
         assert np.abs(g - want).max() < 1e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("scale", [1e-18, 1.0, 1e18])
+def test_three_plane_split_across_the_exponent_range(scale, oracle, x3_backend):
+    """bf16 has fp32's exponent range, so the exact split must hold for very small and very large operands alike
+    (products up to 1e36 and down to 1e-36 here); relative error stays at the fp32 level."""
+    hipb = x3_backend
+    rng = np.random.default_rng(5)
+    r = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    m = oracle.SpatialConvolution(64, 64, 4, 4, 2, 2, 1, 1)
+    m.weight[...] = r(*m.weight.shape) * np.float32(scale)
+    m.bias[...] = 0
+    x = r(2, 64, 16, 16) * np.float32(scale)
+    y = np.array(m.forward(x), copy=True)
+    assert np.isfinite(y).all() and np.abs(y).max() > 0
+    dy = hipb.empty_act(*y.shape)
+    hipb.conv2d_fwd(to_dev(x, hipb), to_dev(m.weight, hipb), to_dev(m.bias, hipb), dy, 4, 2, 1)
+    assert_close(to_np(dy), y, 2e-5, "x3 fwd at scale %g" % scale)
