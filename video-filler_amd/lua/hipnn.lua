@@ -87,6 +87,13 @@ function hipnn.init(device)          -- cutorch.setDevice(opt.gpu)  (train.lua:2
    check(C.vf_ctx_set_workspace(hipnn.ctx, ws[0], n))
 end
 
+-- vf_ctx_set_mfma_mode: 3 (default) fp32 operands as three exact bf16 planes on the bf16 pipe; 0 native f32 MFMA (the
+-- reference's fmaf chain bit for bit); 1 operands rounded to bf16 (opt-in)
+function hipnn.setMfmaMode(mode) check(C.vf_ctx_set_mfma_mode(hipnn.ctx, mode)) end
+-- every weight gradient recorded between these two runs as one grouped launch (wrap net:backward with them)
+function hipnn.beginBackward() check(C.vf_wgrad_group_begin(hipnn.ctx)) end
+function hipnn.endBackward() check(C.vf_wgrad_group_end(hipnn.ctx)) end
+
 local function fptr(t) return ffi.cast('float*', t:data()) end
 
 ---------------------------------------------------------------------------------------------------------------
