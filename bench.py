@@ -50,6 +50,8 @@ def main():
                     help="how conv products are formed: f32_3xbf16 (default; fp32 operands split exactly into 3 bf16 planes, 6 "
                     "cross terms on the bf16 pipe, fp32 accumulate: fp32-grade), f32 (native f32 MFMA), bf16 (operands rounded: "
                     "opt-in, its own tolerance, not a headline configuration)")
+    ap.add_argument("--batch-d", action="store_true", help="N=1: netD's real and fake passes as one batch of 2B (BatchNorm in two "
+                    "groups; same arithmetic per sample)")
     ap.add_argument("--overlap", action="store_true", help="3 streams (dW beside dX, netG forward beside netD's real pass): measured "
                     "+0.7 %% on one GPU with the current kernels (noise level), so the default is one stream")
     ap.add_argument("--no-overlap", action="store_true", help="(default now; kept so that older command lines still parse)")
@@ -112,6 +114,8 @@ def main():
 
     dp = world > 1 or args.force_dist
     tr.force_comm = args.force_dist
+    if args.batch_d and not dp:
+        tr.set_batch_d(True)
     use_graph = not args.no_graph and not (dp and args.sync_bn)
     pipelined = dp and not args.no_pipeline and not args.sync_bn
     if dp:

@@ -115,12 +115,15 @@ def _load(tr, ref):
 
 
 @pytest.mark.parametrize("smooth", [True, False])
-@pytest.mark.parametrize("fuse,lazy,skip", [(True, True, True), (False, False, False)])
-def test_center_trainer_two_iterations(fuse, lazy, skip, smooth, oracle, hipb):
+@pytest.mark.parametrize("fuse,lazy,skip,batch_d", [(True, True, True, False), (False, False, False, False),
+                                                    (True, True, True, True), (False, False, False, True)])
+def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle, hipb):
+    """batch_d: netD's real and fake passes as one batch of 2B with two BatchNorm groups — same oracle, same bars."""
     from video_filler_amd.trainers import CenterTrainer
     opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4, smooth=smooth)
     ref = oracle.CenterTrainer(opt, np.random.default_rng(1))
     tr = CenterTrainer(opt, fuse=fuse, lazy_zero=lazy, skip_dead_grads=skip)
+    tr.set_batch_d(batch_d)
     _load(tr, ref)
     assert len([m for m in tr.netG.leaves() if hasattr(m, "running_mean")]) == 9
     for it in range(2):
@@ -133,9 +136,10 @@ def test_center_trainer_two_iterations(fuse, lazy, skip, smooth, oracle, hipb):
         _resync(ref, tr)
 
 
+@pytest.mark.parametrize("batch_d", [False, True])
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim"])
-def test_vid_trainer_two_iterations(variant, smooth, oracle, hipb):
+def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
     from video_filler_amd.trainers import VidTrainer
     if variant == "weighted":          # train_vid_weighted.lua defaults, predLen = 2
         opt = dict(nBottleneck=64, predLen=2)
@@ -149,6 +153,7 @@ def test_vid_trainer_two_iterations(variant, smooth, oracle, hipb):
     opt["smooth"] = smooth
     ref = oracle.VidTrainer(opt, np.random.default_rng(2))
     tr = VidTrainer(opt)
+    tr.set_batch_d(batch_d)
     _load(tr, ref)
     for it in range(2):
         ctx, full, mask = oracle.synth_vid_batch(4, np.random.default_rng(20 + it), nc_in, nc_out)   # B = 4: BatchNorm over

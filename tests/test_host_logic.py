@@ -138,13 +138,15 @@ def test_gradient_buckets_and_split_backward(cpu_backend):
     assert torch.equal(tr2.gradParametersG, whole)
 
 
-@pytest.mark.parametrize("fuse", [True, False])
-def test_center_trainer_closures_match_oracle(fuse, cpu_backend):
+@pytest.mark.parametrize("fuse,batch_d", [(True, False), (False, False), (True, True), (False, True)])
+def test_center_trainer_closures_match_oracle(fuse, batch_d, cpu_backend):
+    """batch_d: netD's real and fake passes as one batch of 2B, BatchNorm in two groups — the same closures."""
     from video_filler_amd.trainers import CenterTrainer
     from oracle import oracle as O
     opt = dict(SMALL, wtl2=0.999, overlapPred=4)
     ref = O.CenterTrainer(opt, np.random.default_rng(1))
     tr = CenterTrainer(opt, fuse=fuse, lazy_zero=fuse, skip_dead_grads=fuse)
+    tr.set_batch_d(batch_d)
     _load(tr, ref)
     for it in range(2):
         batch = O.synth_center_batch(2, np.random.default_rng(30 + it))
@@ -161,14 +163,16 @@ def test_center_trainer_closures_match_oracle(fuse, cpu_backend):
         assert np.abs(tr.netG.reference_flat().numpy() - ref.parametersG)[sel].max() < 0.02 * 0.002
 
 
+@pytest.mark.parametrize("batch_d", [False, True])
 @pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl"])
-def test_vid_trainer_closures_match_oracle(variant, cpu_backend):
+def test_vid_trainer_closures_match_oracle(variant, batch_d, cpu_backend):
     from video_filler_amd.trainers import VidTrainer
     from oracle import oracle as O
     opt = dict(SMALL, predLen=2) if variant == "weighted" else dict(SMALL, predLen=1, weight_nomask=0, wtgdl=0.5)
     nc = 6 if variant == "weighted" else 3
     ref = O.VidTrainer(opt, np.random.default_rng(2))
     tr = VidTrainer(opt)
+    tr.set_batch_d(batch_d)
     _load(tr, ref)
     ctx, full, mask = O.synth_vid_batch(3, np.random.default_rng(9), nc)
     ref.set_batch(ctx, full, mask)

@@ -100,7 +100,7 @@ class Module:
         return self
 
     def _buf(self, name, B, Cc, H, W):
-        t = getattr(self, name)
+        t = getattr(self, name, None)
         if t is None or tuple(t.shape) != (B, Cc, H, W):
             t = get_backend().empty_act(B, Cc, H, W)
             setattr(self, name, t)
@@ -146,10 +146,11 @@ class SpatialConvolution(Module):
         fn(input, self.weight, self.bias, y, self.kH, self.dH, self.padH, act, slope)
         return y
 
-    def updateGradInput(self, input, gradOutput, in_act=None):
+    def updateGradInput(self, input, gradOutput, in_act=None, buf="gradInput"):
         """in_act = (act, slope): `input` is the in-place activated output of the previous module; its
-        updateGradInput (gx .* act'(input)) is applied in this pass's epilogue instead of in a pass of its own."""
-        gx = self._buf("gradInput", *input.shape)
+        updateGradInput (gx .* act'(input)) is applied in this pass's epilogue instead of in a pass of its own.
+        buf: the attribute that holds the result (a pass over part of the batch keeps its own buffer)."""
+        gx = self._buf(buf, *input.shape)
         B = get_backend()
         if in_act is not None:
             B.conv2d_bwd_data_act(to_nhwc(gradOutput), self.weight, gx, input, in_act[0], in_act[1], self.kH, self.dH, self.padH)
@@ -205,6 +206,11 @@ class SpatialBatchNormalization(Module):
         self._fresh = False
         self.sync_world = 1                       # >1: SyncBN — all-reduce the per-channel sums
         self.sync_group = None
+        # groups > 1: the batch is the concatenation of `groups` independent batches (netD's real and fake passes run
+        # as one batch of 2B): statistics, running-average updates and backward sums are per group, in group order —
+        # exactly what the separate passes would do — while the convolutions around this module see one large batch
+        self.groups = 1
+        self._gsave = None
 
     def updateOutput(self, input, act="none", slope=0.0):
         B = get_backend()
@@ -212,6 +218,19 @@ class SpatialBatchNormalization(Module):
         Bn, Cc, H, W = input.shape
         assert Cc == self.nOutputPlane
         y = self._buf("output", Bn, Cc, H, W)
+        if self.train and self.groups > 1:
+            assert self.sync_world == 1 and Bn % self.groups == 0
+            h = Bn // self.groups
+            for g, (sm, ss, su) in enumerate(self._group_state()):
+                xg, yg = input[g * h:(g + 1) * h], y[g * h:(g + 1) * h]
+                if hasattr(B, "bn_train_fwd"):
+                    B.bn_train_fwd(xg, yg, self.weight, self.bias, self.running_mean, self.running_var, sm, ss, su,
+                                   self.momentum, self.eps, act, slope)
+                else:
+                    B.bn_stats(xg, self.running_mean, su)
+                    B.bn_finalize(su, self.running_mean, self.running_var, sm, ss, h * H * W, self.momentum, self.eps)
+                    B.bn_apply(xg, yg, self.weight, self.bias, sm, ss, act, slope)
+            return y
         if self.train and self.sync_world == 1 and hasattr(B, "bn_train_fwd"):
             B.bn_train_fwd(input, y, self.weight, self.bias, self.running_mean, self.running_var, self.save_mean,
                            self.save_std, self._sums, self.momentum, self.eps, act, slope)
@@ -226,16 +245,48 @@ class SpatialBatchNormalization(Module):
             B.bn_eval_fwd(input, y, self.weight, self.bias, self.running_mean, self.running_var, self.eps, act, slope)
         return y
 
-    def _bwd(self, input, gradOutput, want_gx, want_gp, act="none", slope=0.0, y_act=None):
+    def _group_state(self):
+        if self._gsave is None or len(self._gsave) != self.groups:
+            B = get_backend()
+            n = self.nOutputPlane
+            self._gsave = [(self.save_mean, self.save_std, self._sums)] + [
+                (B.zeros(n), B.zeros(n), B.zeros(2 * n, dtype=torch.float64)) for _ in range(self.groups - 1)]
+        return self._gsave
+
+    def _bwd(self, input, gradOutput, want_gx, want_gp, act="none", slope=0.0, y_act=None, group=None, buf="gradInput"):
+        """group = g: `input` / `gradOutput` / `y_act` hold group g's samples only (a pass over one of the concatenated
+        batches); group = None with groups > 1: all groups, one after the other."""
         assert self.train, "the reference never back-propagates through BN in evaluate mode"
         B = get_backend()
         input, gradOutput = to_nhwc(input), to_nhwc(gradOutput)
         Bn, Cc, H, W = input.shape
-        gx = self._buf("gradInput", Bn, Cc, H, W) if want_gx else None
+        gx = self._buf(buf, Bn, Cc, H, W) if want_gx else None
         pbeta = 1.0
         if want_gp:
             pbeta = 0.0 if self._fresh else 1.0
             self._fresh = False
+        if self.groups > 1:
+            assert self.sync_world == 1
+            state = self._group_state()
+            gw, gb = (self.gradWeight, self.gradBias) if want_gp else (None, None)
+
+            def one(x, ya, gy, gxx, st, pb):
+                sm, ss, su = st
+                if hasattr(B, "bn_bwd"):
+                    B.bn_bwd(x, ya, gy, gxx, gw, gb, self.weight, sm, ss, su, act, slope, pb)
+                else:
+                    B.bn_bwd_stats(x, ya, gy, sm, su, act, slope)
+                    B.bn_bwd_apply(x, ya, gy, gxx, gw, gb, self.weight, sm, ss, su, x.shape[0] * H * W, act, slope, pb)
+
+            if group is not None:
+                one(input, y_act, gradOutput, gx, state[group], pbeta)
+                return gx
+            h = Bn // self.groups
+            for g, st in enumerate(state):
+                sl = slice(g * h, (g + 1) * h)
+                one(input[sl], None if y_act is None else y_act[sl], gradOutput[sl], None if gx is None else gx[sl], st,
+                    pbeta if g == 0 else 1.0)
+            return gx
         if self.sync_world == 1 and hasattr(B, "bn_bwd"):
             B.bn_bwd(input, y_act, gradOutput, gx, self.gradWeight if want_gp else None, self.gradBias if want_gp else None,
                      self.weight, self.save_mean, self.save_std, self._sums, act, slope, pbeta)
@@ -287,9 +338,16 @@ class _Act(Module):
         get_backend().act_fwd(input, self.output, self.act, self.slope)
         return self.output
 
-    def updateGradInput(self, input, gradOutput):
+    def updateGradInput(self, input, gradOutput, y=None):
         # the derivative is evaluated from the ACTIVATED values; for in-place modules `input`
         # already holds them (the producer's .output was overwritten).
+        # y: this module's output restricted to the samples of the pass (Sequential._walk, group passes)
+        if y is not None and not self.inplace:
+            gx = getattr(self, "gradInput_g", None)
+            if gx is None or gx.shape != gradOutput.shape:
+                gx = self.gradInput_g = torch.empty_like(gradOutput)
+            get_backend().act_bwd(y, gradOutput, gx, self.act, self.slope)
+            return gx
         y = input if self.inplace else self.output
         if self.inplace:
             self.gradInput = gradOutput
@@ -420,9 +478,11 @@ class Sequential(Module):
         self.output = cur
         return cur
 
-    def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0):
+    def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0, group=None):
         """Backward over plan entries hi-1 .. lo (default: all of them).  A partial walk lets the caller cut the
-        pass where a gradient bucket is complete (data parallel: that bucket's all-reduce then overlaps the rest)."""
+        pass where a gradient bucket is complete (data parallel: that bucket's all-reduce then overlaps the rest).
+        group = (g, G): the pass covers group g of the G batches the last forward ran concatenated (BatchNorm.groups):
+        the saved activations are sliced to that group's samples; `input` / `gradOutput` hold that group only."""
         plan = self._plan or self._build_plan()
         B = get_backend()
         g = gradOutput
@@ -437,17 +497,27 @@ class Sequential(Module):
         for idx in range(hi - 1, lo - 1, -1):
             m, a = plan[idx]
             x = input if idx == 0 else plan[idx - 1][0].output
+            mout = m.output
+            gbuf = "gradInput"
+            if group is not None:
+                gi, G = group
+                gbuf = "gradInput_g"
+                h = mout.shape[0] // G
+                mout = mout[gi * h:(gi + 1) * h]
+                if idx > 0:
+                    x = x[gi * h:(gi + 1) * h]
             want_gx = need_input_grad or idx > 0
             if isinstance(m, SpatialBatchNormalization):
+                gsel = None if group is None else group[0]
                 if a is None:
-                    g = m._bwd(x, g, want_gx, want_gp)
+                    g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf)
                 else:
                     a.gradInput = g
-                    g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, m.output)
+                    g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, mout, group=gsel, buf=gbuf)
             else:
                 if a is not None:
                     if not act_done:
-                        B.act_bwd(m.output, g, g, a.act, a.slope)   # in place on the incoming gradient
+                        B.act_bwd(mout, g, g, a.act, a.slope)   # in place on the incoming gradient
                     a.gradInput = g
                 # the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this
                 # module's data-gradient epilogue (x IS that activated output)
@@ -456,7 +526,12 @@ class Sequential(Module):
                     pm, pa = plan[idx - 1]
                     if pa is not None and pa.act in ("lrelu", "relu") and not isinstance(pm, SpatialBatchNormalization):
                         in_act = (pa.act, pa.slope)
-                upd = (lambda: m.updateGradInput(x, g, in_act)) if in_act is not None else (lambda: m.updateGradInput(x, g))
+                if isinstance(m, SpatialConvolution):
+                    upd = lambda: m.updateGradInput(x, g, in_act, gbuf)
+                elif group is not None and isinstance(m, _Act):
+                    upd = lambda: m.updateGradInput(x, g, mout)
+                else:
+                    upd = lambda: m.updateGradInput(x, g)
                 if want_gp and self.side is not None and m.parameters():
                     # dW/db only read x and g; nothing on the main stream writes either before the join below
                     with self.side.on():
@@ -510,8 +585,16 @@ class Sequential(Module):
                     break
         return best
 
-    def updateGradInput(self, input, gradOutput):
-        return self._walk(input, gradOutput, False)
+    def updateGradInput(self, input, gradOutput, group=None):
+        """group = (g, G): see _walk — the data-gradient pass over one of the G concatenated batches."""
+        return self._walk(input, gradOutput, False, group=group)
+
+    def setBatchGroups(self, G):
+        """The next forwards carry G concatenated, independent batches (BatchNorm statistics per group)."""
+        for m in self.leaves():
+            if isinstance(m, SpatialBatchNormalization):
+                m.groups = G
+        return self
 
     def backward(self, input, gradOutput, scale=1, need_input_grad=True):
         """need_input_grad=False skips the first layer's gradInput — Torch7 always computes it, the reference

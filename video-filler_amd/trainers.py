@@ -160,9 +160,51 @@ class _TrainerBase:
         self.defer_adam_g = False
         self._pending_g = False
         self._graph_stale = False
+        self.batch_d = False         # set_batch_d(): netD's real and fake passes as one batch of 2B
+        self._cat = self._cat_df = None
 
     def _comm_on(self):
         return self.world > 1 or self.force_comm
+
+    # -- netD's two passes of fDx as ONE batch [real; fake] (single device).  The reference runs netD twice per
+    #    closure on B samples each (train.lua:331-349); the convolutions are linear in the batch and gradParameters
+    #    accumulates over the two backward calls, so one pass over 2B samples is the same arithmetic as long as every
+    #    BatchNorm keeps the two halves apart (nn.SpatialBatchNormalization.groups = 2: statistics, running averages
+    #    and backward sums per half, real first).  Twice the rows per GEMM launch and half the launches for netD.
+    def set_batch_d(self, on=True):
+        assert not (on and (self.world > 1 or self.force_comm)), "batch_d is the single-device iteration"
+        assert self._graph is None and self._graphs is None, "set_batch_d before capture()"
+        self.batch_d = bool(on)
+        self.netD.setBatchGroups(2 if on else 1)
+        return self
+
+    def _netD_both(self, real_in, fake_in):
+        B = get_backend()
+        n = real_in.shape[0]
+        shp = (2 * n,) + tuple(real_in.shape[1:])
+        if self._cat is None or tuple(self._cat.shape) != shp:
+            self._cat = B.empty_act(*shp)
+        B.copy(self._cat[:n], real_in)
+        B.copy(self._cat[n:], fake_in)
+        out = self.netD.forward(self._cat)
+        if self._cat_df is None or tuple(self._cat_df.shape) != tuple(out.shape):
+            self._cat_df = B.zeros(out.numel()).view(out.shape)
+        errD_real = self.criterion.forward(out[:n], self.real_label)
+        errD_fake = self.criterion.forward(out[n:], self.fake_label)
+        B.bce_bwd(out[:n], self.real_label, self._cat_df[:n])
+        B.bce_bwd(out[n:], self.fake_label, self._cat_df[n:])
+        self.netD.backward(self._cat, self._cat_df, need_input_grad=not self.skip_dead_grads)
+        return errD_real + errD_fake
+
+    def _netD_stale_output(self):
+        out = self.netD.output
+        return out[out.shape[0] // 2:] if self.batch_d else out
+
+    def _netD_grad_input(self, x, df_do):
+        """netD:updateGradInput(x, df_do) of fGx (train.lua:366): x is what the fake pass saw."""
+        if self.batch_d:
+            return self.netD.updateGradInput(x, df_do, group=(1, 2))
+        return self.netD.updateGradInput(x, df_do)
 
     def _allreduce_avg(self, flat):
         """RCCL all-reduce-average of a flat gradient vector.  Inside a phased step the closure
@@ -205,6 +247,11 @@ class _TrainerBase:
         if self._pending_g:
             optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
             self._pending_g = False
+
+    def _apply_pending_g_and_sweep(self):
+        if self._pending_g:
+            self._apply_pending_g()
+            self.netG.zeroConvBiases()
 
     def _wait_inflight(self):
         for h in self._inflight:
@@ -413,6 +460,16 @@ class CenterTrainer(_TrainerBase):
                     self._apply_pending_g()
                     self.netG.zeroConvBiases()
                 fake = self.netG.forward(self.input_ctx)
+        if self.batch_d:
+            assert not self._comm_on() and not self._pipelined
+            if fake is None:
+                self._apply_pending_g_and_sweep()
+                fake = self.netG.forward(self.input_ctx)
+            else:
+                self.side_g.join()
+            self.input_center = fake
+            self.errD = self._netD_both(self._real_center, fake)
+            return
         # train with real (input_center:copy(real_center): the centre crop already sits in a device buffer)
         self.input_center = self._real_center
         label = self.real_label
@@ -445,10 +502,10 @@ class CenterTrainer(_TrainerBase):
         self.netG.zeroConvBiases()
         self.netG.zeroGradParameters()
         label = self.real_label                      # fake labels are real for the generator cost
-        output = self.netD.output                    # reused from fDx (train.lua:363): stale w.r.t. D's Adam step
+        output = self._netD_stale_output()           # reused from fDx (train.lua:363): stale w.r.t. D's Adam step
         self.errG = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        df_dg = self.netD.updateGradInput(self.input_center, df_do)
+        df_dg = self._netD_grad_input(self.input_center, df_do)
         errG_total = self.errG
         if wt != 0:
             # train.lua:377-399 fused into one pass: MSE forward, MSE gradient, overlap-band weighting, wtl2 mix
@@ -515,6 +572,20 @@ class VidTrainer(_TrainerBase):
                     self._apply_pending_g()
                     self.netG.zeroConvBiases()
                 fake = self.netG.forward(self.input_ctx)
+        if self.batch_d:
+            assert not self._comm_on() and not self._pipelined
+            if fake is None:
+                self._apply_pending_g_and_sweep()
+                fake = self.netG.forward(self.input_ctx)
+            else:
+                self.side_g.join()
+            if o["weight_nomask"] == 0:
+                self.input_inpainted = self._inpaint_buf
+                B.masked_compose(self.input_inpainted, self.input_real, fake, self.input_mask)
+            else:
+                self.input_inpainted = fake
+            self.errD = self._netD_both(self.input_real, self.input_inpainted)
+            return
         label = self.real_label
         output = self.netD.forward(self.input_real)
         errD_real = self.criterion.forward(output, label)
@@ -548,10 +619,10 @@ class VidTrainer(_TrainerBase):
         self.netG.zeroConvBiases()
         self.netG.zeroGradParameters()
         label = self.real_label
-        output = self.netD.output
+        output = self._netD_stale_output()
         self.errG = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        df_dg = self.netD.updateGradInput(self.input_real, df_do)
+        df_dg = self._netD_grad_input(self.input_real, df_do)
         errG_total = self.errG
         if wtgdl != 0:                               # forward value only (train_vid_weighted.lua:524)
             self.errG_gdl = self.criterionGDL.forward(self.input_inpainted, self.input_real)
