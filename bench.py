@@ -50,8 +50,9 @@ def main():
                     help="how conv products are formed: f32_3xbf16 (default; fp32 operands split exactly into 3 bf16 planes, 6 "
                     "cross terms on the bf16 pipe, fp32 accumulate: fp32-grade), f32 (native f32 MFMA), bf16 (operands rounded: "
                     "opt-in, its own tolerance, not a headline configuration)")
-    ap.add_argument("--batch-d", action="store_true", help="N=1: netD's real and fake passes as one batch of 2B (BatchNorm in two "
-                    "groups; same arithmetic per sample)")
+    ap.add_argument("--no-batch-d", action="store_true", help="N=1: run netD's real and fake passes separately (default: one batch "
+                    "of 2B with BatchNorm in two groups; same arithmetic per sample)")
+    ap.add_argument("--batch-d", action="store_true", help="(default now at N=1; kept so that older command lines still parse)")
     ap.add_argument("--overlap", action="store_true", help="3 streams (dW beside dX, netG forward beside netD's real pass): measured "
                     "+0.7 %% on one GPU with the current kernels (noise level), so the default is one stream")
     ap.add_argument("--no-overlap", action="store_true", help="(default now; kept so that older command lines still parse)")
@@ -114,8 +115,8 @@ def main():
 
     dp = world > 1 or args.force_dist
     tr.force_comm = args.force_dist
-    if args.batch_d and not dp:
-        tr.set_batch_d(True)
+    if args.no_batch_d and tr.batch_d:
+        tr.set_batch_d(False)
     use_graph = not args.no_graph and not (dp and args.sync_bn)
     pipelined = dp and not args.no_pipeline and not args.sync_bn
     if dp:
@@ -295,6 +296,7 @@ def main():
                        "mfma": {"f32_3xbf16": "fp32 operands split exactly into 3 bf16 planes, 6 cross terms on v_mfma_f32_32x32x16_bf16, "
                                               "f32 accumulate (fp32-grade: same parity tolerances as native)",
                                 "f32": "native v_mfma_f32_32x32x2_f32", "bf16": "operands rounded to bf16"}[args.mfma],
+                       "netD_passes": "real+fake as one batch of 2B, BatchNorm per half" if tr.batch_d else "separate (as the reference)",
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -211,9 +211,11 @@ def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hi
         batch = tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(4, np.random.default_rng(5), 6))
         mk = lambda: VidTrainer(opt, seed=3)
     a, b = mk(), mk()
+    a.set_batch_d(False)          # bitwise comparison: the same GEMM shapes on both sides
     a.set_batch(*batch)
     b.set_batch(*batch)
     b.force_comm = True
+    assert not b.batch_d
     for _ in range(5):
         a.step()
     # pipelined: G's exchange and Adam(G) run behind the NEXT iteration's netD real pass; flush() completes the last one

@@ -226,8 +226,8 @@ enum { OP_ACT_FWD, OP_ACT_BWD, OP_AXPBY, OP_CMUL, OP_SCALE_SHIFT, OP_COMPOSE, OP
 
 template <int OP>
 __global__ void k_pointwise(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
-                            float* __restrict__ out, int64_t n, float f0, float f1, int act) {
-  const int64_t n4 = n >> 2;
+                            float* __restrict__ out, int64_t n, float f0, float f1, int act, int vec) {
+  const int64_t n4 = vec ? n >> 2 : 0;      // vec = 0: some operand is not 16-byte aligned (a sub-batch view of a tiny tensor)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   auto op = [&](float av, float bv, float cv, float ov) -> float {
     if constexpr (OP == OP_ACT_FWD) return vf_act_apply(av, act, f0);
@@ -263,12 +263,14 @@ template <int OP>
 static int launch_pw(vf_ctx* ctx, const float* a, const float* b, const float* c, float* out, int64_t n, float f0, float f1,
                      int act) {
   if (n <= 0) return 0;
-  VF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0,
-             "pointwise operands must be 16-byte aligned");
+  const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out;
+  VF_REQUIRE((bits & 3) == 0, "pointwise operands must be float aligned");
+  const int vec = (bits & 15) == 0;
+  VF_REQUIRE(vec || n <= (1 << 16), "pointwise operands of this size must be 16-byte aligned");
   static const char* names[] = {"pw_act_fwd", "pw_act_bwd", "pw_axpby", "pw_cmul", "pw_scale_shift", "pw_compose", "pw_mse_bwd"};
   const int nops = (a != nullptr) + (b != nullptr) + (c != nullptr) + 1 + ((OP == OP_AXPBY || OP == OP_CMUL || OP == OP_SCALE_SHIFT) ? 1 : 0);
   VfProf prof(ctx, names[OP], 0.0, 4.0 * (double)n * nops);
-  hipLaunchKernelGGL((k_pointwise<OP>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, a, b, c, out, n, f0, f1, act);
+  hipLaunchKernelGGL((k_pointwise<OP>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, a, b, c, out, n, f0, f1, act, vec);
   VF_LAUNCH_CHECK();
   return 0;
 }

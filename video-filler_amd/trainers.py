@@ -156,12 +156,24 @@ class _TrainerBase:
         self._pipelined = False      # data-parallel step with G's exchange + Adam deferred into the next iteration
         self._inflight = []          # async all-reduce handles of G's gradient buckets
         self._gen = None
-        self.force_comm = False      # run the exchange even at world == 1 (exercises the DP path on one GPU)
+        self._force_comm = False     # run the exchange even at world == 1 (exercises the DP path on one GPU)
         self.defer_adam_g = False
         self._pending_g = False
         self._graph_stale = False
         self.batch_d = False         # set_batch_d(): netD's real and fake passes as one batch of 2B
         self._cat = self._cat_df = None
+        if world == 1 and os.environ.get("VF_NO_BATCH_D") != "1":
+            self.set_batch_d(True)   # single device: measured +5 % on train.lua's nets
+
+    @property
+    def force_comm(self):
+        return self._force_comm
+
+    @force_comm.setter
+    def force_comm(self, v):
+        self._force_comm = bool(v)
+        if v and self.batch_d:       # the data-parallel iteration keeps netD's real pass separate: it is the window
+            self.set_batch_d(False)  # behind which G's gradient exchange of the previous iteration completes
 
     def _comm_on(self):
         return self.world > 1 or self.force_comm
@@ -172,7 +184,7 @@ class _TrainerBase:
     #    BatchNorm keeps the two halves apart (nn.SpatialBatchNormalization.groups = 2: statistics, running averages
     #    and backward sums per half, real first).  Twice the rows per GEMM launch and half the launches for netD.
     def set_batch_d(self, on=True):
-        assert not (on and (self.world > 1 or self.force_comm)), "batch_d is the single-device iteration"
+        assert not (on and self._comm_on()), "batch_d is the single-device iteration"
         assert self._graph is None and self._graphs is None, "set_batch_d before capture()"
         self.batch_d = bool(on)
         self.netD.setBatchGroups(2 if on else 1)
