@@ -192,6 +192,20 @@ int vf_tiles_gather(vf_ctx* ctx, const float* full, float* tiles, int groups, in
 int vf_tiles_scatter(vf_ctx* ctx, const float* tiles, float* out, int groups, int nc, int H, int W, int fs,
                      const unsigned char* vflip);
 
+/* ---- option branches of train.lua: noiseGen (:109-124, 319-327) and conditionAdv (:158-180) -----------------------
+ * nn.JoinTable(2) over NHWC tensors: dst[p][c_dst + c] = src[p][c_src + c] for c < Ccopy, p < npix (forward: one call
+ * per table element into the joined tensor; updateGradInput: one call per element out of the joined gradient).
+ * The branches' convolutions (5x5 stride 2 pad 2 / 2+32; 1x1) are served by vf_conv2d_* above: any kernel size,
+ * stride and padding is accepted there, the 4x4 shapes of the main nets take the matrix-core path. */
+int vf_channel_copy(vf_ctx* ctx, const float* src, int Csrc, int c_src, float* dst, int Cdst, int c_dst, int Ccopy,
+                    int64_t npix);
+/* noise:uniform(-1,1) (normal = 0) / noise:normal(0,1) (normal = 1), train.lua:319-323.  Counter-based: element i is a
+ * function of (seed, counter, i) only (splitmix64; Torch7's generator stream is not reproducible).  counter_dev, if
+ * not NULL, is a DEVICE int32 read at run time (e.g. Adam's step count, so a replayed HIP graph draws fresh noise
+ * every iteration); otherwise `counter` is used. */
+int vf_noise_fill(vf_ctx* ctx, float* out, int64_t n, uint64_t seed, const int32_t* counter_dev, uint64_t counter,
+                  int normal);
+
 /* ---- every weight gradient of one backward walk in one launch -----------------------------------------------------
  * Between vf_wgrad_group_begin and vf_wgrad_group_end, vf_conv2d_bwd_weight / vf_deconv2d_bwd_weight calls on this
  * context are RECORDED (the 16-byte-vectorised ones; others still launch at once) and the group — one grouped GEMM

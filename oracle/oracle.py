@@ -312,6 +312,67 @@ class View(Module):
         return self.gradInput
 
 
+class JoinTable(Module):
+    """nn.JoinTable(2) on a table of NCHW tensors (train.lua:119,172)."""
+
+    def __init__(self, dimension):
+        super().__init__()
+        assert dimension == 2
+        self.dimension = dimension
+
+    def updateOutput(self, xs):
+        self.output = np.ascontiguousarray(np.concatenate(xs, axis=1))
+        return self.output
+
+    def updateGradInput(self, xs, gy):
+        out, off = [], 0
+        for x in xs:
+            out.append(np.ascontiguousarray(gy[:, off:off + x.shape[1]]))
+            off += x.shape[1]
+        self.gradInput = out
+        return out
+
+    def parameters(self):
+        return [], []
+
+
+class ParallelTable(Module):
+    """nn.ParallelTable (train.lua:115-117,168-170): member i on table element i."""
+
+    def __init__(self):
+        super().__init__()
+        self.modules = []
+
+    def add(self, m):
+        self.modules.append(m)
+        return self
+
+    def apply(self, fn):
+        fn(self)
+        for m in self.modules:
+            m.apply(fn)
+
+    def updateOutput(self, xs):
+        self.output = [m.updateOutput(x) for m, x in zip(self.modules, xs)]
+        return self.output
+
+    def updateGradInput(self, xs, gys):
+        self.gradInput = [m.updateGradInput(x, g) for m, x, g in zip(self.modules, xs, gys)]
+        return self.gradInput
+
+    def backward(self, xs, gys, scale=1.0):
+        self.gradInput = [m.backward(x, g, scale) for m, x, g in zip(self.modules, xs, gys)]
+        return self.gradInput
+
+    def parameters(self):
+        ws, gs = [], []
+        for m in self.modules:
+            w, g = m.parameters()
+            ws += w
+            gs += g
+        return ws, gs
+
+
 class Sequential(Module):
     def __init__(self):
         super().__init__()
@@ -368,7 +429,7 @@ class Sequential(Module):
         owners = []
 
         def collect(m):
-            if isinstance(m, Sequential):
+            if isinstance(m, (Sequential, ParallelTable)):
                 for c in m.modules:
                     collect(c)
             elif hasattr(m, "weight"):
@@ -466,8 +527,10 @@ def _full(nIn, nOut, s2=True):
     return SpatialFullConvolution(nIn, nOut, 4, 4, 2, 2, 1, 1) if s2 else SpatialFullConvolution(nIn, nOut, 4, 4)
 
 
-def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth=False):
-    """train.lua:87-148 (extra_decoder_layer=False, output nc x 64 x 64) and
+def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth=False, noise_nz=0, half_last=False):
+    """noise_nz > 0: the noiseGen generator of train.lua:109-124 (input {context, noise[B, nz, 1, 1]}).
+    half_last: train_logo_withmask.lua:95-98 — the extra decoder layer is ngf -> ngf/2 (BN over ngf/2).
+    train.lua:87-148 (extra_decoder_layer=False, output nc x 64 x 64) and
     train_vid_weighted.lua:112-176 / train_wholeim_input.lua:137-199 (True, output nc_out x 128 x 128).
     smooth=True (tests only) replaces every LeakyReLU(0.2)/ReLU by LeakyReLU(1.0): same graph and kernels, but no
     derivative discontinuity, so gradients can be compared at fp32 precision."""
@@ -480,15 +543,24 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth
     netE.add(_conv(nef * 4, nef * 8)).add(SpatialBatchNormalization(nef * 8)).add(LeakyReLU(0.2, True))
     netE.add(_conv(nef * 8, nBottleneck, s2=False))
     netG = Sequential()
-    netG.add(netE)
-    netG.add(SpatialBatchNormalization(nBottleneck)).add(LeakyReLU(0.2, True))
-    netG.add(_full(nBottleneck, ngf * 8, s2=False)).add(SpatialBatchNormalization(ngf * 8)).add(ReLU(True))
+    nz_size = nBottleneck
+    if noise_nz:
+        netG_noise = Sequential().add(SpatialConvolution(noise_nz, noise_nz, 1, 1, 1, 1, 0, 0))
+        netG.add(ParallelTable().add(netE).add(netG_noise))
+        netG.add(JoinTable(2))
+        nz_size = nBottleneck + noise_nz
+    else:
+        netG.add(netE)
+    netG.add(SpatialBatchNormalization(nz_size)).add(LeakyReLU(0.2, True))
+    netG.add(_full(nz_size, ngf * 8, s2=False)).add(SpatialBatchNormalization(ngf * 8)).add(ReLU(True))
     netG.add(_full(ngf * 8, ngf * 4)).add(SpatialBatchNormalization(ngf * 4)).add(ReLU(True))
     netG.add(_full(ngf * 4, ngf * 2)).add(SpatialBatchNormalization(ngf * 2)).add(ReLU(True))
     netG.add(_full(ngf * 2, ngf)).add(SpatialBatchNormalization(ngf)).add(ReLU(True))
+    last = ngf
     if extra_decoder_layer:
-        netG.add(_full(ngf, ngf)).add(SpatialBatchNormalization(ngf)).add(ReLU(True))
-    netG.add(_full(ngf, nc_out)).add(Tanh())
+        last = ngf // 2 if half_last else ngf
+        netG.add(_full(ngf, last)).add(SpatialBatchNormalization(last)).add(ReLU(True))
+    netG.add(_full(last, nc_out)).add(Tanh())
     return netG
 
 
@@ -498,12 +570,20 @@ def _acts(smooth):
     return (lambda negval, inplace: globals()["LeakyReLU"](1.0, inplace)), (lambda inplace: globals()["LeakyReLU"](1.0, inplace))
 
 
-def build_netD(nc, ndf, extra_first_layer, smooth=False):
-    """train.lua:157-199 (64x64 input) and train_vid_weighted.lua:213-236 (128x128 input,
-    extra floor(ndf/2)-wide first layer)."""
+def build_netD(nc, ndf, extra_first_layer, smooth=False, conditionAdv=False):
+    """train.lua:157-199 (64x64 input; conditionAdv: input {context 128x128, prediction 64x64}, :158-180) and
+    train_vid_weighted.lua:213-236 (128x128 input, extra floor(ndf/2)-wide first layer)."""
     LeakyReLU, ReLU = _acts(smooth)
     netD = Sequential()
-    if extra_first_layer:
+    if conditionAdv:
+        assert not extra_first_layer
+        netD_ctx = Sequential().add(SpatialConvolution(nc, ndf, 5, 5, 2, 2, 2, 2))
+        netD_pred = Sequential().add(SpatialConvolution(nc, ndf, 5, 5, 2, 2, 2 + 32, 2 + 32))
+        netD.add(ParallelTable().add(netD_ctx).add(netD_pred))
+        netD.add(JoinTable(2))
+        netD.add(LeakyReLU(0.2, True))
+        netD.add(_conv(ndf * 2, ndf)).add(SpatialBatchNormalization(ndf)).add(LeakyReLU(0.2, True))
+    elif extra_first_layer:
         mylayer = ndf // 2
         netD.add(_conv(nc, mylayer)).add(LeakyReLU(0.2, True))
         netD.add(_conv(mylayer, ndf)).add(LeakyReLU(0.2, True))
@@ -542,7 +622,8 @@ def zero_conv_biases(net):
 
 
 DEFAULT_OPT_TRAIN = dict(batchSize=64, fineSize=128, nBottleneck=100, nef=64, ngf=64, ndf=64, nc=3, wtl2=0.0,
-                         overlapPred=0, lr=0.0002, beta1=0.5)
+                         overlapPred=0, lr=0.0002, beta1=0.5, nz=100, conditionAdv=False, noiseGen=False,
+                         noisetype="normal")
 DEFAULT_OPT_VID = dict(batchSize=16, fineSize=128, nBottleneck=4000, nef=64, ngf=64, ndf=64, nc=3, predLen=4,
                        wtl2=0.999, weight_nomask=0.05, wtgdl=0.0, overlapPred=0, lr=0.0002, beta1=0.5,
                        nc_in=None, nc_out=None)
@@ -561,10 +642,13 @@ class CenterTrainer:
         o = dict(DEFAULT_OPT_TRAIN)
         o.update(opt)
         self.opt = o
-        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, o.get("smooth", False))
-        self.netD = build_netD(o["nc"], o["ndf"], False, o.get("smooth", False))
+        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, o.get("smooth", False),
+                               noise_nz=o["nz"] if o["noiseGen"] else 0)
+        self.netD = build_netD(o["nc"], o["ndf"], False, o.get("smooth", False), conditionAdv=bool(o["conditionAdv"]))
         weights_init(self.netG, rng)
         weights_init(self.netD, rng)
+        self.noise = None                 # [B, nz, 1, 1]; set_noise() or drawn with noise_fill(seed, t)
+        self.noise_seed = 1234
         self.criterion = BCECriterion()
         self.criterionMSE = MSECriterion() if o["wtl2"] != 0 else None
         self.optimStateG, self.optimStateD = _solver(o)
@@ -575,6 +659,18 @@ class CenterTrainer:
 
     def set_batch(self, real_ctx):
         self.batch = np.ascontiguousarray(real_ctx, np.float32).copy()
+
+    def set_noise(self, noise):
+        """Fix the noise of the next iterations (tests); None: draw noise_fill(seed, Adam step of D) per iteration."""
+        self.noise_fixed = None if noise is None else np.ascontiguousarray(noise, np.float32).copy()
+
+    noise_fixed = None
+
+    def _d_in(self):
+        return [self.input_ctx, self.input_center] if self.opt["conditionAdv"] else self.input_center
+
+    def _g_in(self):
+        return [self.input_ctx, self.noise] if self.opt["noiseGen"] else self.input_ctx
 
     def fDx(self, x):
         o = self.opt
@@ -593,17 +689,23 @@ class CenterTrainer:
             self.input_real_center = real_center.copy()
         B = real_ctx.shape[0]
         label = np.full((B,), 1.0, np.float32)
-        output = self.netD.forward(self.input_center)
+        output = self.netD.forward(self._d_in())                 # train.lua:300-305
         errD_real = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        self.netD.backward(self.input_center, df_do)
-        fake = self.netG.forward(self.input_ctx)
+        self.netD.backward(self._d_in(), df_do)
+        if o["noiseGen"]:                                        # train.lua:319-323: regenerate random noise
+            if self.noise_fixed is not None:
+                self.noise = self.noise_fixed
+            else:
+                self.noise = noise_fill((B, o["nz"], 1, 1), self.noise_seed, self.optimStateD.get("t", 0),
+                                        o["noisetype"] == "normal")
+        fake = self.netG.forward(self._g_in())
         self.input_center[...] = fake
         label[...] = 0.0
-        output = self.netD.forward(self.input_center)
+        output = self.netD.forward(self._d_in())
         errD_fake = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        self.netD.backward(self.input_center, df_do)
+        self.netD.backward(self._d_in(), df_do)
         self.errD = errD_real + errD_fake
         return self.errD, self.gradParametersD
 
@@ -618,7 +720,9 @@ class CenterTrainer:
         output = self.netD.output                                  # stale w.r.t. D's Adam step (train.lua:363)
         self.errG = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        df_dg = self.netD.updateGradInput(self.input_center, df_do)
+        df_dg = self.netD.updateGradInput(self._d_in(), df_do)
+        if o["conditionAdv"]:
+            df_dg = df_dg[1]                                       # df_dg[2] because conditional GAN (train.lua:371)
         errG_total = self.errG
         if wt != 0:
             self.errG_l2 = self.criterionMSE.forward(self.input_center, self.input_real_center)
@@ -642,7 +746,7 @@ class CenterTrainer:
                 else:
                     df_dg += wtl2Matrix * df_dg_l2
                     errG_total = self.errG + wt * self.errG_l2
-        self.netG.backward(self.input_ctx, df_dg)
+        self.netG.backward(self._g_in(), df_dg)                   # train.lua:403-407
         return errG_total, self.gradParametersG
 
     def step(self):
@@ -757,6 +861,35 @@ class VidTrainer:
 
 
 # ------------------------------------------------------------------ synthetic batches
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def noise_fill(shape, seed, counter, normal=True):
+    """The backend's counter-based stand-in for noise:normal(0,1) / noise:uniform(-1,1) (train.lua:319-323; Torch7's
+    generator stream is not reproducible): element i of draw `counter` = splitmix64 of (seed, counter, i), 24-bit
+    uniforms, Box-Muller.  include/vf_hip.h: vf_noise_fill."""
+    n = int(np.prod(shape))
+    base = _splitmix64((seed ^ _splitmix64(counter & 0xFFFFFFFF)) & _M64)
+    out = np.empty(n, np.float32)
+    scale = np.float32(2.0 ** -24)
+    for i in range(n):
+        z = _splitmix64((base + i * 0xD1342543DE82EF95) & _M64)
+        u1 = np.float32((z >> 40) + 1) * scale
+        u2 = np.float32((z >> 16) & 0xFFFFFF) * scale
+        if normal:
+            out[i] = np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
+        else:
+            out[i] = np.float32(2.0) * u2 - np.float32(1.0)
+    return out.reshape(shape)
+
+
 def synth_center_batch(B, rng, nc=3, fineSize=128):
     return rng.uniform(-1.0, 1.0, (B, nc, fineSize, fineSize)).astype(np.float32)
 

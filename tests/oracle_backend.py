@@ -108,6 +108,15 @@ class OracleBackend:
         m = self._conv_mod(O.SpatialFullConvolution if full else O.SpatialConvolution, w, k, stride, pad, full)
         _put(gx, m.updateGradInput(np.empty(tuple(gx.shape), np.float32), _np(gy)))
 
+    def channel_copy(self, src, c_src, dst, c_dst, ncopy):
+        d = _np(dst).copy()
+        d[:, c_dst:c_dst + ncopy] = _np(src)[:, c_src:c_src + ncopy]
+        _put(dst, d)
+
+    def noise_fill(self, out, seed, counter=0, normal=True, counter_dev=None):
+        ctr = int(counter_dev[0]) if counter_dev is not None else counter
+        _put(out, O.noise_fill(tuple(out.shape), seed, ctr, normal))
+
     def bias_grad_multi(self, items):
         for g, gb, beta in items:
             _put(gb, np.float32(beta) * _np(gb) + _np(g).sum(axis=(0, 2, 3), dtype=np.float64).astype(np.float32))

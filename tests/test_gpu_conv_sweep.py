@@ -63,22 +63,73 @@ def test_random_shapes(case, oracle, hipb):
     assert_close(to_np(dgb), ref.gradBias - gb0, 2 * TOL, "bias grad(beta=0) %s" % (case,))
 
 
+GENERIC = [  # (B, Cin, H, Cout, k, stride, pad) — the option branches' shapes (train.lua:109-113,158-170) and others
+    (3, 3, 32, 64, 5, 2, 2),        # conditionAdv context branch (scaled: 128 -> 32)
+    (3, 3, 16, 64, 5, 2, 2 + 8),    # conditionAdv prediction branch: pad 2 + 32 on 64x64, scaled to 2 + 8 on 16x16
+    (2, 3, 64, 64, 5, 2, 2 + 32),   # the same at full size
+    (5, 100, 1, 100, 1, 1, 0),      # noiseGen: nz -> nz, 1x1 on the 1x1 noise map
+    (2, 16, 6, 32, 3, 1, 1),        # 3x3 on a map that is not a power of two
+    (2, 6, 9, 12, 4, 2, 0),         # 4x4 stride 2 without padding
+    (1, 20, 8, 130, 4, 3, 1),       # stride 3; Cout*K beyond the LDS weight stage
+    (2, 8, 8, 4, 4, 1, 0),          # 4x4 stride 1 on a map larger than the bottleneck's 4x4
+]
+
+
+@pytest.mark.parametrize("case", GENERIC)
+def test_generic_conv_shapes(case, oracle, hipb):
+    """nn.SpatialConvolution of any kernel / stride / padding (vf_conv_generic.hip) against the oracle: every pass,
+    accumulate and overwrite."""
+    B, Cin, H, Cout, k, s, p = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    r = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    ref = oracle.SpatialConvolution(Cin, Cout, k, k, s, s, p, p)
+    ref.weight[...] = r(*ref.weight.shape) * 0.05
+    ref.bias[...] = r(Cout)
+    x = r(B, Cin, H, H)
+    y = ref.forward(x)
+    gy = r(*y.shape)
+    ref.gradWeight[...] = r(*ref.weight.shape)
+    ref.gradBias[...] = r(Cout)
+    gw0, gb0 = ref.gradWeight.copy(), ref.gradBias.copy()
+    ref.backward(x, gy)
+    dx, dw, db = to_dev(x, hipb), to_dev(ref.weight, hipb), to_dev(ref.bias, hipb)
+    dy = hipb.empty_act(*y.shape)
+    hipb.conv2d_fwd(dx, dw, db, dy, k, s, p)
+    assert_close(to_np(dy), y, TOL, "fwd %s" % (case,))
+    hipb.conv2d_fwd(dx, dw, db, dy, k, s, p, "lrelu", 0.2)
+    assert_close(to_np(dy), np.where(y > 0, y, np.float32(0.2) * y), TOL, "fwd+lrelu %s" % (case,))
+    dgy, dgx = to_dev(gy, hipb), hipb.empty_act(*x.shape)
+    hipb.conv2d_bwd_data(dgy, dw, dgx, k, s, p)
+    assert_close(to_np(dgx), ref.gradInput, TOL, "bwd_data %s" % (case,))
+    dgw, dgb = to_dev(gw0, hipb), to_dev(gb0, hipb)
+    hipb.conv2d_bwd_weight(dx, dgy, dgw, dgb, k, s, p, 1.0)
+    assert_close(to_np(dgw), ref.gradWeight, TOL, "bwd_weight(beta=1) %s" % (case,))
+    assert_close(to_np(dgb), ref.gradBias, TOL, "bias grad %s" % (case,))
+    hipb.conv2d_bwd_weight(dx, dgy, dgw, dgb, k, s, p, 0.0)
+    assert_close(to_np(dgw), ref.gradWeight - gw0, 2 * TOL, "bwd_weight(beta=0) %s" % (case,))
+    assert_close(to_np(dgb), ref.gradBias - gb0, 2 * TOL, "bias grad(beta=0) %s" % (case,))
+
+
 def test_c_abi_rejects_what_the_reference_never_builds(hipb):
-    """k = 4 only, (stride, pad) in {(2,1), (1,0)}, power-of-two maps: anything else returns an error (never a wrong
-    result or a fault)."""
+    """Transposed convolutions: k = 4 only, (stride, pad) in {(2,1), (1,0)}, power-of-two maps (every
+    nn.SpatialFullConvolution of the reference); a convolution whose kernel exceeds its padded input; BatchNorm over a
+    channel count that misses the vector width: an error, never a wrong result or a fault."""
     x = hipb.empty_act(2, 16, 8, 8)
-    w = hipb.empty(32, 4, 4, 16).permute(0, 3, 1, 2)
+    w = hipb.empty(16, 4, 4, 32).permute(0, 3, 1, 2)
     b = hipb.zeros(32)
-    y = hipb.empty_act(2, 32, 4, 4)
+    y = hipb.empty_act(2, 32, 16, 16)
     with pytest.raises(RuntimeError):
-        hipb.conv2d_fwd(x, w, b, y, 3, 2, 1)              # 3x3 kernel
+        hipb.deconv2d_fwd(x, w, b, y, 3, 2, 1)            # 3x3 kernel
     with pytest.raises(RuntimeError):
-        hipb.conv2d_fwd(x, w, b, y, 4, 2, 0)              # stride 2 without pad 1
+        hipb.deconv2d_fwd(x, w, b, y, 4, 2, 0)            # stride 2 without pad 1
     with pytest.raises(RuntimeError):
-        hipb.conv2d_fwd(x, w, b, y, 4, 3, 1)              # stride 3
+        hipb.deconv2d_fwd(x, w, b, y, 4, 3, 1)            # stride 3
     x6 = hipb.empty_act(2, 16, 6, 6)                      # 6x6 map: not a power of two
     with pytest.raises(RuntimeError):
-        hipb.conv2d_fwd(x6, w, b, hipb.empty_act(2, 32, 3, 3), 4, 2, 1)
+        hipb.deconv2d_fwd(x6, w, b, hipb.empty_act(2, 32, 12, 12), 4, 2, 1)
+    wc = hipb.empty(32, 4, 4, 16).permute(0, 3, 1, 2)
+    with pytest.raises(RuntimeError, match="larger than the padded input"):
+        hipb.conv2d_fwd(hipb.empty_act(2, 16, 2, 2), wc, b, hipb.empty_act(2, 32, 1, 1), 4, 1, 0)
     bn_x = hipb.empty_act(2, 6, 4, 4)                     # BatchNorm over a channel count that is not a multiple of 4
     with pytest.raises(RuntimeError, match="multiple of 4"):
         hipb.bn_stats(bn_x, None, hipb.zeros(12, dtype=__import__("torch").float64))

@@ -178,3 +178,41 @@ def test_predict_clip_matches_oracle(oracle, hipb):
     got_in, got = predict_clip(net, torch.from_numpy(x))
     assert rel_err(to_np(got), want) < 5e-5
     np.testing.assert_array_equal(to_np(got_in), (x + np.float32(1)) * np.float32(0.5))
+
+
+@pytest.mark.parametrize("normal", [True, False])
+def test_noise_fill_matches_the_oracle_restatement(normal, oracle, hipb):
+    """vf_noise_fill (train.lua:319-323's noise:normal / noise:uniform, counter-based): same integers, so uniforms are
+    bit-exact; the normal draw differs only by the libm's logf/cosf rounding.  Keyed by (seed, counter): a device-side
+    counter gives the same stream as the host-side one."""
+    import torch
+    out = hipb.zeros(7 * 100)
+    hipb.noise_fill(out, 99, counter=5, normal=normal)
+    want = oracle.noise_fill((700,), 99, 5, normal)
+    got = to_np(out)
+    if normal:
+        assert np.abs(got - want).max() < 2e-6 * max(1.0, np.abs(want).max())
+        assert abs(got.mean()) < 0.15 and 0.85 < got.std() < 1.15
+    else:
+        assert np.array_equal(got, want) and got.min() >= -1 and got.max() < 1
+    ctr = hipb.from_host(torch.tensor([5, 0], dtype=torch.int32))
+    out2 = hipb.zeros(700)
+    hipb.noise_fill(out2, 99, counter=123, normal=normal, counter_dev=ctr)
+    assert torch.equal(out, out2)
+    hipb.noise_fill(out2, 99, counter=6, normal=normal)
+    assert not torch.equal(out, out2)
+
+
+def test_channel_copy_is_join_table(hipb):
+    import torch
+    a, b = hipb.empty_act(3, 5, 4, 4), hipb.empty_act(3, 2, 4, 4)
+    a.copy_(torch.randn(3, 5, 4, 4)); b.copy_(torch.randn(3, 2, 4, 4))
+    y = hipb.empty_act(3, 7, 4, 4)
+    hipb.channel_copy(a, 0, y, 0, 5)
+    hipb.channel_copy(b, 0, y, 5, 2)
+    assert torch.equal(y, torch.cat([a, b], dim=1))
+    back = hipb.empty_act(3, 2, 4, 4)
+    hipb.channel_copy(y, 5, back, 0, 2)
+    assert torch.equal(back, b)
+    with pytest.raises(RuntimeError):
+        hipb.channel_copy(y, 6, back, 0, 2)

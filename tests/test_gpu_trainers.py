@@ -136,6 +136,31 @@ def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle
         _resync(ref, tr)
 
 
+@pytest.mark.parametrize("smooth", [True, False])
+@pytest.mark.parametrize("variant", ["conditionAdv", "noiseGen", "both"])
+def test_center_trainer_option_branches(variant, smooth, oracle, hipb):
+    """train.lua's option branches: conditionAdv (netD over {context, prediction}: two 5x5 stride-2 convs, pad 2 and
+    2+32, joined; df_dg[2]) and noiseGen (netG over {context, noise}: 1x1 noise conv joined to the bottleneck; noise
+    drawn per iteration from the counter-based generator both sides restate).  Same bars as the main recipe."""
+    from video_filler_amd.trainers import CenterTrainer
+    opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4, smooth=smooth, nz=20,
+               conditionAdv=variant != "noiseGen", noiseGen=variant != "conditionAdv")
+    ref = oracle.CenterTrainer(opt, np.random.default_rng(1))
+    tr = CenterTrainer(opt, seed=4321)
+    ref.noise_seed = 4321
+    _load(tr, ref)
+    for it in range(2):
+        batch = oracle.synth_center_batch(3, np.random.default_rng(60 + it))
+        ref.set_batch(batch)
+        tr.set_batch(torch.from_numpy(batch))
+        ref.step()
+        tr.step()
+        if opt["noiseGen"]:
+            assert np.abs(to_np(tr.noise).reshape(ref.noise.shape) - ref.noise).max() < 1e-5
+        _check_iteration(ref, tr, it, 0.002, 0.0002, "center %s smooth=%s" % (variant, smooth), smooth)
+        _resync(ref, tr)
+
+
 @pytest.mark.parametrize("batch_d", [False, True])
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim"])

@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _HEADER = os.path.join(_HERE, "..", "include", "vf_hip.h")
 
-vp, f32, i32, i64, f64, sz = C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_double, C.c_size_t
+vp, f32, i32, i64, f64, sz, u64 = C.c_void_p, C.c_float, C.c_int, C.c_int64, C.c_double, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes); mirrors include/vf_hip.h one to one
 SIGNATURES = {
@@ -60,6 +60,8 @@ SIGNATURES = {
     "vf_clip_prepare": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp]),
     "vf_tiles_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "vf_tiles_scatter": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "vf_channel_copy": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, i64]),
+    "vf_noise_fill": (i32, [vp, vp, i64, u64, vp, u64, i32]),
     "vf_bce_fwd": (i32, [vp, vp, f32, i32, vp]),
     "vf_bce_bwd": (i32, [vp, vp, f32, vp, i32]),
     "vf_mse_fwd": (i32, [vp, vp, vp, i64, vp]),

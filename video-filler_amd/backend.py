@@ -300,6 +300,16 @@ class HipBackend:
         self._c("vf_tiles_scatter", _ptr(tiles), _ptr(out), groups, Ct // groups, H, W, fs,
                 _ptr(vflip) if vflip is not None else None)
 
+    def channel_copy(self, src, c_src, dst, c_dst, ncopy):
+        """dst[:, c_dst:c_dst+ncopy] = src[:, c_src:c_src+ncopy] on NHWC tensors of equal B, H, W (nn.JoinTable(2))."""
+        Bn, Cs, H, W = src.shape
+        assert tuple(dst.shape[0:1] + dst.shape[2:]) == (Bn, H, W)
+        self._c("vf_channel_copy", _ptr(src), Cs, c_src, _ptr(dst), dst.shape[1], c_dst, ncopy, Bn * H * W)
+
+    def noise_fill(self, out, seed, counter=0, normal=True, counter_dev=None):
+        self._c("vf_noise_fill", _ptr(out), out.numel(), int(seed), _ptr(counter_dev) if counter_dev is not None else None,
+                int(counter), 1 if normal else 0)
+
     def masked_compose(self, out, real, fake, mask):
         self._c("vf_masked_compose", _ptr(out), _ptr(real), _ptr(fake), _ptr(mask), out.numel())
 

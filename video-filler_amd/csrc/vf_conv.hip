@@ -1537,14 +1537,27 @@ static int bias_grad(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C, f
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// The option branches' convolutions (5x5 stride 2 pad 2 / 34, 1x1: train.lua:109-113,158-170) go to vf_conv_generic.hip.
+int vf_internal_gconv_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                          int Cout, int k, int stride, int pad, int act, float slope);
+int vf_internal_gconv_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx, int B, int H, int W, int Cin, int Cout,
+                               int k, int stride, int pad);
+int vf_internal_gconv_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W, int Cin,
+                                 int Cout, int k, int stride, int pad, float beta);
+static bool main_net_shape(int H, int W, int k, int stride, int pad) {
+  return k == 4 && ((stride == 2 && pad == 1) || (stride == 1 && pad == 0 && H == 4 && W == 4)) && vf_is_pow2(H) && vf_is_pow2(W);
+}
+
 VF_API int vf_conv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
                          int Cin, int Cout, int k, int stride, int pad, int act, float slope) {
+  if (!main_net_shape(H, W, k, stride, pad)) return vf_internal_gconv_fwd(ctx, x, w, bias, y, B, H, W, Cin, Cout, k, stride, pad, act, slope);
   if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
   return conv_like_fwd(ctx, x, w, bias, y, B, H, W, Cin, Cout, stride, pad, act, slope);
 }
 
 VF_API int vf_conv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx, int B, int H, int W, int Cin,
                               int Cout, int k, int stride, int pad) {
+  if (!main_net_shape(H, W, k, stride, pad)) return vf_internal_gconv_bwd_data(ctx, gy, w, gx, B, H, W, Cin, Cout, k, stride, pad);
   if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   if (stride == 1) {
@@ -1571,6 +1584,8 @@ VF_API int vf_conv2d_bwd_data_act(vf_ctx* ctx, const float* gy, const float* w, 
 
 VF_API int vf_conv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W,
                                 int Cin, int Cout, int k, int stride, int pad, float beta) {
+  if (!main_net_shape(H, W, k, stride, pad))
+    return vf_internal_gconv_bwd_weight(ctx, x, gy, gw, gb, B, H, W, Cin, Cout, k, stride, pad, beta);
   if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   if (Cout == 1 && stride == 1 && H == 4 && W == 4) {

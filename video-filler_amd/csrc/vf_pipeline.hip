@@ -181,3 +181,53 @@ VF_API int vf_tiles_scatter(vf_ctx* ctx, const float* tiles, float* out, int gro
   VF_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ table modules, noise
+// nn.JoinTable(2) forward / backward in the NHWC layout: dst[p][c_dst + c] = src[p][c_src + c], c < Cc.
+__global__ void k_channel_copy(const float* __restrict__ src, int Cs, int cs0, float* __restrict__ dst, int Cd, int cd0, int Cc,
+                               int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = i / Cc;
+    const int c = (int)(i - p * Cc);
+    dst[p * Cd + cd0 + c] = src[p * Cs + cs0 + c];
+  }
+}
+VF_API int vf_channel_copy(vf_ctx* ctx, const float* src, int Csrc, int c_src, float* dst, int Cdst, int c_dst, int Ccopy,
+                           int64_t npix) {
+  VF_REQUIRE(Ccopy > 0 && c_src >= 0 && c_dst >= 0 && c_src + Ccopy <= Csrc && c_dst + Ccopy <= Cdst && npix > 0,
+             "vf_channel_copy: channels [%d,+%d) of %d -> [%d,+%d) of %d", c_src, Ccopy, Csrc, c_dst, Ccopy, Cdst);
+  const int64_t n = npix * Ccopy;
+  VfProf prof(ctx, "channel_copy", 0.0, 8.0 * (double)n);
+  hipLaunchKernelGGL(k_channel_copy, dim3(pgrid(n)), dim3(256), 0, ctx->stream, src, Csrc, c_src, dst, Cdst, c_dst, Ccopy, n);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// noise:uniform(-1, 1) / noise:normal(0, 1) (train.lua:319-323).  Torch7's Mersenne-Twister stream cannot be reproduced;
+// element i of draw `counter` is a pure function of (seed, counter, i): splitmix64 of the 64-bit index, 24-bit
+// uniforms, Box-Muller for the normal.  The oracle restates it (oracle.noise_fill).
+__device__ __forceinline__ uint64_t vf_splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void k_noise_fill(float* __restrict__ out, int64_t n, uint64_t seed, const int32_t* __restrict__ counter_dev,
+                             uint64_t counter, int normal) {
+  const uint64_t ctr = counter_dev ? (uint64_t)(uint32_t)counter_dev[0] : counter;
+  const uint64_t base = vf_splitmix64(seed ^ vf_splitmix64(ctr));
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t z = vf_splitmix64(base + (uint64_t)i * 0xD1342543DE82EF95ull);
+    const float u1 = (float)((z >> 40) + 1) * 5.9604644775390625e-8f;            // (0, 1]
+    const float u2 = (float)((z >> 16) & 0xFFFFFF) * 5.9604644775390625e-8f;     // [0, 1)
+    out[i] = normal ? sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2) : 2.f * u2 - 1.f;
+  }
+}
+VF_API int vf_noise_fill(vf_ctx* ctx, float* out, int64_t n, uint64_t seed, const int32_t* counter_dev, uint64_t counter,
+                         int normal) {
+  VF_REQUIRE(n > 0, "vf_noise_fill: empty tensor");
+  VfProf prof(ctx, "noise_fill", 0.0, 4.0 * (double)n);
+  hipLaunchKernelGGL(k_noise_fill, dim3(pgrid(n)), dim3(256), 0, ctx->stream, out, n, seed, counter_dev, counter, normal);
+  VF_LAUNCH_CHECK();
+  return 0;
+}

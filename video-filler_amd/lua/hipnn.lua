@@ -68,6 +68,8 @@ int vf_center_prepare(vf_ctx*, const float* batch_nchw, float* ctx_nhwc, float* 
 int vf_clip_prepare(vf_ctx*, const float* clip, const float* mask, float* full, float* masked, float* maskout, int C, int iH, int iW, int fs, int w1, int h1, int flip, float mask_value, int nblocks, int block_size, const int* tlx, const int* tly);
 int vf_tiles_gather(vf_ctx*, const float* full, float* tiles, int groups, int nc, int H, int W, int fs, const unsigned char* vflip);
 int vf_tiles_scatter(vf_ctx*, const float* tiles, float* out, int groups, int nc, int H, int W, int fs, const unsigned char* vflip);
+int vf_channel_copy(vf_ctx*, const float* src, int Csrc, int c_src, float* dst, int Cdst, int c_dst, int Ccopy, int64_t npix);
+int vf_noise_fill(vf_ctx*, float* out, int64_t n, uint64_t seed, const int32_t* counter_dev, uint64_t counter, int normal);
 ]]
 
 local C = ffi.load(os.getenv('VF_HIP_LIB') or 'libvf_hip.so')

@@ -409,6 +409,113 @@ class View(Module):
         return self.gradInput
 
 
+# ---------------------------------------------------------------------------------------------- table modules
+class JoinTable(Module):
+    """nn.JoinTable(2): concatenate a table of [B, C_i, H, W] tensors along the channel dimension (train.lua:119,172).
+    Channels are the innermost axis of the device layout, so this is a strided copy per input (vf_channel_copy)."""
+    _type = "nn.JoinTable"
+
+    def __init__(self, dimension):
+        super().__init__()
+        assert dimension == 2, "the reference joins along dimension 2 (channels) only"
+        self.dimension = dimension
+
+    def updateOutput(self, input):
+        B = get_backend()
+        xs = [to_nhwc(x) for x in input]
+        Bn, _, H, W = xs[0].shape
+        y = self._buf("output", Bn, sum(x.shape[1] for x in xs), H, W)
+        off = 0
+        for x in xs:
+            assert tuple(x.shape[2:]) == (H, W) and x.shape[0] == Bn
+            B.channel_copy(x, 0, y, off, x.shape[1])
+            off += x.shape[1]
+        return y
+
+    def updateGradInput(self, input, gradOutput):
+        B = get_backend()
+        g = to_nhwc(gradOutput)
+        if self.gradInput is None or len(self.gradInput) != len(input):
+            self.gradInput = [None] * len(input)
+        off = 0
+        for i, x in enumerate(input):
+            t = self.gradInput[i]
+            if t is None or t.shape != x.shape:
+                t = self.gradInput[i] = B.empty_act(*x.shape)
+            B.channel_copy(g, off, t, 0, x.shape[1])
+            off += x.shape[1]
+        return self.gradInput
+
+
+class ParallelTable(Module):
+    """nn.ParallelTable: member i maps element i of the input table (train.lua:115-117,168-170).  Members are
+    Sequentials; `skip_grad` lists members whose gradInput nobody reads (the context branch of a conditional netD)."""
+    _type = "nn.ParallelTable"
+
+    def __init__(self):
+        super().__init__()
+        self.modules = []
+        self.skip_grad = ()
+
+    def add(self, m):
+        self.modules.append(m)
+        return self
+
+    def apply(self, fn):
+        fn(self)
+        for m in self.modules:
+            m.apply(fn)
+        return self
+
+    def leaves(self):
+        out = []
+        for m in self.modules:
+            out += m.leaves() if hasattr(m, "leaves") else [m]
+        return out
+
+    def parameters(self):
+        ws, gs = [], []
+        for m in self.leaves():
+            p = m.parameters()
+            if p:
+                ws += p[0]
+                gs += p[1]
+        return (ws, gs) if ws else None
+
+    def updateOutput(self, input):
+        assert len(input) == len(self.modules)
+        self.output = [m.forward(x) for m, x in zip(self.modules, input)]
+        return self.output
+
+    def walk(self, input, gradOutput, want_gx, want_gp):
+        """updateGradInput and/or accGradParameters of every member in one pass each."""
+        gi = []
+        for i, (m, x, g) in enumerate(zip(self.modules, input, gradOutput)):
+            need = want_gx and i not in self.skip_grad
+            if not (need or want_gp):
+                gi.append(None)
+            elif isinstance(m, Sequential):
+                gi.append(m._walk(x, g, want_gp, need))
+            else:
+                gi.append(m.updateGradInput(x, g) if need else None)
+                if want_gp:
+                    m.accGradParameters(x, g, 1)
+        if want_gx:
+            self.gradInput = gi
+        return gi
+
+    def updateGradInput(self, input, gradOutput):
+        return self.walk(input, gradOutput, True, False)
+
+    def accGradParameters(self, input, gradOutput, scale=1):
+        assert scale == 1
+        self.walk(input, gradOutput, False, True)
+
+    def backward(self, input, gradOutput, scale=1):
+        assert scale == 1
+        return self.walk(input, gradOutput, True, True)
+
+
 # ---------------------------------------------------------------------------------------------- container
 _NO_DEFER_BIAS = bool(__import__("os").environ.get("VF_NO_DEFER_BIAS"))      # A/B switches (timing experiments)
 _NO_WG_GROUP = bool(__import__("os").environ.get("VF_NO_WG_GROUP"))
@@ -416,6 +523,7 @@ _NO_WG_GROUP = bool(__import__("os").environ.get("VF_NO_WG_GROUP"))
 
 class Sequential(Module):
     _type = "nn.Sequential"
+    _group_open = False       # a backward walk has a weight-gradient group open (single-threaded host code)
 
     def __init__(self, fuse=True, lazy_zero=True):
         super().__init__()
@@ -441,12 +549,19 @@ class Sequential(Module):
     def leaves(self):
         out = []
         for m in self.modules:
-            out += m.leaves() if isinstance(m, Sequential) else [m]
+            out += m.leaves() if isinstance(m, (Sequential, ParallelTable)) else [m]
         return out
 
-    # -- execution plan: [(main, act_or_None)] over the flattened leaf list
+    def _plan_items(self):
+        """nested Sequentials flattened; a ParallelTable stays one item (its members run their own plans)"""
+        out = []
+        for m in self.modules:
+            out += m._plan_items() if isinstance(m, Sequential) else [m]
+        return out
+
+    # -- execution plan: [(main, act_or_None)] over the flattened item list
     def _build_plan(self):
-        leaves = self.leaves()
+        leaves = self._plan_items()
         plan, i = [], 0
         while i < len(leaves):
             m = leaves[i]
@@ -489,9 +604,11 @@ class Sequential(Module):
         used_side = False
         deferred = [] if (want_gp and self.fuse and hasattr(B, "bias_grad_multi") and not _NO_DEFER_BIAS) else None
         # one stream: the weight-gradient GEMMs of the walk are recorded and launched together at its end
-        grouped = want_gp and self.fuse and self.side is None and hasattr(B, "wgrad_group_begin") and not _NO_WG_GROUP
+        grouped = (want_gp and self.fuse and self.side is None and hasattr(B, "wgrad_group_begin") and not _NO_WG_GROUP
+                   and not Sequential._group_open)       # a member of a ParallelTable records into the outer walk's group
         if grouped:
             B.wgrad_group_begin()
+            Sequential._group_open = True
         hi = len(plan) if hi is None else hi
         act_done = self._act_done_at == hi if hi < len(plan) else False
         for idx in range(hi - 1, lo - 1, -1):
@@ -507,6 +624,11 @@ class Sequential(Module):
                 if idx > 0:
                     x = x[gi * h:(gi + 1) * h]
             want_gx = need_input_grad or idx > 0
+            if isinstance(m, ParallelTable):
+                assert group is None, "group passes are built for plain chains"
+                g = m.walk(x, g, want_gx, want_gp)
+                act_done = False
+                continue
             if isinstance(m, SpatialBatchNormalization):
                 gsel = None if group is None else group[0]
                 if a is None:
@@ -522,7 +644,7 @@ class Sequential(Module):
                 # the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this
                 # module's data-gradient epilogue (x IS that activated output)
                 in_act = None
-                if (self.fuse and want_gx and idx > 0 and type(m) is SpatialConvolution and m.dH == 2 and hasattr(B, "conv2d_bwd_data_act")):
+                if (self.fuse and want_gx and idx > 0 and type(m) is SpatialConvolution and m.dH == 2 and m.kH == 4 and m.padH == 1 and hasattr(B, "conv2d_bwd_data_act")):
                     pm, pa = plan[idx - 1]
                     if pa is not None and pa.act in ("lrelu", "relu") and not isinstance(pm, SpatialBatchNormalization):
                         in_act = (pa.act, pa.slope)
@@ -547,6 +669,7 @@ class Sequential(Module):
                 continue
             act_done = False
         if grouped:
+            Sequential._group_open = False
             B.wgrad_group_end()
         if deferred:
             B.bias_grad_multi(deferred)      # every deferred gradBias of this walk: two launches

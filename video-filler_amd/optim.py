@@ -15,6 +15,17 @@ def adam(opfunc, x, state):
     return x, [fx]
 
 
+def adam_init(x, state):
+    """The state optim.adam creates on its first call (m, v, t = 0); callable up front so the device step counter
+    exists before the first closure (the noise draw of train.lua:319-323 is keyed by it)."""
+    if "m" not in state:
+        state["t"] = 0
+        state["m"] = torch.zeros_like(x)
+        state["v"] = torch.zeros_like(x)
+        state["t_dev"] = get_backend().zeros(2, dtype=torch.int32)
+    return state
+
+
 def adam_update(x, dfdx, state):
     """The update half of optim.adam (everything after `local fx, dfdx = opfunc(x)`), callable on its own so a
     data-parallel step can put a gradient all-reduce between the closure and the update."""
@@ -24,9 +35,6 @@ def adam_update(x, dfdx, state):
     beta2 = state.get("beta2", 0.999)
     eps = state.get("epsilon", 1e-8)
     if "m" not in state:
-        state["t"] = 0
-        state["m"] = torch.zeros_like(x)
-        state["v"] = torch.zeros_like(x)
-        state["t_dev"] = B.zeros(2, dtype=torch.int32)
+        adam_init(x, state)
     state["t"] += 1          # host mirror of the device counter (informational)
     B.adam_step(x, dfdx, state["m"], state["v"], lr, beta1, beta2, eps, state["t_dev"])

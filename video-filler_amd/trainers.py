@@ -21,7 +21,8 @@ from . import data, nn, optim
 from .backend import get_backend, to_nhwc
 
 DEFAULT_OPT_TRAIN = dict(batchSize=64, fineSize=128, nBottleneck=100, nef=64, ngf=64, ndf=64, nc=3, wtl2=0.0,
-                         overlapPred=0, lr=0.0002, beta1=0.5)
+                         overlapPred=0, lr=0.0002, beta1=0.5, nz=100, conditionAdv=False, noiseGen=False,
+                         noisetype="normal")
 DEFAULT_OPT_VID = dict(batchSize=16, fineSize=128, nBottleneck=4000, nef=64, ngf=64, ndf=64, nc=3, predLen=4,
                        wtl2=0.999, weight_nomask=0.05, wtgdl=0.0, overlapPred=0, lr=0.0002, beta1=0.5,
                        nc_in=None, nc_out=None)
@@ -56,8 +57,11 @@ def _acts(smooth):
     return (lambda negval, inplace: nn.LeakyReLU(1.0, inplace)), (lambda inplace: nn.LeakyReLU(1.0, inplace))
 
 
-def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=True, lazy_zero=True, smooth=False):
-    """train.lua:87-148 (64x64 output) / train_vid_weighted.lua:112-176 (extra ngf->ngf layer, 128x128 output)."""
+def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=True, lazy_zero=True, smooth=False, noise_nz=0,
+               half_last=False):
+    """train.lua:87-148 (64x64 output) / train_vid_weighted.lua:112-176 (extra ngf->ngf layer, 128x128 output).
+    noise_nz > 0: the noiseGen generator (train.lua:109-124), input {context, noise [B, nz, 1, 1]};
+    half_last: train_logo_withmask.lua:95-98, the extra decoder layer is ngf -> ngf/2."""
     BN = nn.SpatialBatchNormalization
     LReLU, ReLU = _acts(smooth)
     netE = nn.Sequential(fuse, lazy_zero)
@@ -68,24 +72,43 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=T
     netE.add(_conv(nef * 4, nef * 8)).add(BN(nef * 8)).add(LReLU(0.2, True))
     netE.add(_conv(nef * 8, nBottleneck, s2=False))
     netG = nn.Sequential(fuse, lazy_zero)
-    netG.add(netE)
-    netG.add(BN(nBottleneck)).add(LReLU(0.2, True))
-    netG.add(_full(nBottleneck, ngf * 8, s2=False)).add(BN(ngf * 8)).add(ReLU(True))
+    nz_size = nBottleneck
+    if noise_nz:
+        netG_noise = nn.Sequential(fuse, lazy_zero).add(nn.SpatialConvolution(noise_nz, noise_nz, 1, 1, 1, 1, 0, 0))
+        netG.add(nn.ParallelTable().add(netE).add(netG_noise))
+        netG.add(nn.JoinTable(2))
+        nz_size = nBottleneck + noise_nz
+    else:
+        netG.add(netE)
+    netG.add(BN(nz_size)).add(LReLU(0.2, True))
+    netG.add(_full(nz_size, ngf * 8, s2=False)).add(BN(ngf * 8)).add(ReLU(True))
     netG.add(_full(ngf * 8, ngf * 4)).add(BN(ngf * 4)).add(ReLU(True))
     netG.add(_full(ngf * 4, ngf * 2)).add(BN(ngf * 2)).add(ReLU(True))
     netG.add(_full(ngf * 2, ngf)).add(BN(ngf)).add(ReLU(True))
+    last = ngf
     if extra_decoder_layer:
-        netG.add(_full(ngf, ngf)).add(BN(ngf)).add(ReLU(True))
-    netG.add(_full(ngf, nc_out)).add(nn.Tanh())
+        last = ngf // 2 if half_last else ngf
+        netG.add(_full(ngf, last)).add(BN(last)).add(ReLU(True))
+    netG.add(_full(last, nc_out)).add(nn.Tanh())
     return netG
 
 
-def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True, smooth=False):
-    """train.lua:157-199 (64x64 input) / train_vid_weighted.lua:213-236 (extra floor(ndf/2) layer, 128x128 input)."""
+def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True, smooth=False, conditionAdv=False):
+    """train.lua:157-199 (64x64 input) / train_vid_weighted.lua:213-236 (extra floor(ndf/2) layer, 128x128 input).
+    conditionAdv (train.lua:158-180): input {context 128x128, prediction 64x64}, two 5x5 stride-2 branches joined."""
     BN = nn.SpatialBatchNormalization
     LReLU, _ = _acts(smooth)
     netD = nn.Sequential(fuse, lazy_zero)
-    if extra_first_layer:
+    if conditionAdv:
+        assert not extra_first_layer
+        netD_ctx = nn.Sequential(fuse, lazy_zero).add(nn.SpatialConvolution(nc, ndf, 5, 5, 2, 2, 2, 2))
+        # 32: to keep the scaling of the features the same as the context's (train.lua:166)
+        netD_pred = nn.Sequential(fuse, lazy_zero).add(nn.SpatialConvolution(nc, ndf, 5, 5, 2, 2, 2 + 32, 2 + 32))
+        netD.add(nn.ParallelTable().add(netD_ctx).add(netD_pred))
+        netD.add(nn.JoinTable(2))
+        netD.add(LReLU(0.2, True))
+        netD.add(_conv(ndf * 2, ndf)).add(BN(ndf)).add(LReLU(0.2, True))
+    elif extra_first_layer:
         mylayer = ndf // 2
         netD.add(_conv(nc, mylayer)).add(LReLU(0.2, True))
         netD.add(_conv(mylayer, ndf)).add(LReLU(0.2, True))
@@ -178,6 +201,10 @@ class _TrainerBase:
     def _comm_on(self):
         return self.world > 1 or self.force_comm
 
+    def _g_in(self):
+        """what netG:forward / netG:backward receive (a table when the generator takes noise, train.lua:326,404)"""
+        return self.input_ctx
+
     # -- netD's two passes of fDx as ONE batch [real; fake] (single device).  The reference runs netD twice per
     #    closure on B samples each (train.lua:331-349); the convolutions are linear in the batch and gradParameters
     #    accumulates over the two backward calls, so one pass over 2B samples is the same arithmetic as long as every
@@ -236,9 +263,9 @@ class _TrainerBase:
         need = not self.skip_dead_grads
         if self._split_g is not None:
             k, _ = self._split_g
-            self._g_mid = self.netG.backward_range(self.input_ctx, df_dg, None, k, need)
+            self._g_mid = self.netG.backward_range(self._g_in(), df_dg, None, k, need)
             return
-        self.netG.backward(self.input_ctx, df_dg, need_input_grad=need)
+        self.netG.backward(self._g_in(), df_dg, need_input_grad=need)
         self._allreduce_avg(self.gradParametersG)
 
     def step(self):
@@ -302,7 +329,7 @@ class _TrainerBase:
     def _phase_b2(self):
         k, _ = self.netG.bucket_split()
         if k > 0:
-            self.netG.backward_range(self.input_ctx, self._g_mid, k, 0, not self.skip_dead_grads)
+            self.netG.backward_range(self._g_in(), self._g_mid, k, 0, not self.skip_dead_grads)
 
     def _phase_c(self):
         optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
@@ -434,12 +461,45 @@ class CenterTrainer(_TrainerBase):
         o.update(opt or {})
         self.opt = o
         sm = bool(o.get("smooth", False))
-        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, fuse, lazy_zero, sm)
-        self.netD = build_netD(o["nc"], o["ndf"], False, fuse, lazy_zero, sm)
+        self.netG = build_netG(o["nc"], o["nc"], o["nef"], o["ngf"], o["nBottleneck"], False, fuse, lazy_zero, sm,
+                               noise_nz=o["nz"] if o["noiseGen"] else 0)
+        self.netD = build_netD(o["nc"], o["ndf"], False, fuse, lazy_zero, sm, conditionAdv=bool(o["conditionAdv"]))
+        if o["conditionAdv"] and skip_dead_grads:
+            self.netD.modules[0].skip_grad = (0,)     # nobody reads the gradient w.r.t. the context (train.lua:371)
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn))
+        if o["conditionAdv"] and self.batch_d:
+            self.set_batch_d(False)                   # a table-input netD keeps its two passes
         self.real_label, self.fake_label = 1, 0
         self.input_ctx = self.input_center = self.input_real_center = self._real_center = None
+        self.noise = self._noise_fixed = None
+        self.noise_seed = seed
+        if o["noiseGen"]:
+            optim.adam_init(self.parametersD, self.optimStateD)   # the noise draw is keyed by D's step counter
+
+    def set_noise(self, noise):
+        """Fix the generator's noise input (tests); None: a fresh draw per iteration (train.lua:319-323)."""
+        self._noise_fixed = None if noise is None else to_nhwc(get_backend().from_host(noise).float())
+
+    def _d_in(self, center):
+        """netD's input: {input_ctx, input_center} when conditionAdv (train.lua:300-301)"""
+        return [self.input_ctx, center] if self.opt["conditionAdv"] else center
+
+    def _g_in(self):
+        return [self.input_ctx, self.noise] if self.opt["noiseGen"] else self.input_ctx
+
+    def _netG_forward(self):
+        o = self.opt
+        if o["noiseGen"]:                     # regenerate random noise (train.lua:319-323)
+            if self._noise_fixed is not None:
+                self.noise = self._noise_fixed
+            else:
+                Bn = self.input_ctx.shape[0]
+                if self.noise is None or self.noise.shape[0] != Bn:
+                    self.noise = get_backend().empty_act(Bn, o["nz"], 1, 1)
+                get_backend().noise_fill(self.noise, self.noise_seed, normal=o["noisetype"] == "normal",
+                                         counter_dev=self.optimStateD["t_dev"])
+        return self.netG.forward(self._g_in())
 
     def set_batch(self, real_ctx):
         """What train.lua:284-298 does on the loader's batch (a B x nc x fineSize x fineSize tensor in [-1,1]):
@@ -471,12 +531,12 @@ class CenterTrainer(_TrainerBase):
                 if self._pending_g:               # deferred Adam(G) of the previous iteration, then the bias sweep
                     self._apply_pending_g()
                     self.netG.zeroConvBiases()
-                fake = self.netG.forward(self.input_ctx)
+                fake = self._netG_forward()
         if self.batch_d:
             assert not self._comm_on() and not self._pipelined
             if fake is None:
                 self._apply_pending_g_and_sweep()
-                fake = self.netG.forward(self.input_ctx)
+                fake = self._netG_forward()
             else:
                 self.side_g.join()
             self.input_center = fake
@@ -485,25 +545,25 @@ class CenterTrainer(_TrainerBase):
         # train with real (input_center:copy(real_center): the centre crop already sits in a device buffer)
         self.input_center = self._real_center
         label = self.real_label
-        output = self.netD.forward(self.input_center)
+        output = self.netD.forward(self._d_in(self.input_center))
         errD_real = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        self.netD.backward(self.input_center, df_do, need_input_grad=not self.skip_dead_grads)
+        self.netD.backward(self._d_in(self.input_center), df_do, need_input_grad=not self.skip_dead_grads)
         yield "generator parameters needed"
         # train with fake
         if fake is None:
             if self._pending_g:
                 self._apply_pending_g()
                 self.netG.zeroConvBiases()
-            fake = self.netG.forward(self.input_ctx)
+            fake = self._netG_forward()
         else:
             self.side_g.join()
         self.input_center = fake               # input_center:copy(fake): netD reads the generator's output buffer
         label = self.fake_label
-        output = self.netD.forward(self.input_center)
+        output = self.netD.forward(self._d_in(self.input_center))
         errD_fake = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        self.netD.backward(self.input_center, df_do, need_input_grad=not self.skip_dead_grads)
+        self.netD.backward(self._d_in(self.input_center), df_do, need_input_grad=not self.skip_dead_grads)
         self.errD = errD_real + errD_fake
         self._allreduce_avg(self.gradParametersD)
 
@@ -517,7 +577,9 @@ class CenterTrainer(_TrainerBase):
         output = self._netD_stale_output()           # reused from fDx (train.lua:363): stale w.r.t. D's Adam step
         self.errG = self.criterion.forward(output, label)
         df_do = self.criterion.backward(output, label)
-        df_dg = self._netD_grad_input(self.input_center, df_do)
+        df_dg = self._netD_grad_input(self._d_in(self.input_center), df_do)
+        if o["conditionAdv"]:
+            df_dg = df_dg[1]                         # df_dg[2] because conditional GAN (train.lua:371)
         errG_total = self.errG
         if wt != 0:
             # train.lua:377-399 fused into one pass: MSE forward, MSE gradient, overlap-band weighting, wtl2 mix
