@@ -766,10 +766,14 @@ class VidTrainer:
         nc = o["nc"] * o["predLen"]
         self.nc_in = o["nc_in"] or nc
         self.nc_out = o["nc_out"] or nc
-        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, o.get("smooth", False))
+        # logoNet: train_logo_withmask.lua:95-98 — the last decoder stage is ngf -> ngf/2 -> nc; its closures are this
+        # class's with predLen = 1, weight_nomask = 1 (weights of ones), wtgdl = 0
+        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, o.get("smooth", False),
+                               half_last=bool(o.get("logoNet", False)))
         self.netD = build_netD(self.nc_out, o["ndf"], True, o.get("smooth", False))
         weights_init(self.netG, rng)
         weights_init(self.netD, rng)
+        self.netI = None                  # withInit: the initializer net (train_vid_weighted.lua:260-264), set by the caller
         self.criterion = BCECriterion()
         self.criterionMSE = MSECriterion() if o["wtl2"] != 0 else None
         self.criterionGDL = GDLCriterion(1) if o["wtgdl"] != 0 else None
@@ -791,6 +795,10 @@ class VidTrainer:
         self.input_ctx = real_ctx.copy()
         self.input_real = real_full.copy()
         self.input_mask = real_mask.astype(np.float32)            # input_mask:copy(real_mask), Byte -> Float
+        if self.netI is not None:                                  # train_vid_weighted.lua:401-405 (netI as loaded:
+            fake_init = self.netI.forward(self.input_ctx)          #  training mode, batch statistics)
+            sel = self.input_mask != 0                             # inpaint_utils.fillIn, 4-D mask: maskedCopy
+            self.input_ctx[sel] = fake_init[sel]
         B = real_ctx.shape[0]
         label = np.full((B,), 1.0, np.float32)
         output = self.netD.forward(self.input_real)

@@ -163,12 +163,18 @@ def test_center_trainer_option_branches(variant, smooth, oracle, hipb):
 
 @pytest.mark.parametrize("batch_d", [False, True])
 @pytest.mark.parametrize("smooth", [True, False])
-@pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim"])
+@pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim", "logoNet", "withInit"])
 def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
-    from video_filler_amd.trainers import VidTrainer
+    from video_filler_amd.trainers import VidTrainer, build_netG
     if variant == "weighted":          # train_vid_weighted.lua defaults, predLen = 2
         opt = dict(nBottleneck=64, predLen=2)
         nc_in = nc_out = 6
+    elif variant == "logoNet":         # train_logo_withmask.lua: decoder ends ngf -> ngf/2 -> nc; plain L2, D sees the raw output
+        opt = dict(nBottleneck=64, predLen=1, weight_nomask=1, wtgdl=0, logoNet=True)
+        nc_in = nc_out = 3
+    elif variant == "withInit":        # train_vid_weighted.lua:401-405: initializer net + fillIn before the closures
+        opt = dict(nBottleneck=64, predLen=1)
+        nc_in = nc_out = 3
     elif variant == "nomask0_gdl":     # weight_nomask = 0 -> masked compose; GDL value path
         opt = dict(nBottleneck=64, predLen=1, weight_nomask=0, wtgdl=0.5)
         nc_in = nc_out = 3
@@ -180,6 +186,15 @@ def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
     tr = VidTrainer(opt)
     tr.set_batch_d(batch_d)
     _load(tr, ref)
+    if variant == "withInit":
+        rI = oracle.build_netG(3, 3, 16, 16, 32, True, smooth)
+        oracle.weights_init(rI, np.random.default_rng(8))
+        pI, _ = rI.getParameters()
+        hI = build_netG(3, 3, 16, 16, 32, True, smooth=smooth)
+        hI.getParameters()
+        hI.load_reference_flat(torch.from_numpy(pI.copy()).to(tr.parametersG.device))
+        ref.netI = rI
+        tr.set_initializer(hI)
     for it in range(2):
         ctx, full, mask = oracle.synth_vid_batch(4, np.random.default_rng(20 + it), nc_in, nc_out)   # B = 4: BatchNorm over
         # the 1x1 bottleneck needs more than 2 samples to be well conditioned

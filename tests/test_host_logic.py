@@ -228,6 +228,49 @@ def test_vid_trainer_closures_match_oracle(variant, batch_d, cpu_backend):
     assert rel_err(tr.netG.reference_flat(grads=True).numpy(), ref.gradParametersG) < 2e-5
 
 
+@pytest.mark.parametrize("variant", ["logoNet", "withInit"])
+def test_vid_trainer_option_branches_match_oracle(variant, cpu_backend):
+    """train_logo_withmask.lua's generator (last decoder stage ngf -> ngf/2) and train_vid_weighted.lua's withInit path
+    (initializer net in training mode, inpaint_utils.fillIn, then the usual closures)."""
+    from video_filler_amd.trainers import VidTrainer, build_netG
+    from oracle import oracle as O
+    if variant == "logoNet":
+        opt = dict(SMALL, predLen=1, weight_nomask=1, wtgdl=0, logoNet=True)
+    else:
+        opt = dict(SMALL, predLen=1)
+    ref = O.VidTrainer(opt, np.random.default_rng(2))
+    tr = VidTrainer(opt)
+    if variant == "logoNet":
+        assert tr.netG.leaves()[-2].nInputPlane == SMALL["ngf"] // 2
+    else:
+        rI = O.build_netG(3, 3, 8, 8, 16, True)
+        O.weights_init(rI, np.random.default_rng(8))
+        pI, _ = rI.getParameters()
+        hI = build_netG(3, 3, 8, 8, 16, True)
+        hI.getParameters()
+        hI.load_reference_flat(torch.from_numpy(pI.copy()))
+        ref.netI = rI
+        tr.set_initializer(hI)
+    _load(tr, ref)
+    ctx, full, mask = O.synth_vid_batch(3, np.random.default_rng(9), 3)
+    ref.set_batch(ctx, full, mask)
+    tr.set_batch(torch.from_numpy(ctx), torch.from_numpy(full), torch.from_numpy(mask))
+    ref.step()
+    tr.step()
+    got = tr.losses()
+    for k in ("errD", "errG", "errG_l2"):
+        want = getattr(ref, k)
+        assert abs(got[k] - want) < 1e-5 * max(1, abs(want)), k
+    assert rel_err(tr.netD.reference_flat(grads=True).numpy(), ref.gradParametersD) < 2e-5
+    assert rel_err(tr.netG.reference_flat(grads=True).numpy(), ref.gradParametersG) < 2e-5
+    if variant == "withInit":
+        np.testing.assert_array_equal(tr.input_ctx.numpy(), ctx)          # the loader's batch is left intact
+        assert rel_err(tr._ctx_filled.numpy(), ref.input_ctx) < 1e-6
+        rb = [m for m in rI.modules[0].modules if hasattr(m, "running_mean")][0]
+        hb = [m for m in hI.leaves() if hasattr(m, "running_mean")][0]
+        assert rel_err(hb.running_mean.numpy(), rb.running_mean) < 1e-5    # netI ran in training mode on both sides
+
+
 def test_checkpoint_roundtrip(tmp_path, cpu_backend):
     from video_filler_amd import util
     from video_filler_amd.trainers import build_netG, weights_init

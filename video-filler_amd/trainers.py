@@ -608,8 +608,13 @@ class VidTrainer(_TrainerBase):
         self.nc_in = o["nc_in"] or nc
         self.nc_out = o["nc_out"] or nc
         sm = bool(o.get("smooth", False))
-        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, fuse, lazy_zero, sm)
+        # logoNet: train_logo_withmask.lua:95-98 (last decoder stage ngf -> ngf/2 -> nc); that script's closures are
+        # this class's with predLen = 1, weight_nomask = 1 (weights of ones) and wtgdl = 0
+        self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, fuse, lazy_zero, sm,
+                               half_last=bool(o.get("logoNet", False)))
         self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero, sm)
+        self.netI = None                 # withInit: set_initializer(net) (train_vid_weighted.lua:260-264)
+        self._ctx_filled = None
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self.criterionGDL = nn.GDLCriterion(1) if o["wtgdl"] != 0 else None
         self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn))
@@ -632,6 +637,28 @@ class VidTrainer(_TrainerBase):
         self.input_ctx, self.input_real, self.input_mask = self._real_ctx, self._real_full, self._real_mask
         self.input_inpainted = self._inpaint_buf
 
+    def set_initializer(self, netI):
+        """opt.withInit: `netI = util.load(opt.initName)` (train_vid_weighted.lua:260-264).  The script never calls
+        netI:evaluate(), so the net runs as loaded — training mode, batch statistics — and so it does here."""
+        assert self._graph is None and self._graphs is None, "set_initializer before capture()"
+        self.netI = netI
+        return self
+
+    def _g_in(self):
+        return self._ctx_filled if self.netI is not None else self.input_ctx
+
+    def _fill_from_initializer(self):
+        """fake_init = netI:forward(input_ctx); input_ctx = inpainter.fillIn(input_ctx, input_mask, fake_init)
+        (train_vid_weighted.lua:401-405).  The filled clip goes to its own buffer: the loader's batch stays intact
+        for a replayed graph."""
+        if self.netI is None:
+            return
+        fake_init = self.netI.forward(self.input_ctx)
+        assert fake_init.shape == self.input_ctx.shape, "inpaint_utils.fillIn: src and dst must have the same size"
+        if self._ctx_filled is None or self._ctx_filled.shape != self.input_ctx.shape:
+            self._ctx_filled = torch.empty_like(self.input_ctx)
+        get_backend().masked_compose(self._ctx_filled, self.input_ctx, fake_init, self.input_mask)
+
     def _fDx_gen(self):
         B, o = get_backend(), self.opt
         early_g = self.side_g is not None and not self._pipelined
@@ -639,18 +666,19 @@ class VidTrainer(_TrainerBase):
         if not self._pending_g:
             self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
+        self._fill_from_initializer()
         fake = None
         if early_g:                            # netG forward beside netD's real pass (independent work)
             with self.side_g.on():
                 if self._pending_g:
                     self._apply_pending_g()
                     self.netG.zeroConvBiases()
-                fake = self.netG.forward(self.input_ctx)
+                fake = self.netG.forward(self._g_in())
         if self.batch_d:
             assert not self._comm_on() and not self._pipelined
             if fake is None:
                 self._apply_pending_g_and_sweep()
-                fake = self.netG.forward(self.input_ctx)
+                fake = self.netG.forward(self._g_in())
             else:
                 self.side_g.join()
             if o["weight_nomask"] == 0:
@@ -670,7 +698,7 @@ class VidTrainer(_TrainerBase):
             if self._pending_g:
                 self._apply_pending_g()
                 self.netG.zeroConvBiases()
-            fake = self.netG.forward(self.input_ctx)
+            fake = self.netG.forward(self._g_in())
         else:
             self.side_g.join()
         if o["weight_nomask"] == 0:                  # train_vid_weighted.lua:429-432
