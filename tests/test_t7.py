@@ -154,6 +154,36 @@ def test_checkpoint_roundtrip_through_util(which, tmp_path, cpu_backend):
     assert torch.equal(other.reference_flat(), net.reference_flat())
 
 
+def test_checkpoint_roundtrip_of_the_table_nets(tmp_path, cpu_backend):
+    """The conditionAdv netD and the noiseGen netG (nn.ParallelTable + nn.JoinTable, 5x5 and 1x1 convolutions) through
+    util.save / util.load: same module tree, same flat parameters, same evaluate-mode function."""
+    from video_filler_amd import util, nn
+    from video_filler_amd.trainers import build_netG, build_netD, weights_init
+    gen = torch.Generator().manual_seed(5)
+    chl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    for name, net, x in (
+            ("netD_cond", build_netD(3, 8, False, conditionAdv=True),
+             [chl(torch.rand((2, 3, 128, 128), generator=gen)), chl(torch.rand((2, 3, 64, 64), generator=gen))]),
+            ("netG_noise", build_netG(3, 3, 8, 8, 16, False, noise_nz=12),
+             [chl(torch.rand((2, 3, 128, 128), generator=gen)), chl(torch.randn((2, 12, 1, 1), generator=gen))])):
+        weights_init(net, gen)
+        net.getParameters()
+        path = str(tmp_path / (name + ".t7"))
+        util.save(path, net)
+        tree = t7.load(path)
+        first = tree["modules"][1]
+        assert first.cls == "nn.ParallelTable" and tree["modules"][2].cls == "nn.JoinTable" and tree["modules"][2]["dimension"] == 2
+        back = util.load(path)
+        assert isinstance(back.modules[0], nn.ParallelTable) and isinstance(back.modules[1], nn.JoinTable)
+        assert [m.type_name() for m in back.leaves()] == [m.type_name() for m in net.leaves()]
+        back.getParameters()
+        assert torch.equal(back.reference_flat(), net.reference_flat())
+        net.evaluate()
+        back.evaluate()
+        y0 = net.forward(x).clone()
+        assert torch.equal(y0, back.forward(x))
+
+
 def test_reads_pre_2016_running_std(cpu_backend):
     """nn before 2016 stored running_std = 1/sqrt(var + eps) (util.lua:46 copies running_std)."""
     var = np.array([0.5, 2.0, 1.0], np.float32)

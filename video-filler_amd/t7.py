@@ -251,6 +251,10 @@ def net_to_t7(net):
     def conv(m):
         if isinstance(m, Sequential):
             return base(m, "nn.Sequential", modules=[conv(c) for c in m.modules])
+        if isinstance(m, nn.ParallelTable):         # train.lua:115,168 (noiseGen / conditionAdv nets)
+            return base(m, "nn.ParallelTable", modules=[conv(c) for c in m.modules])
+        if isinstance(m, nn.JoinTable):
+            return base(m, "nn.JoinTable", dimension=m.dimension, size=np.zeros((0,), np.int64))
         if isinstance(m, nn.SpatialFullConvolution) or isinstance(m, nn.SpatialConvolution):
             f = dict(nInputPlane=m.nInputPlane, nOutputPlane=m.nOutputPlane, kW=m.kW, kH=m.kH, dW=m.dW, dH=m.dH, padW=m.padW,
                      padH=m.padH, weight=host(m.weight), bias=host(m.bias))
@@ -298,6 +302,12 @@ def net_from_t7(obj, fuse=True, lazy_zero=True):
             for m in lua_list(f["modules"]):
                 s.add(conv(m))
             m = s
+        elif c == "nn.ParallelTable":
+            m = nn.ParallelTable()
+            for sub in lua_list(f["modules"]):
+                m.add(conv(sub))
+        elif c == "nn.JoinTable":
+            m = nn.JoinTable(int(f["dimension"]))
         elif c in ("nn.SpatialConvolution", "nn.SpatialFullConvolution", "cudnn.SpatialConvolution", "cudnn.SpatialFullConvolution"):
             cls = nn.SpatialFullConvolution if "Full" in c else nn.SpatialConvolution
             m = cls(f["nInputPlane"], f["nOutputPlane"], f["kW"], f["kH"], f["dW"], f["dH"], f.get("padW", 0), f.get("padH", 0))
