@@ -113,6 +113,7 @@ struct IGemm {
   int parity;                      // 1: z&3 = (ph<<1)|pw shifts oy0/ox0/ooy0/oox0 and selects kh0/kw0
   int gm, gn, gz;                  // logical grid (the launch is 1-D, remapped per XCD)
   int ksplit, nk, nq;              // K steps (of 32), number of splits, 16-wide chunks on the vector path
+  int klin;                        // K order of the vector path: 1 = tap outer, channel chunk inner (see next_chunk)
   int dbg;                         // ablation switch (timing experiments only; wrong results): 1 = no operand reload
   long long* stamps;               // timing experiments only: 8 stamp slots per block (VF_IGEMM_STAMPS=<file>)
   int act;
@@ -254,8 +255,17 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     // chunk order: channel chunk OUTER, tap INNER — the 16 taps of one channel chunk touch the same input window, so
     // the re-reads are temporally close (L1/L2 hits) instead of one full window sweep per tap
     it_q = 2 * kt0;
-    it_c0 = (it_q / ntaps) << 4;
-    it_tap = it_q % ntaps;
+    if (p.klin) {
+      // a 1x1 output map (the bottleneck layers) has no window overlap between taps to exploit; walking K in memory
+      // order instead makes each weight row a single forward stream of 128-byte lines per block rather than 64-byte
+      // pieces 2 KB apart (the 131 MB weight matrix is what this GEMM is bounded by)
+      const int cpt = p.C >> 4;
+      it_tap = it_q / cpt;
+      it_c0 = (it_q - it_tap * cpt) << 4;
+    } else {
+      it_c0 = (it_q / ntaps) << 4;
+      it_tap = it_q % ntaps;
+    }
   }
   auto next_chunk = [&]() {
     Chunk c;
@@ -265,7 +275,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     c.dW = (unsigned)(sW_0 + th * sW_th + tw * sW_tw + it_c0 * sW_c);
     c.ok = it_q < p.nq;
     ++it_q;
-    if (++it_tap >= ntaps) {
+    if (p.klin) {
+      it_c0 += 16;
+      if (it_c0 >= p.C) {
+        it_c0 = 0;
+        ++it_tap;
+      }
+    } else if (++it_tap >= ntaps) {
       it_tap = 0;
       it_c0 += 16;
     }
@@ -1154,6 +1170,8 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
   static const int tune_dbg = getenv("VF_IGEMM_DBG") ? atoi(getenv("VF_IGEMM_DBG")) : 0;
   g.dbg = tune_dbg;
+  static const int tune_klin = getenv("VF_NO_KLIN") ? 0 : 1;
+  g.klin = tune_klin && !g.parity && g.lgMh == 0 && g.lgMw == 0 && g.TH * g.TW > 1;
   g.gm = gm; g.gn = gn; g.gz = zpar * ksplit;
   dim3 grid((unsigned)gm * gn * zpar * ksplit);
   // timing experiments only: per-block stamps; every 32nd launch is synchronised and appended to the file
