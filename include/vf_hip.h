@@ -123,6 +123,18 @@ int vf_bn_bwd_apply(vf_ctx* ctx, const float* x, const float* y_act, const float
 int vf_bn_bwd(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
               float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
               int64_t npix, int C, int act, float slope, float pbeta);
+/* The same two calls over a batch that is the concatenation of `groups` independent batches of npix_per_group pixels
+ * each (netD's real and fake passes of one closure run as one tensor, train.lua:300-349): statistics, running-average
+ * updates and backward sums are per group, in group order — exactly what `groups` separate calls would compute, in one
+ * launch per stage.  save_mean / save_invstd are [groups][C], sums is [groups][2C]; gamma/beta gradients accumulate the
+ * groups' contributions in order (pbeta applies to the first). */
+int vf_bn_train_fwd_groups(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                           double* sums, int64_t npix_per_group, int C, int groups, float momentum, float eps,
+                           int act, float slope);
+int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                     float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
+                     double* sums, int64_t npix_per_group, int C, int groups, int act, float slope, float pbeta);
 
 /* ---- pointwise modules (nn.LeakyReLU / ReLU / Tanh / Sigmoid; train.lua:90,146,196) --------- */
 int vf_act_fwd(vf_ctx* ctx, const float* x, float* y, int64_t n, int act, float slope); /* y may alias x */

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_close, to_dev, to_np
+from helpers import assert_close, rel_err, to_dev, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -338,6 +338,57 @@ def test_batchnorm_fused_entry_points(shape, act, oracle, hipb):
     assert_close(to_np(dgx), ref.gradInput, 5e-5, "bn fused gradInput")
     assert_close(to_np(gg), ref.gradWeight, 2e-5, "bn fused gradWeight")
     assert_close(to_np(gb), ref.gradBias, 2e-5, "bn fused gradBias")
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 8, 8), (4, 128, 32, 32), (16, 512, 4, 4), (6, 100, 1, 1)])
+@pytest.mark.parametrize("act", ["none", "lrelu"])
+def test_batchnorm_batch_groups_equal_separate_calls(shape, act, hipb):
+    """vf_bn_train_fwd_groups / vf_bn_bwd_groups over [real; fake] against two vf_bn_train_fwd / vf_bn_bwd calls on the
+    halves: same outputs, saved statistics, running averages (updated real first, then fake) and accumulated
+    gamma/beta gradients.  The grouped form takes both halves' sums about the SAME shift (the running mean before the
+    first update) where the second separate call uses the once-updated one: identical in exact arithmetic, a few fp32
+    ulps apart in practice — hence 2e-6, not bitwise."""
+    B, C, H, W = shape
+    G, h = 2, B // 2
+    gen = torch.Generator().manual_seed(B * C + H)
+    r = lambda *sh: torch.randn(sh, generator=gen)
+    x = to_dev((r(B, C, H, W) * 1.5 + 0.3).numpy(), hipb)
+    gy = to_dev(r(B, C, H, W).numpy(), hipb)
+    gamma, beta = hipb.from_host(1 + 0.1 * r(C)), hipb.from_host(0.1 * r(C))
+    rm0, rv0 = hipb.from_host(0.2 * r(C)), hipb.from_host(1 + 0.1 * r(C).abs())
+    slope = 0.2
+    f64 = torch.float64
+    # separate calls
+    rm, rv = rm0.clone(), rv0.clone()
+    y = hipb.empty_act(B, C, H, W)
+    gx = hipb.empty_act(B, C, H, W)
+    sm, si, su = [hipb.zeros(C) for _ in range(G)], [hipb.zeros(C) for _ in range(G)], [hipb.zeros(2 * C, dtype=f64) for _ in range(G)]
+    gg, gb = hipb.from_host(r(C)), hipb.from_host(r(C))
+    gg0, gb0 = gg.clone(), gb.clone()
+    for g in range(G):
+        sl = slice(g * h, (g + 1) * h)
+        hipb.bn_train_fwd(x[sl], y[sl], gamma, beta, rm, rv, sm[g], si[g], su[g], 0.1, 1e-5, act, slope)
+    for g in range(G):
+        sl = slice(g * h, (g + 1) * h)
+        hipb.bn_bwd(x[sl], y[sl] if act != "none" else None, gy[sl], gx[sl], gg, gb, gamma, sm[g], si[g], su[g], act, slope,
+                    0.5 if g == 0 else 1.0)
+    # grouped
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    y2, gx2 = hipb.empty_act(B, C, H, W), hipb.empty_act(B, C, H, W)
+    gm, gs, gsum = hipb.zeros(G * C), hipb.zeros(G * C), hipb.zeros(G * 2 * C, dtype=f64)
+    gg2, gb2 = gg0.clone(), gb0.clone()
+    hipb.bn_train_fwd_groups(x, y2, gamma, beta, rm2, rv2, gm, gs, gsum, G, 0.1, 1e-5, act, slope)
+    hipb.bn_bwd_groups(x, y2 if act != "none" else None, gy, gx2, gg2, gb2, gamma, gm, gs, gsum, G, act, slope, 0.5)
+    tol = 2e-6
+    assert rel_err(to_np(y2), to_np(y)) < tol
+    assert rel_err(to_np(gx2), to_np(gx)) < 5 * tol
+    assert rel_err(to_np(gm), to_np(torch.cat(sm))) < tol and rel_err(to_np(gs), to_np(torch.cat(si))) < tol
+    assert rel_err(to_np(rm2), to_np(rm)) < tol and rel_err(to_np(rv2), to_np(rv)) < tol
+    assert rel_err(to_np(gg2), to_np(gg)) < 5 * tol and rel_err(to_np(gb2), to_np(gb)) < 5 * tol
+    # a pass over ONE group with that group's row of the saved state (fGx's third netD pass)
+    gx3 = hipb.empty_act(h, C, H, W)
+    hipb.bn_bwd(x[h:], y2[h:] if act != "none" else None, gy[h:], gx3, None, None, gamma, gm[C:], gs[C:], gsum[2 * C:], act, slope, 1.0)
+    assert rel_err(to_np(gx3), to_np(gx[h:])) < 5 * tol
 
 
 @pytest.mark.parametrize("case", [(2, 64, 16, 64, "lrelu"), (3, 16, 8, 32, "relu"), (64, 64, 64, 64, "lrelu"), (5, 64, 4, 128, "lrelu"),

@@ -45,6 +45,8 @@ SIGNATURES = {
     "vf_bn_bwd_stats": (i32, [vp] * 6 + [i64, i32, i32, f32]),
     "vf_bn_bwd_apply": (i32, [vp] * 11 + [i64, i64, i32, i32, f32, f32]),
     "vf_bn_bwd": (i32, [vp] * 11 + [i64, i32, i32, f32, f32]),
+    "vf_bn_train_fwd_groups": (i32, [vp] * 10 + [i64, i32, i32, f32, f32, i32, f32]),
+    "vf_bn_bwd_groups": (i32, [vp] * 11 + [i64, i32, i32, i32, f32, f32]),
     "vf_act_fwd": (i32, [vp, vp, vp, i64, i32, f32]),
     "vf_act_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32]),
     "vf_axpby": (i32, [vp, f32, vp, f32, vp, i64]),

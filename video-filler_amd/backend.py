@@ -229,6 +229,21 @@ class HipBackend:
         self._c("vf_bn_train_fwd", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(save_mean),
                 _ptr(save_invstd), _ptr(sums), B * H * W, Cc, momentum, eps, ACT[act], slope)
 
+    def bn_train_fwd_groups(self, x, y, gamma, beta, rm, rv, save_mean, save_invstd, sums, groups, momentum, eps,
+                            act="none", slope=0.0):
+        """x = `groups` concatenated batches; save_mean / save_invstd [groups][C], sums [groups][2C] (vf_hip.h)."""
+        B, Cc, H, W = x.shape
+        assert B % groups == 0 and save_mean.numel() == groups * Cc and sums.numel() == groups * 2 * Cc
+        self._c("vf_bn_train_fwd_groups", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(save_mean),
+                _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, momentum, eps, ACT[act], slope)
+
+    def bn_bwd_groups(self, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, groups, act="none",
+                      slope=0.0, pbeta=1.0):
+        B, Cc, H, W = x.shape
+        assert B % groups == 0 and save_mean.numel() == groups * Cc and sums.numel() == groups * 2 * Cc
+        self._c("vf_bn_bwd_groups", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
+                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, ACT[act], slope, pbeta)
+
     def bn_eval_fwd(self, x, y, gamma, beta, rm, rv, eps, act="none", slope=0.0):
         B, Cc, H, W = x.shape
         self._c("vf_bn_eval_fwd", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), B * H * W, Cc, eps,

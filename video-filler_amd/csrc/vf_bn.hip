@@ -57,6 +57,9 @@ static int bn_stat_blocks(int64_t npix, int C, int bytes_per_block) {
 // ---- forward statistics: partial[slab][2][C] (double)
 __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, const float* __restrict__ shift,
                                                   double* __restrict__ part, int64_t npix, int C, int cq, int rows_per_block) {
+  // blockIdx.z = batch group (netD's real and fake halves in one tensor): rows [z*npix, (z+1)*npix), its own partials
+  x += (int64_t)blockIdx.z * npix * C;
+  part += (int64_t)blockIdx.z * gridDim.x * 2 * C;
   const int rp = 256 / cq;
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
   const int c4 = blockIdx.y * cq + tx;
@@ -104,8 +107,12 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
                                                          double* __restrict__ sums, float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
                                                          float* __restrict__ save_invstd, double n, float momentum, float eps,
-                                                         float* __restrict__ gb, float beta) {
+                                                         float* __restrict__ gb, float beta, int groups) {
   const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  if constexpr (EPI == 0) {       // blockIdx.y = batch group: its own partials and totals
+    part += (int64_t)blockIdx.y * nslab * ncol;
+    sums += (int64_t)blockIdx.y * ncol;
+  }
   int col;
   bool ok;
   if constexpr (EPI == 1) {
@@ -117,47 +124,60 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
     col = blockIdx.x * 4 + slot;
     ok = col < ncol;
   }
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  if (ok) {
-    const double* p = part + col;
-    int k = lane;
-    for (; k + 192 < nslab; k += 256) {
-      s0 += p[(int64_t)k * ncol];
-      s1 += p[(int64_t)(k + 64) * ncol];
-      s2 += p[(int64_t)(k + 128) * ncol];
-      s3 += p[(int64_t)(k + 192) * ncol];
+  auto column_total = [&](const double* pbase) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (ok) {
+      const double* p = pbase + col;
+      int k = lane;
+      for (; k + 192 < nslab; k += 256) {
+        s0 += p[(int64_t)k * ncol];
+        s1 += p[(int64_t)(k + 64) * ncol];
+        s2 += p[(int64_t)(k + 128) * ncol];
+        s3 += p[(int64_t)(k + 192) * ncol];
+      }
+      for (; k < nslab; k += 64) s0 += p[(int64_t)k * ncol];
     }
-    for (; k < nslab; k += 64) s0 += p[(int64_t)k * ncol];
-  }
-  double t = (s0 + s1) + (s2 + s3);
+    double t = (s0 + s1) + (s2 + s3);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    return t;
+  };
   if constexpr (EPI == 0) {
+    const double t = column_total(part);
     if (lane == 0 && ok) sums[col] = t;
   } else if constexpr (EPI == 2) {
+    const double t = column_total(part);
     if (lane == 0 && ok) gb[col] = (beta != 0.f ? beta * gb[col] : 0.f) + (float)t;
   } else {
+    // groups > 1: the batch groups are finalized one after the other, as separate forward calls would — every group's
+    // sums were taken about the SAME shift (the running mean before the first update), the running averages move once
+    // per group in group order
     __shared__ double tot[4];
-    if (lane == 0) tot[slot] = t;
-    __syncthreads();
-    if (lane == 0 && ok && (slot & 1) == 0) {
-      const int C = ncol >> 1;
-      const int c = blockIdx.x * 2 + (slot >> 1);
-      const double q1 = tot[slot], q2 = tot[slot + 1];
-      if (sums) {
-        sums[c] = q1;
-        sums[C + c] = q2;
+    const int C = ncol >> 1;
+    const int c = blockIdx.x * 2 + (slot >> 1);
+    double shift = 0;
+    if (ok) shift = running_mean[c];
+    for (int g = 0; g < groups; ++g) {
+      const double t = column_total(part + (int64_t)g * nslab * ncol);
+      __syncthreads();
+      if (lane == 0) tot[slot] = t;
+      __syncthreads();
+      if (lane == 0 && ok && (slot & 1) == 0) {
+        const double q1 = tot[slot], q2 = tot[slot + 1];
+        if (sums) {
+          sums[(int64_t)g * ncol + c] = q1;
+          sums[(int64_t)g * ncol + C + c] = q2;
+        }
+        const double mean = shift + q1 / n;
+        double m2 = q2 - q1 * q1 / n;  // = sum (x - mean)^2
+        if (m2 < 0) m2 = 0;
+        const float invstd = (m2 == 0 && eps == 0.f) ? 0.f : (float)(1.0 / sqrt(m2 / n + (double)eps));
+        save_mean[(int64_t)g * C + c] = (float)mean;
+        save_invstd[(int64_t)g * C + c] = invstd;
+        running_mean[c] = (float)(momentum * mean + (1.0 - momentum) * running_mean[c]);
+        const double unbiased = m2 / (n - 1.0);  // n == 1 -> inf/NaN, as the reference
+        running_var[c] = (float)(momentum * unbiased + (1.0 - momentum) * running_var[c]);
       }
-      const double shift = running_mean[c];
-      const double mean = shift + q1 / n;
-      double m2 = q2 - q1 * q1 / n;  // = sum (x - mean)^2
-      if (m2 < 0) m2 = 0;
-      const float invstd = (m2 == 0 && eps == 0.f) ? 0.f : (float)(1.0 / sqrt(m2 / n + (double)eps));
-      save_mean[c] = (float)mean;
-      save_invstd[c] = invstd;
-      running_mean[c] = (float)(momentum * mean + (1.0 - momentum) * running_mean[c]);
-      const double unbiased = m2 / (n - 1.0);  // n == 1 -> inf/NaN, as the reference
-      running_var[c] = (float)(momentum * unbiased + (1.0 - momentum) * running_var[c]);
     }
   }
 }
@@ -230,6 +250,10 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, f
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                   int64_t npix, int C, int cq, int rows_per_block, int act, float slope) {
+  x += (int64_t)blockIdx.z * npix * C;        // batch group z: its rows, its statistics
+  y += (int64_t)blockIdx.z * npix * C;
+  mean += (int64_t)blockIdx.z * C;
+  invstd += (int64_t)blockIdx.z * C;
   const int rp = 256 / cq;
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
   const int c4 = blockIdx.y * cq + tx;
@@ -260,6 +284,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ 
                                                       const float* __restrict__ gy, const float* __restrict__ mean,
                                                       double* __restrict__ part, int64_t npix, int C, int cq,
                                                       int rows_per_block, int act, float slope) {
+  {
+    const int64_t go = (int64_t)blockIdx.z * npix * C;      // batch group z
+    x += go;
+    gy += go;
+    if (yact) yact += go;
+    mean += (int64_t)blockIdx.z * C;
+    part += (int64_t)blockIdx.z * gridDim.x * 2 * C;
+  }
   const int rp = 256 / cq;
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
   const int c4 = blockIdx.y * cq + tx;
@@ -314,26 +346,43 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
   const int c4 = blockIdx.y * cq + tx;
   if (c4 >= (C >> 2)) return;
+  if (blockIdx.x == 0 && blockIdx.z == 0 && ty == 0) {
+    // gamma/beta gradients: the groups' contributions in group order, each rounded to fp32 and accumulated as the
+    // separate backward calls would (pbeta on the first, 1 on the rest)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = (ggamma && pbeta != 0.f) ? pbeta * ggamma[4 * c4 + e] : 0.f;
+      float gb = (gbeta && pbeta != 0.f) ? pbeta * gbeta[4 * c4 + e] : 0.f;
+      for (int g = 0; g < (int)gridDim.z; ++g) {
+        const double sm = sums[(int64_t)g * 2 * C + 4 * c4 + e], dp = sums[(int64_t)g * 2 * C + C + 4 * c4 + e];
+        gg = gg + (float)(dp * invstd[(int64_t)g * C + 4 * c4 + e]);
+        gb = gb + (float)sm;
+      }
+      if (ggamma) ggamma[4 * c4 + e] = gg;
+      if (gbeta) gbeta[4 * c4 + e] = gb;
+    }
+  }
+  if (!gx) return;
+  {
+    const int64_t go = (int64_t)blockIdx.z * npix * C;      // batch group z
+    x += go;
+    gy += go;
+    gx += go;
+    if (yact) yact += go;
+    mean += (int64_t)blockIdx.z * C;
+    invstd += (int64_t)blockIdx.z * C;
+    sums += (int64_t)blockIdx.z * 2 * C;
+  }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(npix, r0 + rows_per_block);
   const f32x4 mu = *(const f32x4*)(mean + 4 * c4), is = *(const f32x4*)(invstd + 4 * c4);
   const f32x4 ga = gamma ? *(const f32x4*)(gamma + 4 * c4) : f32x4{1, 1, 1, 1};
   f32x4 kk, gm;
-  double sum[4], dotp[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    sum[e] = sums[4 * c4 + e];
-    dotp[e] = sums[C + 4 * c4 + e];
-    kk[e] = (float)(dotp[e] * is[e] * is[e] / n);
-    gm[e] = (float)(sum[e] / n);
+    const double sum = sums[4 * c4 + e], dotp = sums[C + 4 * c4 + e];
+    kk[e] = (float)(dotp * is[e] * is[e] / n);
+    gm[e] = (float)(sum / n);
   }
-  if (blockIdx.x == 0 && ty == 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (ggamma) ggamma[4 * c4 + e] = (pbeta != 0.f ? pbeta * ggamma[4 * c4 + e] : 0.f) + (float)(dotp[e] * is[e]);
-      if (gbeta) gbeta[4 * c4 + e] = (pbeta != 0.f ? pbeta * gbeta[4 * c4 + e] : 0.f) + (float)sum[e];
-    }
-  }
-  if (!gx) return;
   for (int64_t r = r0 + ty; r < r1; r += rp) {
     const int64_t o = r * C + 4 * c4;
     f32x4 g = *(const f32x4*)(gy + o);
@@ -414,10 +463,10 @@ __global__ __launch_bounds__(256) void k_reduce_bias_multi(const VfColsumDesc* _
 }
 
 // ================================================================================================ host
-static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C) {
-  hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4)), dim3(256), 0, ctx->stream,
+static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C, int groups = 1) {
+  hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4), groups), dim3(256), 0, ctx->stream,
                      (const double*)vf_ws_ptr(ctx), g.gx, 2 * C, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                     (float*)nullptr, 0.0, 0.f, 0.f, (float*)nullptr, 0.f);
+                     (float*)nullptr, 0.0, 0.f, 0.f, (float*)nullptr, 0.f, 1);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -441,7 +490,7 @@ int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C,
   VF_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_reduce_partials<2>), dim3((int)vf_cdiv(C, 4)), dim3(256), 0, ctx->stream, (const double*)part, nslab,
                      C, (double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.0, 0.f, 0.f,
-                     gb, beta);
+                     gb, beta, 1);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -476,24 +525,50 @@ VF_API int vf_bn_apply(vf_ctx* ctx, const float* x, float* y, const float* gamma
   return 0;
 }
 
-VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
-                           int64_t npix, int C, float momentum, float eps, int act, float slope) {
+static int bn_apply_groups(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, const float* mean,
+                           const float* invstd, int64_t npix, int C, int groups, int act, float slope) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  const BnGeom g = bn_geom(npix, C);
+  VfProf prof(ctx, "bn_apply", 0.0, 8.0 * (double)npix * C * groups);
+  hipLaunchKernelGGL(k_bn_apply, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, y, gamma, beta, mean, invstd, npix, C,
+                     g.cq, g.rows_per_block, act, slope);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+static int bn_train_fwd_groups(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
+                               int64_t npix, int C, int groups, float momentum, float eps, int act, float slope) {
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  VF_REQUIRE(groups >= 1 && groups <= 64, "BatchNorm batch groups: %d", groups);
   const BnGeom g = bn_geom(npix, C, bn_stat_blocks(npix, C, 32768));
-  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
+  VF_REQUIRE((size_t)groups * g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
   {
-    VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C);
-    hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, (const float*)running_mean,
+    VfProf prof(ctx, "bn_stats", 0.0, 4.0 * (double)npix * C * groups);
+    hipLaunchKernelGGL(k_bn_stats, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, (const float*)running_mean,
                        (double*)vf_ws_ptr(ctx), npix, C, g.cq, g.rows_per_block);
     VF_LAUNCH_CHECK();
     // second stage + finalize in one launch (the single-device path needs no hook between them)
     hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 2)), dim3(256), 0, ctx->stream, (const double*)vf_ws_ptr(ctx),
                        g.gx, 2 * C, sums, running_mean, running_var, save_mean, save_invstd, (double)npix, momentum, eps,
-                       (float*)nullptr, 0.f);
+                       (float*)nullptr, 0.f, groups);
     VF_LAUNCH_CHECK();
   }
-  return vf_bn_apply(ctx, x, y, gamma, beta, save_mean, save_invstd, npix, C, act, slope);
+  return bn_apply_groups(ctx, x, y, gamma, beta, save_mean, save_invstd, npix, C, groups, act, slope);
+}
+
+VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
+                           int64_t npix, int C, float momentum, float eps, int act, float slope) {
+  return bn_train_fwd_groups(ctx, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, sums, npix, C, 1, momentum,
+                             eps, act, slope);
+}
+
+VF_API int vf_bn_train_fwd_groups(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
+                                  int64_t npix_per_group, int C, int groups, float momentum, float eps, int act, float slope) {
+  return bn_train_fwd_groups(ctx, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, sums, npix_per_group, C,
+                             groups, momentum, eps, act, slope);
 }
 
 VF_API int vf_bn_eval_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
@@ -508,38 +583,59 @@ VF_API int vf_bn_eval_fwd(vf_ctx* ctx, const float* x, float* y, const float* ga
   return vf_bn_apply(ctx, x, y, gamma, beta, mean, invstd, npix, C, act, slope);
 }
 
-VF_API int vf_bn_bwd_stats(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, const float* save_mean,
-                           double* sums, int64_t npix, int C, int act, float slope) {
+static int bn_bwd_stats_groups(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, const float* save_mean,
+                               double* sums, int64_t npix, int C, int groups, int act, float slope) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "fused activation backward needs the activated output");
+  VF_REQUIRE(groups >= 1 && groups <= 64, "BatchNorm batch groups: %d", groups);
   const BnGeom g = bn_geom(npix, C, bn_stat_blocks(npix, C, 16384));
-  VF_REQUIRE((size_t)g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
-  VfProf prof(ctx, "bn_bwd_stats", 0.0, 4.0 * (double)npix * C * (act != VF_ACT_NONE ? 3 : 2));
-  hipLaunchKernelGGL(k_bn_bwd_stats, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, save_mean, (double*)vf_ws_ptr(ctx),
-                     npix, C, g.cq, g.rows_per_block, act, slope);
+  VF_REQUIRE((size_t)groups * g.gx * 2 * C * sizeof(double) <= vf_ws_avail(ctx), "workspace too small for BN partials");
+  VfProf prof(ctx, "bn_bwd_stats", 0.0, 4.0 * (double)npix * C * groups * (act != VF_ACT_NONE ? 3 : 2));
+  hipLaunchKernelGGL(k_bn_bwd_stats, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, y_act, gy, save_mean,
+                     (double*)vf_ws_ptr(ctx), npix, C, g.cq, g.rows_per_block, act, slope);
   VF_LAUNCH_CHECK();
-  return run_stats(ctx, g, sums, C);
+  return run_stats(ctx, g, sums, C, groups);
 }
 
-VF_API int vf_bn_bwd_apply(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
-                           float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
-                           const double* sums, int64_t npix, int64_t n_total, int C, int act, float slope, float pbeta) {
+static int bn_bwd_apply_groups(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                               float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
+                               const double* sums, int64_t npix, int64_t n_total, int C, int groups, int act, float slope,
+                               float pbeta) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   const BnGeom g = bn_geom(npix, C);
-  VfProf prof(ctx, "bn_bwd_apply", 0.0, gx ? 4.0 * (double)npix * C * (act != VF_ACT_NONE ? 4 : 3) : 0.0);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y_act, gy, gx, ggamma, gbeta, gamma,
+  VfProf prof(ctx, "bn_bwd_apply", 0.0, gx ? 4.0 * (double)npix * C * groups * (act != VF_ACT_NONE ? 4 : 3) : 0.0);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, y_act, gy, gx, ggamma, gbeta, gamma,
                      save_mean, save_invstd, sums, npix, (double)n_total, C, g.cq, g.rows_per_block, act, slope, pbeta);
   VF_LAUNCH_CHECK();
   return 0;
 }
 
+VF_API int vf_bn_bwd_stats(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, const float* save_mean,
+                           double* sums, int64_t npix, int C, int act, float slope) {
+  return bn_bwd_stats_groups(ctx, x, y_act, gy, save_mean, sums, npix, C, 1, act, slope);
+}
+
+VF_API int vf_bn_bwd_apply(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                           float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
+                           const double* sums, int64_t npix, int64_t n_total, int C, int act, float slope, float pbeta) {
+  return bn_bwd_apply_groups(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix, n_total, C, 1, act,
+                             slope, pbeta);
+}
+
 VF_API int vf_bn_bwd(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
                      float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
                      int64_t npix, int C, int act, float slope, float pbeta) {
-  VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "fused activation backward needs the activated output");
-  if (int rc = vf_bn_bwd_stats(ctx, x, y_act, gy, save_mean, sums, npix, C, act, slope)) return rc;
-  return vf_bn_bwd_apply(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix, npix, C, act, slope,
-                         pbeta);
+  if (int rc = bn_bwd_stats_groups(ctx, x, y_act, gy, save_mean, sums, npix, C, 1, act, slope)) return rc;
+  return bn_bwd_apply_groups(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix, npix, C, 1, act,
+                             slope, pbeta);
+}
+
+VF_API int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                            float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
+                            int64_t npix_per_group, int C, int groups, int act, float slope, float pbeta) {
+  if (int rc = bn_bwd_stats_groups(ctx, x, y_act, gy, save_mean, sums, npix_per_group, C, groups, act, slope)) return rc;
+  return bn_bwd_apply_groups(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix_per_group,
+                             npix_per_group, C, groups, act, slope, pbeta);
 }
 
 // ---- all bias gradients of a backward walk (see VfColsumDesc)

@@ -1154,7 +1154,9 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     // (tried: 256 x 64 tiles — four 64x64 wave tiles stacked in M, one block per CU — for the N = 64 layers: 153 us
     //  against 125 us for E2's data-gradient; one wave per SIMD does not cover its own LDS/global latency)
   }
-  static const int tune_split_blocks = getenv("VF_SPLIT_BLOCKS") ? atoi(getenv("VF_SPLIT_BLOCKS")) : 512;
+  // the weight-streaming bottleneck GEMMs (M <= 64) want every CU's three LDS slots filled: more bytes in flight
+  static const int env_split_blocks = getenv("VF_SPLIT_BLOCKS") ? atoi(getenv("VF_SPLIT_BLOCKS")) : 0;
+  const int tune_split_blocks = env_split_blocks ? env_split_blocks : (g.M <= 64 ? 768 : 512);
   const int gm = (int)vf_cdiv(g.M, t.bm), gn = (int)vf_cdiv(g.N, t.bn);
   const int64_t blocks = (int64_t)gm * gn * zpar;
   int ksplit = 1;

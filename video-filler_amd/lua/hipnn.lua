@@ -46,6 +46,8 @@ int vf_deconv2d_bwd_weight(vf_ctx*, const float* x, const float* gy, float* gw, 
 int vf_bn_train_fwd(vf_ctx*, const float* x, float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums, int64_t npix, int C, float momentum, float eps, int act, float slope);
 int vf_bn_eval_fwd(vf_ctx*, const float* x, float* y, const float* gamma, const float* beta, const float* running_mean, const float* running_var, int64_t npix, int C, float eps, int act, float slope);
 int vf_bn_bwd(vf_ctx*, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma, float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums, int64_t npix, int C, int act, float slope, float pbeta);
+int vf_bn_train_fwd_groups(vf_ctx*, const float* x, float* y, const float* gamma, const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums, int64_t npix_per_group, int C, int groups, float momentum, float eps, int act, float slope);
+int vf_bn_bwd_groups(vf_ctx*, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma, float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums, int64_t npix_per_group, int C, int groups, int act, float slope, float pbeta);
 int vf_act_fwd(vf_ctx*, const float* x, float* y, int64_t n, int act, float slope);
 int vf_act_bwd(vf_ctx*, const float* y, const float* gy, float* gx, int64_t n, int act, float slope);
 int vf_axpby(vf_ctx*, float a, const float* x, float b, float* y, int64_t n);

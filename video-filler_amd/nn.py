@@ -221,7 +221,12 @@ class SpatialBatchNormalization(Module):
         if self.train and self.groups > 1:
             assert self.sync_world == 1 and Bn % self.groups == 0
             h = Bn // self.groups
-            for g, (sm, ss, su) in enumerate(self._group_state()):
+            state = self._group_state()
+            if hasattr(B, "bn_train_fwd_groups"):       # all groups: one launch per stage
+                B.bn_train_fwd_groups(input, y, self.weight, self.bias, self.running_mean, self.running_var, self._gmean,
+                                      self._gstd, self._gsums, self.groups, self.momentum, self.eps, act, slope)
+                return y
+            for g, (sm, ss, su) in enumerate(state):
                 xg, yg = input[g * h:(g + 1) * h], y[g * h:(g + 1) * h]
                 if hasattr(B, "bn_train_fwd"):
                     B.bn_train_fwd(xg, yg, self.weight, self.bias, self.running_mean, self.running_var, sm, ss, su,
@@ -246,11 +251,15 @@ class SpatialBatchNormalization(Module):
         return y
 
     def _group_state(self):
+        """per-group (save_mean, save_std, sums): rows of one [groups][C] / [groups][2C] allocation each, so that one
+        kernel launch can serve every group (vf_bn_*_groups)"""
         if self._gsave is None or len(self._gsave) != self.groups:
             B = get_backend()
-            n = self.nOutputPlane
-            self._gsave = [(self.save_mean, self.save_std, self._sums)] + [
-                (B.zeros(n), B.zeros(n), B.zeros(2 * n, dtype=torch.float64)) for _ in range(self.groups - 1)]
+            n, G = self.nOutputPlane, self.groups
+            self._gmean, self._gstd = B.zeros(G * n), B.zeros(G * n)
+            self._gsums = B.zeros(G * 2 * n, dtype=torch.float64)
+            self._gsave = [(self._gmean[g * n:(g + 1) * n], self._gstd[g * n:(g + 1) * n],
+                            self._gsums[g * 2 * n:(g + 1) * 2 * n]) for g in range(G)]
         return self._gsave
 
     def _bwd(self, input, gradOutput, want_gx, want_gp, act="none", slope=0.0, y_act=None, group=None, buf="gradInput"):
@@ -282,6 +291,10 @@ class SpatialBatchNormalization(Module):
                 one(input, y_act, gradOutput, gx, state[group], pbeta)
                 return gx
             h = Bn // self.groups
+            if hasattr(B, "bn_bwd_groups"):
+                B.bn_bwd_groups(input, y_act, gradOutput, gx, gw, gb, self.weight, self._gmean, self._gstd, self._gsums,
+                                self.groups, act, slope, pbeta)
+                return gx
             for g, st in enumerate(state):
                 sl = slice(g * h, (g + 1) * h)
                 one(input[sl], None if y_act is None else y_act[sl], gradOutput[sl], None if gx is None else gx[sl], st,
