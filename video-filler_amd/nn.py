@@ -222,7 +222,7 @@ class SpatialBatchNormalization(Module):
             assert self.sync_world == 1 and Bn % self.groups == 0
             h = Bn // self.groups
             state = self._group_state()
-            if hasattr(B, "bn_train_fwd_groups"):       # all groups: one launch per stage
+            if hasattr(B, "bn_train_fwd_groups") and not _NO_BN_GROUPS:       # all groups: one launch per stage
                 B.bn_train_fwd_groups(input, y, self.weight, self.bias, self.running_mean, self.running_var, self._gmean,
                                       self._gstd, self._gsums, self.groups, self.momentum, self.eps, act, slope)
                 return y
@@ -291,7 +291,7 @@ class SpatialBatchNormalization(Module):
                 one(input, y_act, gradOutput, gx, state[group], pbeta)
                 return gx
             h = Bn // self.groups
-            if hasattr(B, "bn_bwd_groups"):
+            if hasattr(B, "bn_bwd_groups") and not _NO_BN_GROUPS:
                 B.bn_bwd_groups(input, y_act, gradOutput, gx, gw, gb, self.weight, self._gmean, self._gstd, self._gsums,
                                 self.groups, act, slope, pbeta)
                 return gx
@@ -532,6 +532,7 @@ class ParallelTable(Module):
 # ---------------------------------------------------------------------------------------------- container
 _NO_DEFER_BIAS = bool(__import__("os").environ.get("VF_NO_DEFER_BIAS"))      # A/B switches (timing experiments)
 _NO_WG_GROUP = bool(__import__("os").environ.get("VF_NO_WG_GROUP"))
+_NO_BN_GROUPS = bool(__import__("os").environ.get("VF_NO_BN_GROUPS"))
 
 
 class Sequential(Module):
