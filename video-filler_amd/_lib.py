@@ -88,7 +88,8 @@ def header_symbols():
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libvf_hip.so")
+    """VF_HIP_LIB names another build of the same library (A/B timing of kernel versions; the Lua binding honours it too)."""
+    return os.environ.get("VF_HIP_LIB") or os.path.join(_HERE, "lib", "libvf_hip.so")
 
 
 _LIB = None

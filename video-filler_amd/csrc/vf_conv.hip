@@ -132,7 +132,9 @@ struct IGemm {
 // (x = hi + mid + lo: 3 x 8 = the 24 significand bits of an fp32) and the six largest cross terms are accumulated —
 // what is dropped (mid*lo, lo*mid, lo*lo) is below 2^-24 of the product, the size of one fp32 rounding.
 // Everything outside the LDS tile (addresses, loads, epilogue, split-K) is shared with the fp32 path.
-template <int BM, int BN, int WM, int WN, bool BKM, int V, int BF = 0>
+// KLIN: K walked in memory order (tap outer, channel chunk inner) — the 1x1-output bottleneck layers (see next_chunk);
+// a template parameter so that no other instantiation carries its counters.
+template <int BM, int BN, int WM, int WN, bool BKM, int V, int BF = 0, bool KLIN = false>
 __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   // One K step = 32 = two 16-wide chunks; each chunk has its own (tap, c0), so any C % 16 == 0 vectorises.
   constexpr int BK = 32, LDA = BK + 4;
@@ -250,40 +252,47 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   const int sW_th = 4 * p.khs * 4 * p.wsTap, sW_tw = 4 * p.kws * p.wsTap, sW_0 = 4 * (kh0 * 4 + kw0) * p.wsTap;
   const int sW_c = 4 * (BKM ? p.wsC : 1);
   int it_tap = 0, it_c0 = 0, it_q = 0;     // state of the NEXT chunk to be described
+  // the memory-order walk (KLIN) keeps its OWN two counters and is selected at compile time: written as a runtime
+  // branch with the mirror-image update of it_tap / it_c0, LLVM merges the two branches into a select of ADDRESSES,
+  // the counters move to scratch memory, and every K step of EVERY kernel starts with a scratch_load +
+  // s_waitcnt vmcnt(0) in front of the operand prefetches (measured: -5 % per step)
+  int kl_tap = 0, kl_c0 = 0;
   const int ntaps = p.TH * p.TW;
   if constexpr (V >= 1) {
     // chunk order: channel chunk OUTER, tap INNER — the 16 taps of one channel chunk touch the same input window, so
     // the re-reads are temporally close (L1/L2 hits) instead of one full window sweep per tap
     it_q = 2 * kt0;
-    if (p.klin) {
+    it_c0 = (it_q / ntaps) << 4;
+    it_tap = it_q % ntaps;
+    if constexpr (KLIN) {
       // a 1x1 output map (the bottleneck layers) has no window overlap between taps to exploit; walking K in memory
       // order instead makes each weight row a single forward stream of 128-byte lines per block rather than 64-byte
       // pieces 2 KB apart (the 131 MB weight matrix is what this GEMM is bounded by)
       const int cpt = p.C >> 4;
-      it_tap = it_q / cpt;
-      it_c0 = (it_q - it_tap * cpt) << 4;
-    } else {
-      it_c0 = (it_q / ntaps) << 4;
-      it_tap = it_q % ntaps;
+      kl_tap = it_q / cpt;
+      kl_c0 = (it_q - kl_tap * cpt) << 4;
     }
   }
   auto next_chunk = [&]() {
     Chunk c;
-    const int th = it_tap >> lgTW, tw = it_tap & (p.TW - 1);
-    c.tap = it_tap;
-    c.dA = (unsigned)(th * sA_th + tw * sA_tw + 4 * it_c0);
-    c.dW = (unsigned)(sW_0 + th * sW_th + tw * sW_tw + it_c0 * sW_c);
+    const int tap = KLIN ? kl_tap : it_tap, c0 = KLIN ? kl_c0 : it_c0;
+    const int th = tap >> lgTW, tw = tap & (p.TW - 1);
+    c.tap = tap;
+    c.dA = (unsigned)(th * sA_th + tw * sA_tw + 4 * c0);
+    c.dW = (unsigned)(sW_0 + th * sW_th + tw * sW_tw + c0 * sW_c);
     c.ok = it_q < p.nq;
     ++it_q;
-    if (p.klin) {
-      it_c0 += 16;
-      if (it_c0 >= p.C) {
-        it_c0 = 0;
-        ++it_tap;
+    if constexpr (KLIN) {
+      kl_c0 += 16;
+      if (kl_c0 >= p.C) {
+        kl_c0 = 0;
+        ++kl_tap;
       }
-    } else if (++it_tap >= ntaps) {
-      it_tap = 0;
-      it_c0 += 16;
+    } else {
+      if (++it_tap >= ntaps) {
+        it_tap = 0;
+        it_c0 += 16;
+      }
     }
     return c;
   };
@@ -1088,6 +1097,12 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 template <int BM, int BN, int WM, int WN, int BF>
 static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
   dim3 block(256);
+  if constexpr (BM == 64 && BN == 128) {
+    if (g.klin && !bkm && v == 2) {
+      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, BF, true>), grid, block, g);
+      return;
+    }
+  }
   if (!bkm) {
     if (v == 2)
       VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, BF>), grid, block, g);
@@ -1154,9 +1169,8 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     // (tried: 256 x 64 tiles — four 64x64 wave tiles stacked in M, one block per CU — for the N = 64 layers: 153 us
     //  against 125 us for E2's data-gradient; one wave per SIMD does not cover its own LDS/global latency)
   }
-  // the weight-streaming bottleneck GEMMs (M <= 64) want every CU's three LDS slots filled: more bytes in flight
   static const int env_split_blocks = getenv("VF_SPLIT_BLOCKS") ? atoi(getenv("VF_SPLIT_BLOCKS")) : 0;
-  const int tune_split_blocks = env_split_blocks ? env_split_blocks : (g.M <= 64 ? 768 : 512);
+  const int tune_split_blocks = env_split_blocks ? env_split_blocks : 512;     // (768 for the M <= 64 GEMMs: a wash)
   const int gm = (int)vf_cdiv(g.M, t.bm), gn = (int)vf_cdiv(g.N, t.bn);
   const int64_t blocks = (int64_t)gm * gn * zpar;
   int ksplit = 1;
@@ -1173,7 +1187,7 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   static const int tune_dbg = getenv("VF_IGEMM_DBG") ? atoi(getenv("VF_IGEMM_DBG")) : 0;
   g.dbg = tune_dbg;
   static const int tune_klin = getenv("VF_NO_KLIN") ? 0 : 1;
-  g.klin = tune_klin && !g.parity && g.lgMh == 0 && g.lgMw == 0 && g.TH * g.TW > 1;
+  g.klin = tune_klin && !g.parity && g.lgMh == 0 && g.lgMw == 0 && g.TH * g.TW > 1 && t.bm == 64 && t.bn == 128 && !bkm && v == 2;
   g.gm = gm; g.gn = gn; g.gz = zpar * ksplit;
   dim3 grid((unsigned)gm * gn * zpar * ksplit);
   // timing experiments only: per-block stamps; every 32nd launch is synchronised and appended to the file
