@@ -134,7 +134,11 @@ struct IGemm {
 // Everything outside the LDS tile (addresses, loads, epilogue, split-K) is shared with the fp32 path.
 // KLIN: K walked in memory order (tap outer, channel chunk inner) — the 1x1-output bottleneck layers (see next_chunk);
 // a template parameter so that no other instantiation carries its counters.
-template <int BM, int BN, int WM, int WN, bool BKM, int V, int BF = 0, bool KLIN = false>
+template <int I> struct VfIC { static constexpr int value = I; };
+// DB (mode 3, V = 2 only): double-buffered LDS with the split and the LDS writes of step k+1 issued between the MFMAs of
+// step k and the global loads running two steps ahead in a second register set — for launches whose grid leaves at
+// most two blocks per CU anyway (the 66 KB this needs costs no occupancy there; see launch_igemm).
+template <int BM, int BN, int WM, int WN, bool BKM, int V, int BF = 0, bool KLIN = false, bool DB = false>
 __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   // One K step = 32 = two 16-wide chunks; each chunk has its own (tap, c0), so any C % 16 == 0 vectorises.
   constexpr int BK = 32, LDA = BK + 4;
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   constexpr int LDN = BN + 32;                         // k-major bf16 B tile (BF && BKM): [k][LDN], transposing reads
   constexpr int AH_SZ = BM * LDH, BH_SZ = BKM ? BK * LDN : BN * LDH;    // bf16 elements per buffer (BF)
   constexpr int NP = BF > 0 ? BF : 1;                  // bf16 planes per operand
-  constexpr int NBUF = BF == 3 ? 1 : 2;                // three planes: single-buffered LDS (capacity), loads still run ahead
+  static_assert(!DB || (BF == 3 && V == 2), "the double-buffered schedule is built for mode 3's vector path");
+  constexpr int NBUF = (BF == 3 && !DB) ? 1 : 2;       // three planes: single-buffered LDS (capacity), loads still run ahead
   constexpr int PL_SZ = AH_SZ + BH_SZ;                 // one plane of (A, B), bf16 elements
   constexpr int SMEM_F = BF ? (NBUF * NP * PL_SZ + 1) / 2 : 2 * (A_SZ + B_SZ);
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   const int kq = tid & 7;          // 16-byte column of the 32-wide K step
   const int kh = kq >> 2, kl = kq & 3;  // chunk (0/1) and 16-byte column inside the chunk
 
-  f32x4 ra[A_CH], rb[B_CH];
+  f32x4 ra[DB ? 2 : 1][A_CH], rb[DB ? 2 : 1][B_CH];      // operand pieces in flight (DB: two steps' worth)
   const __amdgpu_buffer_rsrc_t rsA = vf_rsrc(p.A, p.a_bytes), rsW = vf_rsrc(p.Wt, p.w_bytes);
 
   auto tap_index = [&](int tap) {
@@ -335,14 +340,15 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
       }
     }
   };
-  auto load_piece = [&](int pc) {
+  auto load_piece = [&](int pc, auto SET) {
+    constexpr int rs = decltype(SET)::value;
     const int kt = t_kt;
     if constexpr (V >= 1) {
       if (pc < A_CH) {
         // ---------------- A: lanes with kh = 0 / 1 fetch chunk 0 / 1
         const int i = pc;
         const bool ok = t_okq && ((a_mask[i] >> t_tapv) & 1u);
-        ra[i] = vf_bload4(rsA, ok ? a_byte[i] + t_dA : VF_OOB);
+        ra[rs][i] = vf_bload4(rsA, ok ? a_byte[i] + t_dA : VF_OOB);
       } else {
         // ---------------- B
         const int i = pc - A_CH;
@@ -355,13 +361,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
         const unsigned dW = hi ? tc1.dW : tc0.dW;
         const bool ok = w_ok[i] && (hi ? tc1.ok : tc0.ok);
         if constexpr (V == 2) {
-          rb[i] = vf_bload4(rsW, ok ? w_byte[i] + dW : VF_OOB);
+          rb[rs][i] = vf_bload4(rsW, ok ? w_byte[i] + dW : VF_OOB);
         } else {   // V == 1: k-major B whose N is not a multiple of 4 -> four scalar loads along n
           const int n = n0 + 4 * ((tid + 256 * i) % (BN / 4));
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = vf_bload1(rsW, (ok && n + j < p.N) ? w_byte[i] + dW + 4u * j : VF_OOB);
-          rb[i] = v;
+          rb[rs][i] = v;
         }
       }
     } else {
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           const bool ok = s_kok[j] && a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
           v[j] = vf_bload1(rsA, ok ? 4u * (unsigned)(a_boff[i] + (iy * p.Wi + ix) * p.C + s_c[j]) : VF_OOB);
         }
-        ra[i] = v;
+        ra[rs][i] = v;
       } else {
         const int i = pc - A_CH;
         const int id = tid + 256 * i;
@@ -396,17 +402,18 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = vf_bload1(rsW, (okk && n + j < p.N) ? 4u * (unsigned)(base + n + j) : VF_OOB);
         }
-        rb[i] = v;
+        rb[rs][i] = v;
       }
     }
   };
   auto load_tile = [&](int kt) {
     begin_tile(kt, true);
 #pragma unroll
-    for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc);
+    for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc, VfIC<0>{});
   };
 
-  auto store_piece = [&](int buf, int pc) {
+  auto store_piece = [&](int buf, int pc, auto SET) {
+    constexpr int rs = decltype(SET)::value;
     if constexpr (BF) {
       // mode 3: plane q = top 16 bits of the residual after the planes before it (vf_split3); mode 1: bf16(v), RNE
       __bf16* base = (__bf16*)smem + buf * (NP * PL_SZ);
@@ -415,17 +422,17 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
         if (256 * i + 255 < BM * 8 || id < BM * 8) {
           __bf16* dst = base + (id >> 3) * LDH + 4 * kq;
           if constexpr (NP == 3) {
-            const VfPlanes3 s3 = vf_split3(ra[i]);
+            const VfPlanes3 s3 = vf_split3(ra[rs][i]);
 #pragma unroll
             for (int q = 0; q < 3; ++q) *(uint2*)(dst + q * PL_SZ) = s3.p[q];
           } else {
-            *(bf16x4*)dst = __builtin_convertvector(ra[i], bf16x4);
+            *(bf16x4*)dst = __builtin_convertvector(ra[rs][i], bf16x4);
           }
         }
       } else {
         const int i = pc - A_CH, id = tid + 256 * i;
         if (256 * i + 255 < BN * 8 || id < BN * 8) {
-          f32x4 v = rb[i];
+          f32x4 v = rb[rs][i];
           int off;
           if constexpr (!BKM) {
             off = (id >> 3) * LDH + 4 * kq;
@@ -449,22 +456,22 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     float* Bs = As + A_SZ;
     if (pc < A_CH) {
       const int i = pc, id = tid + 256 * i;
-      if (256 * i + 255 < BM * 8 || id < BM * 8) *(f32x4*)(As + (id >> 3) * LDA + 4 * kq) = ra[i];
+      if (256 * i + 255 < BM * 8 || id < BM * 8) *(f32x4*)(As + (id >> 3) * LDA + 4 * kq) = ra[rs][i];
     } else {
       const int i = pc - A_CH, id = tid + 256 * i;
       if (256 * i + 255 < BN * 8 || id < BN * 8) {     // constant-true for full pieces: no exec-mask branch in the loop
         if constexpr (!BKM) {
-          *(f32x4*)(Bs + (id >> 3) * LDB + 4 * kq) = rb[i];
+          *(f32x4*)(Bs + (id >> 3) * LDB + 4 * kq) = rb[rs][i];
         } else {
           const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
-          *(f32x4*)(Bs + kk * LDB + 4 * nq) = rb[i];
+          *(f32x4*)(Bs + kk * LDB + 4 * nq) = rb[rs][i];
         }
       }
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int pc = 0; pc < A_CH + B_CH; ++pc) store_piece(buf, pc);
+    for (int pc = 0; pc < A_CH + B_CH; ++pc) store_piece(buf, pc, VfIC<0>{});
   };
 
   f32x16 acc[MT][NT];
@@ -483,13 +490,79 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   }
   __syncthreads();
   if (p.stamps && tid == 0) p.stamps[8 * blockIdx.x + 1] = wall_clock64();
+  if constexpr (DB) {
+    // Step kt (register set S = parity of kt - kt0, LDS buffer S):
+    //   MFMA slot i < NPC  is followed by operand piece i of step kt+2 (global -> register set S, whose previous
+    //                      content — step kt — went to LDS during step kt-1);
+    //   the last NPC slots are each followed by one piece of step kt+1 (register set S^1, loaded during step kt-1):
+    //                      split into planes + three LDS writes into buffer S^1, in the shadow of the running MFMA;
+    //   the fragments of the second 16-deep group are read right after the first MFMA.  One barrier per step.
+    constexpr int NPC = A_CH + B_CH;
+    constexpr int NMF = 6 * MT * NT;               // MFMAs per 16-deep group
+    constexpr int SLOTS = (BK / 16) * NMF;
+    static_assert(2 * NPC <= SLOTS, "loads and LDS writes of one K step must fit between its MFMAs");
+    begin_tile(kt0 + 1, kt0 + 1 < kt1);
+#pragma unroll
+    for (int pc = 0; pc < NPC; ++pc) load_piece(pc, VfIC<1>{});
+    auto step = [&](int kt, auto SET) {
+      constexpr int S = decltype(SET)::value;
+      const __bf16* base = (const __bf16*)smem + S * (NP * PL_SZ);
+      // nothing of this step may float above this point (left alone, the split of step kt+1's pieces is hoisted to the
+      // top of the step, in front of the loads issued here, and waits for ALL outstanding loads there)
+      __builtin_amdgcn_sched_barrier(0);
+      begin_tile(kt + 2, kt + 2 < kt1);
+      bf16x8 a[2][NP][MT], b[2][NP][NT];
+      auto read_frag = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const __bf16* Ah = base + q * PL_SZ;
+          const __bf16* Bh = Ah + AH_SZ;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[g][q][mt] = *(const bf16x8*)(Ah + (wm + mt * 32 + lr) * LDH + 16 * g + 8 * lh);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (!BKM)
+              b[g][q][nt] = *(const bf16x8*)(Bh + (wn + nt * 32 + lr) * LDH + 16 * g + 8 * lh);
+            else
+              b[g][q][nt] = vf_tr_frag<LDN>(Bh, wn + nt * 32, 16 * g, lane);
+          }
+        }
+      };
+      read_frag(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {       // smallest terms first
+              constexpr int qa[6] = {1, 0, 2, 0, 1, 0}, qb[6] = {1, 2, 0, 1, 0, 0};
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g][qa[t]][mt], b[g][qb[t]][nt], acc[mt][nt], 0, 0, 0);
+              const int slot = g * NMF + (mt * NT + nt) * 6 + t;
+              if (slot == 0 && BK / 16 > 1) read_frag(1);
+              if (slot < NPC) load_piece(slot, SET);
+              // (unconditional: on the last step this writes zeros into the buffer nobody reads again; a branch here
+              //  makes the compiler drain every outstanding load at the top of each step)
+              if (slot >= SLOTS - NPC) store_piece(S ^ 1, slot - (SLOTS - NPC), VfIC<(S ^ 1)>{});
+              __builtin_amdgcn_sched_barrier(0);
+            }
+      }
+      __syncthreads();
+    };
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      step(kt, VfIC<0>{});
+      if (kt + 1 < kt1) step(kt + 1, VfIC<1>{});
+    }
+  } else
   if constexpr (BF) {
     for (int kt = kt0; kt < kt1; ++kt) {
       const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
       const __bf16* base = (const __bf16*)smem + buf * (NP * PL_SZ);
       begin_tile(kt + 1, kt + 1 < kt1);
 #pragma unroll
-      for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc);
+      for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc, VfIC<0>{});
 #pragma unroll
       for (int g = 0; g < BK / 16; ++g) {
         bf16x8 a[NP][MT], b[NP][NT];
@@ -569,8 +642,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           for (int nt = 0; nt < NT; ++nt) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ss & 1][mt][j], fb[ss & 1][nt][j], acc[mt][nt], 0, 0, 0);
             const int slot = ss * NMF + (j * MT + mt) * NT + nt;
-            if (slot < NPC) load_piece(slot);
-            if (slot >= SLOTS - NPC) store_piece(buf ^ 1, slot - (SLOTS - NPC));
+            if (slot < NPC) load_piece(slot, VfIC<0>{});
+            if (slot >= SLOTS - NPC) store_piece(buf ^ 1, slot - (SLOTS - NPC), VfIC<0>{});
             __builtin_amdgcn_sched_barrier(0);
           }
     }
@@ -1095,8 +1168,18 @@ __global__ __launch_bounds__(256) void k_col2im4x4(const float* __restrict__ col
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int BM, int BN, int WM, int WN, int BF>
-static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
+static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops,
+                                bool db = false) {
   dim3 block(256);
+  if constexpr (BF == 3 && BM == 64 && BN == 64) {
+    if (db && v == 2) {
+      if (!bkm)
+        VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, 3, false, true>), grid, block, g);
+      else
+        VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 2, 3, false, true>), grid, block, g);
+      return;
+    }
+  }
   if constexpr (BM == 64 && BN == 128) {
     if (g.klin && !bkm && v == 2) {
       VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, BF, true>), grid, block, g);
@@ -1118,9 +1201,10 @@ static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm
   }
 }
 template <int BM, int BN, int WM, int WN>
-static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops) {
+static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops,
+                              bool db = false) {
   if (ctx->mfma_bf16 == 3)
-    launch_igemm_tile_m<BM, BN, WM, WN, 3>(ctx, g, grid, bkm, v, name, flops);
+    launch_igemm_tile_m<BM, BN, WM, WN, 3>(ctx, g, grid, bkm, v, name, flops, db);
   else if (ctx->mfma_bf16 == 1)
     launch_igemm_tile_m<BM, BN, WM, WN, 1>(ctx, g, grid, bkm, v, name, flops);
   else
@@ -1205,8 +1289,12 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   }
   char pname[64];
   // one name per kernel symbol (what rocprofv3 lists): k_igemm<bm, bn, ., ., kmajorB, v, mode>
-  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v,
-           ctx->mfma_bf16 == 3 ? "_bf16x3" : (ctx->mfma_bf16 ? "_bf16" : ""));
+  // double-buffered schedule: where the grid leaves at most two blocks per CU anyway (its 66 KB tiles cost nothing then)
+  static const int tune_db = getenv("VF_IGEMM_DB") ? atoi(getenv("VF_IGEMM_DB")) : 1;
+  const bool db = ctx->mfma_bf16 == 3 && v == 2 && t.bm == 64 && t.bn == 64 &&
+                  (tune_db == 2 || (tune_db == 1 && (int64_t)grid.x <= 2 * 256));
+  snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v,
+           ctx->mfma_bf16 == 3 ? "_bf16x3" : (ctx->mfma_bf16 ? "_bf16" : ""), db ? "_db" : "");
   {
     const double fl = 2.0 * (double)g.M * g.N * Ktot * zpar;
     if (t.bm == 256)
@@ -1218,7 +1306,7 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     else if (t.bn == 128)
       launch_igemm_tile<64, 128, 64, 32>(ctx, g, grid, bkm, v, pname, fl);
     else
-      launch_igemm_tile<64, 64, 32, 32>(ctx, g, grid, bkm, v, pname, fl);
+      launch_igemm_tile<64, 64, 32, 32>(ctx, g, grid, bkm, v, pname, fl, db);
   }
   VF_LAUNCH_CHECK();
   if (stamp_dump) {
