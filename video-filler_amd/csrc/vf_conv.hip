@@ -594,6 +594,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mt], b[0][nt], acc[mt][nt], 0, 0, 0);
           }
       }
+      // keep the split of the next step's pieces below this step's MFMAs: hoisted above them (it depends on the loads
+      // only) it makes the wave wait for a load it issued two MFMAs earlier
+      if constexpr (NBUF == 1) __builtin_amdgcn_sched_barrier(0);
       if constexpr (NBUF == 1) __syncthreads();       // everyone has read the tile before it is overwritten
       store_tile(NBUF == 2 ? (buf ^ 1) : 0);
       __syncthreads();
