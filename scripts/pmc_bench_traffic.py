@@ -16,11 +16,12 @@ def bench_name(k):
     m = re.match(r"void k_wgrad<(\d+), \w+, \w+(?:, (\d))?>", k)
     if m:
         return "wgrad_%sx128%s" % (m.group(1), suf.get(m.group(2) or "0", ""))
-    m = re.match(r"void k_igemm<(\d+), (\d+), \d+, \d+, (\w+), (\d)(?:, (\d))?>", k)
+    # k_igemm<BM, BN, WM, WN, kmajorB, V, mode, KLIN, DB>
+    m = re.match(r"void k_igemm<(\d+), (\d+), \d+, \d+, (\w+), (\d)(?:, (\d))?(?:, (\w+))?(?:, (\w+))?>", k)
     if m:
-        return "igemm_%sx%s_%s_v%s%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4),
-                                        suf.get(m.group(5) or "0", ""))
-    m = re.match(r"(?:void )?(k_[a-z0-9_]+)", k)
+        return "igemm_%sx%s_%s_v%s%s%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4),
+                                          suf.get(m.group(5) or "0", ""), "_db" if m.group(7) == "true" else "")
+    m = re.match(r"(?:void )?k_([a-z0-9_]+)", k)      # k_adam -> adam, k_bn_stats -> bn_stats ...
     return m.group(1) if m else k
 
 acc = {}
