@@ -481,6 +481,7 @@ __global__ void k_adam_prep(int32_t* state, double lr, double b1, double b2) {
   state[1] = __float_as_int((float)(lr * sqrt(bc2) / bc1));
 }
 // One pass: read x,g,m,v (16 B) ; write x,m,v (12 B) = 28 B/param.  fp32 op order follows optim/adam.lua.
+template <bool NT>
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float b1, float omb1, float b2, float omb2,
                                               float eps, const int32_t* __restrict__ state) {
@@ -497,9 +498,17 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ x, const float
     vv = vi;
     xv = xv - (step * mi) / d;
   };
+  auto ld = [&](const float* p, int64_t i) {
+    if constexpr (NT) return __builtin_nontemporal_load((const f32x4*)p + i);
+    else return ((const f32x4*)p)[i];
+  };
+  auto st = [&](float* p, int64_t i, f32x4 val) {
+    if constexpr (NT) __builtin_nontemporal_store(val, (f32x4*)p + i);
+    else ((f32x4*)p)[i] = val;
+  };
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 xv = ((f32x4*)x)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
-    const f32x4 gv = ((const f32x4*)g)[i];
+    f32x4 xv = ld(x, i), mv = ld(m, i), vv = ld(v, i);
+    const f32x4 gv = ld(g, i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float xe = xv[e], me = mv[e], ve = vv[e];
@@ -508,9 +517,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ x, const float
       mv[e] = me;
       vv[e] = ve;
     }
-    ((f32x4*)x)[i] = xv;
-    ((f32x4*)m)[i] = mv;
-    ((f32x4*)v)[i] = vv;
+    st(x, i, xv);
+    st(m, i, mv);
+    st(v, i, vv);
   }
   for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) upd(x[i], g[i], m[i], v[i]);
 }
@@ -519,8 +528,15 @@ VF_API int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* 
   VF_REQUIRE((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam operands must be 16-byte aligned");
   hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, ctx->stream, t_dev, lr, beta1, beta2);
   VF_LAUNCH_CHECK();
-  VF_LAUNCH_TIMED(ctx, "adam", 0.0, 28.0 * (double)n, k_adam, dim3(grid_for(n, 4)), dim3(256), x, g, m, v, n, (float)beta1,
-                  (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
+  static const int tune_nt = getenv("VF_ADAM_NT") ? atoi(getenv("VF_ADAM_NT")) : 0;
+  static const int tune_blocks = getenv("VF_ADAM_BLOCKS") ? atoi(getenv("VF_ADAM_BLOCKS")) : 2048;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(vf_cdiv(n, 1024), tune_blocks));
+  if (tune_nt)
+    VF_LAUNCH_TIMED(ctx, "adam", 0.0, 28.0 * (double)n, k_adam<true>, dim3(blocks), dim3(256), x, g, m, v, n, (float)beta1,
+                    (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
+  else
+    VF_LAUNCH_TIMED(ctx, "adam", 0.0, 28.0 * (double)n, k_adam<false>, dim3(blocks), dim3(256), x, g, m, v, n, (float)beta1,
+                    (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
   VF_LAUNCH_CHECK();
   return 0;
 }
