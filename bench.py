@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--no-batch-d", action="store_true", help="N=1: run netD's real and fake passes separately (default: one batch "
                     "of 2B with BatchNorm in two groups; same arithmetic per sample)")
     ap.add_argument("--batch-d", action="store_true", help="(default now at N=1; kept so that older command lines still parse)")
+    ap.add_argument("--adam-overlap", action="store_true", help="N=1: update Adam(G)'s two bottleneck weight tensors on a side stream "
+                    "beside the next encoder forward (measured: -4 %: the 2048-block HBM stream slows the convolutions it shares "
+                    "the chip with by more than it hides)")
     ap.add_argument("--overlap", action="store_true", help="3 streams (dW beside dX, netG forward beside netD's real pass): measured "
                     "+0.7 %% on one GPU with the current kernels (noise level), so the default is one stream")
     ap.add_argument("--no-overlap", action="store_true", help="(default now; kept so that older command lines still parse)")
@@ -128,7 +131,7 @@ def main():
         for _ in range(max(args.warmup, 10) if use_graph else args.warmup):
             run()
     elif use_graph:
-        tr.capture(warmup=max(args.warmup, 2))
+        tr.capture(warmup=max(args.warmup, 2), adam_overlap=args.adam_overlap)
         run = tr.replay
         for _ in range(max(args.warmup, 10)):     # untimed replays: lets clocks settle on a fresh box
             run()
@@ -296,6 +299,7 @@ def main():
                        "mfma": {"f32_3xbf16": "fp32 operands split exactly into 3 bf16 planes, 6 cross terms on v_mfma_f32_32x32x16_bf16, "
                                               "f32 accumulate (fp32-grade: same parity tolerances as native)",
                                 "f32": "native v_mfma_f32_32x32x2_f32", "bf16": "operands rounded to bf16"}[args.mfma],
+                       "adam_G": "bottleneck weight tensors on a side stream beside the next encoder forward" if tr.adam_overlap else "one launch at the end of the iteration",
                        "netD_passes": "real+fake as one batch of 2B, BatchNorm per half" if tr.batch_d else "separate (as the reference)",
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
             "roofline": roofline,

@@ -180,6 +180,13 @@ int vf_masked_mse_bwd(vf_ctx* ctx, const float* x, const float* xhat, const uint
  * Hyper-parameters are doubles, as Lua numbers are. */
 int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                  double beta2, double eps, int32_t* t_dev);
+/* The two halves of vf_adam_step, so that one update can be applied range by range (and on more than one stream):
+ * vf_adam_prep advances the step count and derives the step size ONCE (t_dev[0] += 1, t_dev[1] = bits of
+ * lr*sqrt(1-beta2^t)/(1-beta1^t)); vf_adam_apply updates x[0..n) (any 16-byte aligned sub-range of the flat
+ * vectors) with that step size.  prep + apply over the whole vector == vf_adam_step. */
+int vf_adam_prep(vf_ctx* ctx, double lr, double beta1, double beta2, int32_t* t_dev);
+int vf_adam_apply(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2,
+                  double eps, const int32_t* t_dev);
 
 /* ---- batch preparation and the inference tile loop (the data formats either side of the closures) ---------
  * train.lua:284-298: from the loader's batch (B x C x fs x fs planar, [-1,1]) produce the NHWC generator input with

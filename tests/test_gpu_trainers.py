@@ -229,6 +229,42 @@ def test_graph_replay_matches_eager(oracle, hipb):
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k]))
 
 
+@pytest.mark.parametrize("kind", ["center", "vid"])
+def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb):
+    """Adam(G) split over two streams (the two bottleneck weight tensors beside the next iteration's encoder forward,
+    joined in front of the bottleneck conv), eager and captured: element for element optim.adam's arithmetic, so the
+    parameters are BITWISE those of the plain loop."""
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+    if kind == "center":
+        opt = dict(nBottleneck=512, wtl2=0.999, overlapPred=4)
+        batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)
+        mk = lambda: CenterTrainer(opt, seed=3)
+    else:
+        opt = dict(nBottleneck=512, predLen=2)
+        batch = tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(4, np.random.default_rng(5), 6))
+        mk = lambda: VidTrainer(opt, seed=3)
+    a, b, c = mk(), mk(), mk()
+    for t in (a, b, c):
+        t.set_batch(*batch)
+    for _ in range(5):
+        a.step()
+    b.enable_adam_overlap(True)        # nBottleneck = 512: E6 and D1 have 512*512*16 = 4 Mi elements each (the threshold)
+    assert b.adam_overlap and len(b._g_big[0]) == 2
+    for _ in range(5):
+        b.step()
+    b.flush()
+    c.capture(warmup=3, adam_overlap=True)
+    assert c.adam_overlap
+    c.replay()
+    c.replay()
+    c.flush()
+    torch.cuda.synchronize()
+    for t in (b, c):
+        assert torch.equal(t.parametersG, a.parametersG) and torch.equal(t.parametersD, a.parametersD)
+        assert torch.equal(t.optimStateG["m"], a.optimStateG["m"]) and torch.equal(t.optimStateG["v"], a.optimStateG["v"])
+        assert int(t.optimStateG["t_dev"][0].item()) == 5
+
+
 @pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("kind", ["center", "vid"])
 def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hipb):

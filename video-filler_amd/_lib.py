@@ -73,6 +73,8 @@ SIGNATURES = {
     "vf_masked_mse_fwd": (i32, [vp, vp, vp, vp, f32, i64, vp]),
     "vf_masked_mse_bwd": (i32, [vp, vp, vp, vp, f32, vp, i64]),
     "vf_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, vp]),
+    "vf_adam_prep": (i32, [vp, f64, f64, f64, vp]),
+    "vf_adam_apply": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, vp]),
     "vf_prof_begin": (i32, [vp]),
     "vf_prof_end": (i32, [vp]),
     "vf_prof_count": (i32, []),

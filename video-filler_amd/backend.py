@@ -369,6 +369,12 @@ class HipBackend:
     def adam_step(self, x, g, m, v, lr, beta1, beta2, eps, t_dev):
         self._c("vf_adam_step", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), lr, beta1, beta2, eps, _ptr(t_dev))
 
+    def adam_prep(self, lr, beta1, beta2, t_dev):
+        self._c("vf_adam_prep", lr, beta1, beta2, _ptr(t_dev))
+
+    def adam_apply(self, x, g, m, v, beta1, beta2, eps, t_dev):
+        self._c("vf_adam_apply", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), beta1, beta2, eps, _ptr(t_dev))
+
     # ---- per-kernel timers
     def prof_begin(self):
         self._c("vf_prof_begin")

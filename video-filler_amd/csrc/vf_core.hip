@@ -523,20 +523,32 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ x, const float
   }
   for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) upd(x[i], g[i], m[i], v[i]);
 }
-VF_API int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
-                        double beta2, double eps, int32_t* t_dev) {
+static int adam_apply(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps,
+                      const int32_t* t_dev) {
   VF_REQUIRE((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam operands must be 16-byte aligned");
-  hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, ctx->stream, t_dev, lr, beta1, beta2);
-  VF_LAUNCH_CHECK();
   static const int tune_nt = getenv("VF_ADAM_NT") ? atoi(getenv("VF_ADAM_NT")) : 0;
   static const int tune_blocks = getenv("VF_ADAM_BLOCKS") ? atoi(getenv("VF_ADAM_BLOCKS")) : 2048;
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(vf_cdiv(n, 1024), tune_blocks));
   if (tune_nt)
     VF_LAUNCH_TIMED(ctx, "adam", 0.0, 28.0 * (double)n, k_adam<true>, dim3(blocks), dim3(256), x, g, m, v, n, (float)beta1,
-                    (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
+                    (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, t_dev);
   else
     VF_LAUNCH_TIMED(ctx, "adam", 0.0, 28.0 * (double)n, k_adam<false>, dim3(blocks), dim3(256), x, g, m, v, n, (float)beta1,
-                    (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const int32_t*)t_dev);
+                    (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, t_dev);
   VF_LAUNCH_CHECK();
   return 0;
+}
+VF_API int vf_adam_prep(vf_ctx* ctx, double lr, double beta1, double beta2, int32_t* t_dev) {
+  hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, ctx->stream, t_dev, lr, beta1, beta2);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+VF_API int vf_adam_apply(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2,
+                         double eps, const int32_t* t_dev) {
+  return adam_apply(ctx, x, g, m, v, n, beta1, beta2, eps, t_dev);
+}
+VF_API int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                        double beta2, double eps, int32_t* t_dev) {
+  if (int rc = vf_adam_prep(ctx, lr, beta1, beta2, t_dev)) return rc;
+  return adam_apply(ctx, x, g, m, v, n, beta1, beta2, eps, t_dev);
 }

@@ -62,6 +62,8 @@ int vf_gdl_fwd(vf_ctx*, const float* yhat, const float* y, int B, int H, int W, 
 int vf_masked_mse_fwd(vf_ctx*, const float* x, const float* xhat, const uint8_t* mask, float w, int64_t n, double* loss);
 int vf_masked_mse_bwd(vf_ctx*, const float* x, const float* xhat, const uint8_t* mask, float w, float* gx, int64_t n);
 int vf_adam_step(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int32_t* t_dev);
+int vf_adam_prep(vf_ctx*, double lr, double beta1, double beta2, int32_t* t_dev);
+int vf_adam_apply(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
 int vf_bias_grad_plan(int64_t P, int C, int* cq, int* rows_per_block, int* gx, int* gy);

@@ -66,8 +66,8 @@ class Module:
     def type_name(self):            # torch.type(m)
         return self._type
 
-    def forward(self, input):
-        return self.updateOutput(input)
+    def forward(self, input, **kw):
+        return self.updateOutput(input, **kw)
 
     def backward(self, input, gradOutput, scale=1):
         self.updateGradInput(input, gradOutput)
@@ -595,10 +595,14 @@ class Sequential(Module):
         self._plan = plan
         return plan
 
-    def updateOutput(self, input):
+    def updateOutput(self, input, before=None):
+        """before = (plan index, fn): fn() runs right before that plan entry (a stream join in front of the first layer
+        whose weights a side stream is still updating)."""
         plan = self._plan or self._build_plan()
         cur = input
-        for m, a in plan:
+        for idx, (m, a) in enumerate(plan):
+            if before is not None and idx == before[0]:
+                before[1]()
             if a is None:
                 cur = m.updateOutput(cur)
             else:

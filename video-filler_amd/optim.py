@@ -38,3 +38,26 @@ def adam_update(x, dfdx, state):
         adam_init(x, state)
     state["t"] += 1          # host mirror of the device counter (informational)
     B.adam_step(x, dfdx, state["m"], state["v"], lr, beta1, beta2, eps, state["t_dev"])
+
+
+def adam_update_split(x, dfdx, state, side_ranges, side):
+    """adam_update with the element ranges `side_ranges` ([(lo, hi)], 16-byte aligned) applied on the backend `side`
+    (its own stream, ordered after the step-size kernel) and everything else on the current one.  The caller joins
+    `side` before anything reads those ranges.  Element for element the same update as adam_update."""
+    B = get_backend()
+    lr = state.get("learningRate", 0.001)
+    beta1 = state.get("beta1", 0.9)
+    beta2 = state.get("beta2", 0.999)
+    eps = state.get("epsilon", 1e-8)
+    adam_init(x, state)
+    state["t"] += 1
+    m, v, t_dev = state["m"], state["v"], state["t_dev"]
+    B.adam_prep(lr, beta1, beta2, t_dev)
+    with side.on():
+        for lo, hi in side_ranges:
+            side.adam_apply(x[lo:hi], dfdx[lo:hi], m[lo:hi], v[lo:hi], beta1, beta2, eps, t_dev)
+    pos = 0
+    for lo, hi in sorted(side_ranges) + [(x.numel(), x.numel())]:
+        if lo > pos:
+            B.adam_apply(x[pos:lo], dfdx[pos:lo], m[pos:lo], v[pos:lo], beta1, beta2, eps, t_dev)
+        pos = hi

@@ -181,6 +181,9 @@ class _TrainerBase:
         self._gen = None
         self._force_comm = False     # run the exchange even at world == 1 (exercises the DP path on one GPU)
         self.defer_adam_g = False
+        self.adam_overlap = False    # enable_adam_overlap(): Adam(G)'s two big weight tensors beside the next encoder forward
+        self.side_a = None
+        self._g_big = None
         self._pending_g = False
         self._graph_stale = False
         self.batch_d = False         # set_batch_d(): netD's real and fake passes as one batch of 2B
@@ -276,11 +279,45 @@ class _TrainerBase:
         28 B/param HBM-bound update then overlaps MFMA-bound work.  Same arithmetic, same order on every buffer;
         `flush()` applies a pending update (call it before reading parametersG)."""
         optim.adam(self.fDx, self.parametersD, self.optimStateD)
-        if self.defer_adam_g and self.side_g is not None:
+        if (self.defer_adam_g and self.side_g is not None) or self.adam_overlap:
             self.fGx(self.parametersG)
             self._pending_g = True
         else:
             optim.adam(self.fGx, self.parametersG, self.optimStateG)
+
+    # -- Adam(G) beside the next iteration's encoder forward (single device).  92 % of the generator's parameters are
+    #    the two bottleneck weight tensors (E6, D1: 32.8 M each); the first layer that reads either is E6.  The update of
+    #    those two ranges runs on a side stream while the main stream updates everything else, sweeps the biases and
+    #    runs E1..E5 (MFMA-bound convolutions next to an HBM-bound stream); the main stream joins in front of E6.
+    #    Element for element the same arithmetic as optim.adam; `flush()` applies a pending update in one piece.
+    #    Measured (configs[1], same box): 3.36 -> 3.50 ms per step — the 2048-block HBM stream slows the convolutions it
+    #    shares the chip with by more than it hides — so this stays opt-in (`capture(adam_overlap=True)`).
+    def enable_adam_overlap(self, on=True, min_numel=4 << 20):
+        assert self._graph is None and self._graphs is None, "enable_adam_overlap before capture()"
+        self.adam_overlap = False
+        if not on or self._comm_on() or not hasattr(get_backend(), "fork"):
+            return self
+        plan = self.netG._plan or self.netG._build_plan()
+        big = [(m, o, n) for m, name, gname, o, n in self.netG._flat[2] if name == "weight" and n >= min_numel]
+        idxs = [i for i, (pm, _) in enumerate(plan) if any(pm is m for m, _, _ in big)]
+        if not big or len(idxs) != len(big):
+            return self                    # no big tensor, or one sits inside a table member: keep the plain update
+        if self.side_a is None:
+            self.side_a = get_backend().fork(workspace_bytes=1 << 20)
+        self._g_big = ([(o, o + n) for _, o, n in big], min(idxs))
+        self.adam_overlap = True
+        return self
+
+    def _pending_then_forward(self, fwd):
+        """apply a deferred Adam(G), sweep the conv biases (train.lua:279), run netG's forward"""
+        if self._pending_g and self.adam_overlap:
+            ranges, idx = self._g_big
+            optim.adam_update_split(self.parametersG, self.gradParametersG, self.optimStateG, ranges, self.side_a)
+            self._pending_g = False
+            self.netG.zeroConvBiases()
+            return fwd(before=(idx, self.side_a.join))
+        self._apply_pending_g_and_sweep()
+        return fwd()
 
     def _apply_pending_g(self):
         if self._pending_g:
@@ -304,7 +341,7 @@ class _TrainerBase:
         if self._pending_g:
             self._wait_inflight()
             self._apply_pending_g()
-            if (self._graph is not None and self.defer_adam_g) or (self._graphs is not None and self._pipelined):
+            if (self._graph is not None and (self.defer_adam_g or self.adam_overlap)) or (self._graphs is not None and self._pipelined):
                 self._graph_stale = True
 
     # -- the same iteration cut at the gradient exchanges (data parallel):
@@ -390,9 +427,11 @@ class _TrainerBase:
         self._pending_g = True
 
     # -- HIP graph of one whole iteration (single-GPU): zero launch gaps, no host work per step
-    def capture(self, warmup=3, defer_adam_g=False):
+    def capture(self, warmup=3, defer_adam_g=False, adam_overlap=False):
         assert not self._comm_on(), "one graph covers the single-device iteration; use capture_phased() for DP"
         B = get_backend()
+        if adam_overlap:
+            self.enable_adam_overlap(True)
         # optional: rotate Adam(G) into the next iteration's netD-real window (measured: +2% on the video nets, nothing
         # on train.lua's — the side stream that must also run netG's forward becomes the critical path)
         self.defer_adam_g = bool(defer_adam_g) and self.side_g is not None
@@ -406,7 +445,7 @@ class _TrainerBase:
         B.use_current_stream()
         self._graph = g
         self._graph_stale = False
-        self._pending_g = self.defer_adam_g      # the graph leaves the last iteration's Adam(G) pending
+        self._pending_g = self.defer_adam_g or self.adam_overlap      # the graph leaves the last iteration's Adam(G) pending
         return g
 
     def capture_phased(self, warmup=3, pipelined=False):
@@ -488,7 +527,7 @@ class CenterTrainer(_TrainerBase):
     def _g_in(self):
         return [self.input_ctx, self.noise] if self.opt["noiseGen"] else self.input_ctx
 
-    def _netG_forward(self):
+    def _netG_forward(self, **kw):
         o = self.opt
         if o["noiseGen"]:                     # regenerate random noise (train.lua:319-323)
             if self._noise_fixed is not None:
@@ -499,7 +538,7 @@ class CenterTrainer(_TrainerBase):
                     self.noise = get_backend().empty_act(Bn, o["nz"], 1, 1)
                 get_backend().noise_fill(self.noise, self.noise_seed, normal=o["noisetype"] == "normal",
                                          counter_dev=self.optimStateD["t_dev"])
-        return self.netG.forward(self._g_in())
+        return self.netG.forward(self._g_in(), **kw)
 
     def set_batch(self, real_ctx):
         """What train.lua:284-298 does on the loader's batch (a B x nc x fineSize x fineSize tensor in [-1,1]):
@@ -535,8 +574,7 @@ class CenterTrainer(_TrainerBase):
         if self.batch_d:
             assert not self._comm_on() and not self._pipelined
             if fake is None:
-                self._apply_pending_g_and_sweep()
-                fake = self._netG_forward()
+                fake = self._pending_then_forward(self._netG_forward)
             else:
                 self.side_g.join()
             self.input_center = fake
@@ -552,10 +590,7 @@ class CenterTrainer(_TrainerBase):
         yield "generator parameters needed"
         # train with fake
         if fake is None:
-            if self._pending_g:
-                self._apply_pending_g()
-                self.netG.zeroConvBiases()
-            fake = self._netG_forward()
+            fake = self._pending_then_forward(self._netG_forward)
         else:
             self.side_g.join()
         self.input_center = fake               # input_center:copy(fake): netD reads the generator's output buffer
@@ -677,8 +712,7 @@ class VidTrainer(_TrainerBase):
         if self.batch_d:
             assert not self._comm_on() and not self._pipelined
             if fake is None:
-                self._apply_pending_g_and_sweep()
-                fake = self.netG.forward(self._g_in())
+                fake = self._pending_then_forward(lambda **kw: self.netG.forward(self._g_in(), **kw))
             else:
                 self.side_g.join()
             if o["weight_nomask"] == 0:
@@ -695,10 +729,7 @@ class VidTrainer(_TrainerBase):
         self.netD.backward(self.input_real, df_do, need_input_grad=not self.skip_dead_grads)
         yield "generator parameters needed"
         if fake is None:
-            if self._pending_g:
-                self._apply_pending_g()
-                self.netG.zeroConvBiases()
-            fake = self.netG.forward(self._g_in())
+            fake = self._pending_then_forward(lambda **kw: self.netG.forward(self._g_in(), **kw))
         else:
             self.side_g.join()
         if o["weight_nomask"] == 0:                  # train_vid_weighted.lua:429-432
