@@ -150,7 +150,15 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   constexpr int B_CH = (BN * 8 + 255) / 256;
   constexpr int A_SZ = BM * LDA;
   constexpr int B_SZ = BKM ? BK * LDB : BN * LDB;
-  constexpr int LDH = BK + 8;                          // bf16 elements per LDS row (BF)
+  // Row-major bf16 tiles (BF): 64-byte rows, NO padding, the four 16-byte k-octets of a row XOR-swizzled by
+  // (row >> 2) & 3.  ds_read_b128 serves {0-3,12-15,20-27}-style 16-lane groups on a 256-byte bank row: the four
+  // row-quads of a group get the four different swizzles, so their octets land on 16 distinct slots; ds_write_b64
+  // serves 16 contiguous lanes (= two whole rows) on a 128-byte window, which two unpadded 64-byte rows fill exactly.
+  // (The padded linear layout — 80-byte rows — kept the reads conflict-free but made every plane write 2-way:
+  //  SQ_LDS_BANK_CONFLICT was a third of the LDS pipe's active cycles.)
+  constexpr int LDH = BK;                              // bf16 elements per LDS row (BF)
+  auto frag_off = [](int row, int octet) { return row * LDH + ((octet ^ ((row >> 2) & 3)) << 3); };        // 8 k of `row`
+  auto piece_off = [](int row, int kq) { return row * LDH + (((kq >> 1) ^ ((row >> 2) & 3)) << 3) + ((kq & 1) << 2); };
   constexpr int LDN = BN + 32;                         // k-major bf16 B tile (BF && BKM): [k][LDN], transposing reads
   constexpr int AH_SZ = BM * LDH, BH_SZ = BKM ? BK * LDN : BN * LDH;    // bf16 elements per buffer (BF)
   constexpr int NP = BF > 0 ? BF : 1;                  // bf16 planes per operand
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
       if (pc < A_CH) {
         const int i = pc, id = tid + 256 * i;
         if (256 * i + 255 < BM * 8 || id < BM * 8) {
-          __bf16* dst = base + (id >> 3) * LDH + 4 * kq;
+          __bf16* dst = base + piece_off(id >> 3, kq);
           if constexpr (NP == 3) {
             const VfPlanes3 s3 = vf_split3(ra[rs][i]);
 #pragma unroll
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           f32x4 v = rb[rs][i];
           int off;
           if constexpr (!BKM) {
-            off = (id >> 3) * LDH + 4 * kq;
+            off = piece_off(id >> 3, kq);
           } else {      // the piece holds 4 consecutive n at one k: stored as it comes, transposed by the reads
             const int kk = id / (BN / 4), nq = id - kk * (BN / 4);
             off = kk * LDN + 4 * nq;
@@ -518,11 +526,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           const __bf16* Ah = base + q * PL_SZ;
           const __bf16* Bh = Ah + AH_SZ;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[g][q][mt] = *(const bf16x8*)(Ah + (wm + mt * 32 + lr) * LDH + 16 * g + 8 * lh);
+          for (int mt = 0; mt < MT; ++mt) a[g][q][mt] = *(const bf16x8*)(Ah + frag_off(wm + mt * 32 + lr, 2 * g + lh));
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             if constexpr (!BKM)
-              b[g][q][nt] = *(const bf16x8*)(Bh + (wn + nt * 32 + lr) * LDH + 16 * g + 8 * lh);
+              b[g][q][nt] = *(const bf16x8*)(Bh + frag_off(wn + nt * 32 + lr, 2 * g + lh));
             else
               b[g][q][nt] = vf_tr_frag<LDN>(Bh, wn + nt * 32, 16 * g, lane);
           }
@@ -571,11 +579,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           const __bf16* Ah = base + q * PL_SZ;
           const __bf16* Bh = Ah + AH_SZ;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[q][mt] = *(const bf16x8*)(Ah + (wm + mt * 32 + lr) * LDH + 16 * g + 8 * lh);
+          for (int mt = 0; mt < MT; ++mt) a[q][mt] = *(const bf16x8*)(Ah + frag_off(wm + mt * 32 + lr, 2 * g + lh));
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             if constexpr (!BKM)
-              b[q][nt] = *(const bf16x8*)(Bh + (wn + nt * 32 + lr) * LDH + 16 * g + 8 * lh);
+              b[q][nt] = *(const bf16x8*)(Bh + frag_off(wn + nt * 32 + lr, 2 * g + lh));
             else
               b[q][nt] = vf_tr_frag<LDN>(Bh, wn + nt * 32, 16 * g, lane);
           }
