@@ -1,4 +1,5 @@
-"""Per-K-step phase stamps of one wave (block 7, thread 0) written by the `spy` build of k_igemm under VF_IGEMM_STAMPS:
+"""Per-K-step phase stamps of one wave (block 7, thread 0) written by a -DVF_IGEMM_SPY build of vf_conv.hip
+(hipcc ... -DVF_IGEMM_SPY -c csrc/vf_conv.hip, linked into an alternate .so selected with VF_HIP_LIB) under VF_IGEMM_STAMPS:
 the dump's rows 256.. hold 32 steps x 8 slots of shader-clock stamps: 0 step top, 1 loads issued, 2 MFMAs issued,
 3 past barrier 1, 4 split + LDS writes issued, 5 past barrier 2."""
 import sys

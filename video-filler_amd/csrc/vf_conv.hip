@@ -134,6 +134,18 @@ struct IGemm {
 // Everything outside the LDS tile (addresses, loads, epilogue, split-K) is shared with the fp32 path.
 // KLIN: K walked in memory order (tap outer, channel chunk inner) — the 1x1-output bottleneck layers (see next_chunk);
 // a template parameter so that no other instantiation carries its counters.
+// -DVF_IGEMM_SPY (timing experiments; scripts/probe/spy_report.py): thread 0 of block 7 stamps the shader clock between
+// the phases of each of its first 32 K steps of the single-buffered mode-3 loop, into rows 4096.. of the VF_IGEMM_STAMPS
+// buffer.  Compiled out otherwise.
+#ifdef VF_IGEMM_SPY
+#define VF_SPY(slot)                                                                                             \
+  do {                                                                                                           \
+    if (p.stamps && blockIdx.x == 7 && tid == 0 && kt - kt0 < 32)                                                \
+      p.stamps[8 * 4096 + (kt - kt0) * 8 + (slot)] = (long long)__builtin_readcyclecounter();                    \
+  } while (0)
+#else
+#define VF_SPY(slot) do { } while (0)
+#endif
 template <int I> struct VfIC { static constexpr int value = I; };
 // DB (mode 3, V = 2 only): double-buffered LDS with the split and the LDS writes of step k+1 issued between the MFMAs of
 // step k and the global loads running two steps ahead in a second register set — for launches whose grid leaves at
@@ -568,9 +580,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
     for (int kt = kt0; kt < kt1; ++kt) {
       const int buf = NBUF == 2 ? ((kt - kt0) & 1) : 0;
       const __bf16* base = (const __bf16*)smem + buf * (NP * PL_SZ);
+      VF_SPY(0);
       begin_tile(kt + 1, kt + 1 < kt1);
 #pragma unroll
       for (int pc = 0; pc < A_CH + B_CH; ++pc) load_piece(pc, VfIC<0>{});
+      VF_SPY(1);
 #pragma unroll
       for (int g = 0; g < BK / 16; ++g) {
         bf16x8 a[NP][MT], b[NP][NT];
@@ -605,9 +619,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
       // keep the split of the next step's pieces below this step's MFMAs: hoisted above them (it depends on the loads
       // only) it makes the wave wait for a load it issued two MFMAs earlier
       if constexpr (NBUF == 1) __builtin_amdgcn_sched_barrier(0);
+      VF_SPY(2);
       if constexpr (NBUF == 1) __syncthreads();       // everyone has read the tile before it is overwritten
+      VF_SPY(3);
       store_tile(NBUF == 2 ? (buf ^ 1) : 0);
+      VF_SPY(4);
       __syncthreads();
+      VF_SPY(5);
     }
   } else {
   constexpr int NPC = A_CH + B_CH;             // operand pieces per K step
@@ -1329,6 +1347,14 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
         for (int q = 0; q < 6; ++q) fprintf(f, " %lld", g.stamps[8 * b + q]);
         fprintf(f, "\n");
       }
+#ifdef VF_IGEMM_SPY
+      for (unsigned b = 4096; b < 4128; ++b) {
+        fprintf(f, "S%u", b);
+        for (int q = 0; q < 6; ++q) fprintf(f, " %lld", g.stamps[8 * b + q]);
+        fprintf(f, "\n");
+        for (int q = 0; q < 8; ++q) g.stamps[8 * b + q] = 0;
+      }
+#endif
       fclose(f);
     }
   }
