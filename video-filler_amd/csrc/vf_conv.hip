@@ -734,24 +734,30 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, float* __restrict_
     dst[i] = s;
   }
 }
-// 16-byte form: 64 float4 columns x 4 split lanes per block; lanes are combined in a fixed order.
+// 16-byte form: COLS float4 columns x (256 / COLS) split lanes per block; lanes are combined in a fixed order.
+// COLS = 64 is the workhorse; COLS = 16 (16 split lanes) serves small outputs with very deep splits (the image-side
+// weight gradients: 48 x 64 outputs from 500+ slabs — twelve 64-column blocks walking 128 slabs each sat at 15 us).
+template <int COLS>
 __global__ __launch_bounds__(256) void k_slab_reduce4(const float* __restrict__ slab, float* __restrict__ dst,
                                                       const float* __restrict__ bias, int64_t total4, int N, int ksplit,
                                                       int act, float slope, float beta,
                                                       const float* __restrict__ dmask = nullptr, int dact = 0,
                                                       float dslope = 0.f) {
-  const int tx = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int64_t i4 = (int64_t)blockIdx.x * 64 + tx;
+  constexpr int L = 256 / COLS;
+  const int tx = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const int64_t i4 = (int64_t)blockIdx.x * COLS + tx;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i4 < total4) {
 #pragma unroll 4
-    for (int k = sl; k < ksplit; k += 4) s += ((const f32x4*)slab)[(int64_t)k * total4 + i4];
+    for (int k = sl; k < ksplit; k += L) s += ((const f32x4*)slab)[(int64_t)k * total4 + i4];
   }
-  __shared__ f32x4 red[4][64];
+  __shared__ f32x4 red[L][COLS];
   red[sl][tx] = s;
   __syncthreads();
   if (sl == 0 && i4 < total4) {
-    f32x4 t = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+    f32x4 t = red[0][tx];
+#pragma unroll
+    for (int l = 1; l < L; ++l) t += red[l][tx];
     if (beta != 0.f) t += beta * ((const f32x4*)dst)[i4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -772,8 +778,12 @@ static int launch_slab_reduce(vf_ctx* ctx, const float* slab, float* dst, const 
                               float dslope = 0.f) {
   if (total % 4 == 0 && ((((uintptr_t)slab) | ((uintptr_t)dst) | ((uintptr_t)dmask)) & 15) == 0 && ksplit > 0) {
     const int64_t total4 = total / 4;
-    hipLaunchKernelGGL(k_slab_reduce4, dim3((int)vf_cdiv(total4, 64)), dim3(256), 0, ctx->stream, slab, dst, bias, total4, N,
-                       ksplit, act, slope, beta, dmask, dact, dslope);
+    if (total4 <= 8192 && ksplit >= 64)
+      hipLaunchKernelGGL(k_slab_reduce4<16>, dim3((int)vf_cdiv(total4, 16)), dim3(256), 0, ctx->stream, slab, dst, bias, total4, N,
+                         ksplit, act, slope, beta, dmask, dact, dslope);
+    else
+      hipLaunchKernelGGL(k_slab_reduce4<64>, dim3((int)vf_cdiv(total4, 64)), dim3(256), 0, ctx->stream, slab, dst, bias, total4, N,
+                         ksplit, act, slope, beta, dmask, dact, dslope);
   } else {
     const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);
     hipLaunchKernelGGL(k_slab_reduce, dim3(nb), dim3(256), 0, ctx->stream, slab, dst, bias, total, N, ksplit, act, slope, beta,
