@@ -28,14 +28,31 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 peak (the opt-in --mfma bf16 mode 
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/vf_hip.h): ties a PMC summary to the build it was taken from"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "video-filler_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "vf_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="batchSize per GPU (train.lua:7)")
-    ap.add_argument("--nBottleneck", type=int, default=4000)
-    ap.add_argument("--workload", default="center", choices=["center", "vid16", "vid4"])
+    ap.add_argument("--batch", type=int, default=None, help="batchSize per GPU (train.lua:7); default per workload: center 64 "
+                    "(configs[1]), vid16 / vid4 16 (configs[2]), wholeim 4 (configs[4]: global 32 over 8 GPUs)")
+    ap.add_argument("--nBottleneck", type=int, default=None, help="default 4000 (README recipes); wholeim: 6400 (the script's own)")
+    ap.add_argument("--workload", default="center", choices=["center", "vid16", "vid4", "wholeim"],
+                    help="center = configs[1] (the headline); vid16 = configs[2]; wholeim = configs[4] "
+                    "(train_wholeim_input.lua defaults, 27 -> 12 channels, 192/192/128, wtgdl 0.5; add --mfma bf16 for its bf16 form)")
+    ap.add_argument("--step-stats", type=int, default=100, help="steps of the per-step percentile pass after the timed region "
+                    "(0: skip it, e.g. under rocprofv3 --pmc)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -54,12 +71,16 @@ def main():
                     "of 2B with BatchNorm in two groups; same arithmetic per sample)")
     ap.add_argument("--batch-d", action="store_true", help="(default now at N=1; kept so that older command lines still parse)")
     ap.add_argument("--adam-overlap", action="store_true", help="N=1: update Adam(G)'s two bottleneck weight tensors on a side stream "
-                    "beside the next encoder forward (measured: -4 %: the 2048-block HBM stream slows the convolutions it shares "
+                    "beside the next encoder forward (measured: -4 %%: the 2048-block HBM stream slows the convolutions it shares "
                     "the chip with by more than it hides)")
     ap.add_argument("--overlap", action="store_true", help="3 streams (dW beside dX, netG forward beside netD's real pass): measured "
                     "+0.7 %% on one GPU with the current kernels (noise level), so the default is one stream")
     ap.add_argument("--no-overlap", action="store_true", help="(default now; kept so that older command lines still parse)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = {"center": 64, "vid16": 16, "vid4": 16, "wholeim": 4}[args.workload]
+    if args.nBottleneck is None:
+        args.nBottleneck = 6400 if args.workload == "wholeim" else 4000
 
     # stdout carries exactly ONE JSON line: libraries that print banners there (RCCL does at init) go to stderr
     sys.stdout.flush()
@@ -102,6 +123,20 @@ def main():
         tr.set_batch(batch)
         wl = "train.lua inpaintCenter (nBottleneck=%d wtl2=0.999 overlapPred=4) fineSize=128 batchSize=%d/GPU" % (
             args.nBottleneck, args.batch)
+    elif args.workload == "wholeim":
+        # train_wholeim_input.lua:39-43 defaults: 3x3 array of patches in (27 channels), 2x2 out (12), nef = ngf = 192,
+        # ndf = 128, nBottleneck 6400; wtgdl 0.5 exercises the GDL value path; fineSize 128
+        opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, nc_in=27, nc_out=12, nef=192, ngf=192, ndf=128,
+                   weight_nomask=1, wtgdl=0.5)
+        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap)
+        full = torch.rand((args.batch, 12, 128, 128), generator=gen) * 2 - 1
+        mask = torch.zeros((args.batch, 12, 128, 128), dtype=torch.uint8)
+        mask[:, :, 32:96, 32:96] = 1
+        ctx = torch.rand((args.batch, 27, 128, 128), generator=gen) * 2 - 1
+        ctx[:, :, 32:96, 32:96] = 2 * (110.0 / 255.0) - 1
+        tr.set_batch(ctx, full, mask)
+        wl = ("train_wholeim_input.lua 27->12 channels nef=ngf=192 ndf=128 nBottleneck=%d wtgdl=0.5 fineSize=128 "
+              "batchSize=%d/GPU" % (args.nBottleneck, args.batch))
     else:
         predLen = 16 if args.workload == "vid16" else 4
         nc = 3 * predLen
@@ -158,13 +193,18 @@ def main():
     # per-step distribution (median and p10/p90 over >= 100 iterations): a separate pass after the timed
     # region, one event pair per step on the launch stream, nothing synchronises inside it
     step_stats = None
-    if rank == 0 and world == 1 and args.steps >= 10:      # (short runs, e.g. under rocprofv3 --pmc, skip it)
-        nd = 100
+    if rank == 0 and world == 1 and args.step_stats > 0:
+        nd = args.step_stats
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(nd + 1)]
         evs[0].record()
         for i in range(nd):
             run()
             evs[i + 1].record()
+            # eager steps are ~270 launches each: bound what is in flight (a graph replay is ONE launch and needs no bound).
+            # 100 un-synchronised eager steps = 27 k queued dispatches; under rocprofv3 --pmc that ended in a SIGSEGV inside
+            # the runtime's dispatch path (profiler-side per-dispatch state, not this library)
+            if not use_graph and (i & 7) == 7:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nd))
         step_stats = dict(n=nd, p10=round(ts[nd // 10], 4), p50=round(ts[nd // 2], 4), p90=round(ts[(9 * nd) // 10], 4))
@@ -220,6 +260,16 @@ def main():
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_us=round(avg_ms * 1e3, 2),
                             launches_per_step=dom["launches"] / nprof, share_of_step=round(dom["ms"] / tot, 3))
+            # the same measurement against the pipe the kernel actually issues on.  `frac` prices the ALGORITHMIC fp32
+            # FLOPs against the f32-input MFMA peak (what a native fp32 kernel is bounded by); in the default mode each
+            # fp32 product is formed from 6 bf16 MFMAs, so the bf16 pipe executes 6x the algorithmic FLOPs:
+            mult = {"f32_3xbf16": 6.0, "bf16": 1.0, "f32": None}[args.mfma]
+            if mult is not None:
+                roofline["bf16_pipe"] = dict(executed_tflops=round(mult * ach, 1), peak=PEAK_BF16_MFMA_TFLOPS,
+                                             frac=round(mult * ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                                             algorithmic_frac_of_bf16_peak=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                                             note="executed = %gx algorithmic (bf16 MFMAs issued per fp32 product); frac = share of the "
+                                                  "dense bf16 matrix peak the kernel keeps busy" % mult)
         else:
             ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
             roofline = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -246,11 +296,17 @@ def main():
         try:
             import glob
             pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic.json")))[-1]
-            pmc = json.load(open(pmc_file))["kernels"].get(name)
-            if pmc is not None and args.workload == "center" and args.batch == 64:
+            pmc_all = json.load(open(pmc_file))
+            pmc = pmc_all["kernels"].get(name)
+            # the counters belong to ONE build of the kernels: the summary records the digest of csrc/ it was collected
+            # with (scripts/pmc_bench_traffic.py) and a summary of any other build is refused
+            fresh = pmc_all.get("csrc_sha256") == csrc_digest()
+            if pmc is not None and args.workload == "center" and args.batch == 64 and fresh:
                 roofline["traffic"] = int(pmc["hbm_MB_per_launch"] * 1e6)
                 roofline["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)"
                 roofline["traffic_source"] = os.path.relpath(pmc_file, ROOT)
+            elif not fresh:
+                roofline["traffic_note"] = "%s was collected with another build of csrc/ (digest mismatch): not used" % os.path.relpath(pmc_file, ROOT)
         except (IndexError, OSError, KeyError, ValueError):
             pass
         kernels = {k: dict(launches_per_step=v["launches"] / nprof, ms_per_step=round(v["ms"] / nprof, 4),
@@ -268,6 +324,12 @@ def main():
         if args.workload == "center":
             ref = O.CenterTrainer(dict(nBottleneck=args.nBottleneck, wtl2=0.999, overlapPred=4), np.random.default_rng(1234))
             ref.set_batch(O.synth_center_batch(cb, np.random.default_rng(1235)))
+        elif args.workload == "wholeim":
+            cb = min(cb, 2)       # 31 GFLOP of convolutions per sample and iteration: two samples bound the sample at ~1 min
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import FastRng
+            ref = O.VidTrainer(dict(opt), FastRng(1234))
+            ref.set_batch(*O.synth_vid_batch(cb, np.random.default_rng(1235), 27, 12))
         else:
             cb = min(cb, 2)
             predLen = 16 if args.workload == "vid16" else 4
@@ -276,7 +338,7 @@ def main():
         c0 = time.perf_counter()
         ref.step()
         cdt = time.perf_counter() - c0
-        cpu = dict(value=round(cb / cdt, 3), unit="images/s", cores=1, kind="port",
+        cpu = dict(value=round(cb / cdt, 3), unit="images/s" if args.workload == "center" else "clips/s", cores=1, kind="port",
                    sample="1 full iteration (fDx+Adam+fGx+Adam) of the same nets at batchSize=%d, %.1f s" % (cb, cdt))
         # second row (SURVEY 8(d) ii): the same iteration with OpenMP over all host cores the box gives this process
         try:
@@ -296,9 +358,10 @@ def main():
     if rank == 0:
         n_img = world * args.batch * args.steps
         out = {
-            "metric": "netG+netD fwd+bwd images/sec, 128x128 center-mask",
+            "metric": ("netG+netD fwd+bwd images/sec, 128x128 center-mask" if args.workload == "center" else
+                       "netG+netD fwd+bwd clips/sec, 128x128 (%s)" % args.workload),
             "value": round(n_img / dt, 2),
-            "unit": "images/s",
+            "unit": "images/s" if args.workload == "center" else "clips/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,

@@ -234,6 +234,9 @@ int vf_noise_fill(vf_ctx* ctx, float* out, int64_t n, uint64_t seed, const int32
  * slabs of all recorded layers at once (vf_workspace_bytes_hint); if it does not, the group is flushed early. */
 int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
+/* Drop an open group without launching anything (a host-side error cut the backward walk short): the recorded GEMMs are
+ * discarded and the context is back to immediate launches.  No-op when no group is open. */
+int vf_wgrad_group_abort(vf_ctx* ctx);
 
 /* ---- every conv bias gradient of one backward walk in two launches ----------------------------------------------
  * gradBias = sum over pixels of gradOutput (THNN accGradParameters) is not needed before optim.adam, and each layer's

@@ -79,6 +79,8 @@ def _sz(n):
 
 # ------------------------------------------------------------------ modules
 class Module:
+    act_trace = None      # tests: a list that receives (module, activated output copy) from every (Leaky)ReLU forward
+
     def __init__(self):
         self.output = None
         self.gradInput = None
@@ -236,6 +238,8 @@ class LeakyReLU(Module):
     def updateOutput(self, x):
         self.output = x if self.inplace else x.copy()
         lib().vfo_lrelu_fwd(_p(self.output), _sz(self.output.size), _f(self.negval))
+        if Module.act_trace is not None:
+            Module.act_trace.append((self, self.output.copy()))
         return self.output
 
     def updateGradInput(self, x, gy):
@@ -254,6 +258,8 @@ class ReLU(Module):
     def updateOutput(self, x):
         self.output = x if self.inplace else x.copy()
         lib().vfo_relu_fwd(_p(self.output), _sz(self.output.size))
+        if Module.act_trace is not None:
+            Module.act_trace.append((self, self.output.copy()))
         return self.output
 
     def updateGradInput(self, x, gy):

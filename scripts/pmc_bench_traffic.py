@@ -46,7 +46,10 @@ for name, e in sorted(acc.items()):
     out[name] = dict(launches_counted=nf, FETCH_SIZE_KiB_per_launch=round(fetch_kib, 1), WRITE_SIZE_KiB_per_launch=round(write_kib, 1),
                      hbm_read_MB_per_launch_x2=round(2 * fetch_kib * 1024 / 1e6, 2), hbm_write_MB_per_launch=round(write_kib * 1024 / 1e6, 2),
                      hbm_MB_per_launch=round((2 * fetch_kib + write_kib) * 1024 / 1e6, 2))
-json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graph --no-overlap --steps 2 "
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest  # noqa: E402
+head = os.environ.get("VF_GIT_HEAD", "")
+json.dump(dict(csrc_sha256=csrc_digest(), git_head=head, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graph --no-overlap --steps 2 "
                     "--warmup 1`; averages over every launch of the kernel in that run; FETCH_SIZE x2 (gfx950 correction, "
                     "MI355X_MICROARCH.md); kernels keyed as in bench.py's kernel table",
                kernels=out), open(dst, "w"), indent=1)

@@ -9,6 +9,6 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/pmc_bench
 rm -rf $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $ROOT/bench.py --no-graph --no-overlap --no-cpu-baseline --steps 2 --warmup 1 > $OUT.$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $ROOT/bench.py --no-graph --no-overlap --no-cpu-baseline --steps 2 --warmup 1 --step-stats 0 > $OUT.$c.log 2>&1
 done
 python3 $ROOT/scripts/pmc_bench_traffic.py $OUT $ROOT/gpurun_out/pmc_bench_traffic.json

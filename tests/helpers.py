@@ -26,3 +26,111 @@ def rel_err(a, b):
 def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
     assert e <= tol, "%s: max-norm relative error %.3e > %.1e" % (what, e, tol)
+
+
+class FastRng:
+    """Stand-in for numpy's Generator in `weights_init` at FULL net sizes (hundreds of millions of parameters): float32
+    ziggurat draws instead of float64 ones.  `normal(mu, sd, shape)` is the only call weights_init makes; the value
+    stream is `mu + sd * standard_normal(float32)` evaluated in float32, so any side that consumes the same shapes in the
+    same order (the oracle's weights_init; `fast_init_flat` below for the HIP nets) holds bit-identical weights."""
+
+    def __init__(self, seed):
+        self.g = np.random.default_rng(seed)
+
+    def normal(self, mu, sd, shape):
+        z = self.g.standard_normal(shape, dtype=np.float32)
+        z *= np.float32(sd)
+        z += np.float32(mu)
+        return z
+
+
+def fast_init_flat(net, rng):
+    """The reference-order parameter vector `weights_init(net, rng)` would leave in the oracle's twin of the
+    HIP net `net` (after getParameters()): convolution weights N(0, 0.02), BatchNorm gains N(1, 0.02), every bias 0 — the
+    draws consumed module by module in the same order (train.lua:58-67)."""
+    parts = []
+    for m, name, gname, o, n in net._flat[2]:
+        if name == "bias":
+            parts.append(np.zeros(n, np.float32))
+        elif "BatchNormalization" in m.type_name():
+            parts.append(rng.normal(1.0, 0.02, (n,)))
+        else:
+            parts.append(rng.normal(0.0, 0.02, (n,)))
+    return np.concatenate(parts)
+
+
+class KinkSync:
+    """Pins the derivative choice of every (Leaky)ReLU in a HIP training iteration to the oracle's.
+
+    LeakyReLU/ReLU derivatives jump at 0 and are evaluated from the activated output.  Two correct fp32
+    implementations differ by ~1e-7 in a pre-activation, so an element that sits that close to the kink can take slope 1
+    on one side and 0.2 (or 0) on the other, which moves whole gradient tensors by up to 1e-2 of their norm although
+    nothing is wrong.  With this helper the oracle runs first and records every activated tensor; during the HIP run
+    (nn.Sequential.act_hook) every element whose ORACLE value is within `delta` (relative to that tensor's max) of 0 is
+    overwritten with the oracle's value — a perturbation of at most `delta` on a handful of elements — so both sides
+    take the same branch everywhere and the gradients can be held to the fp32 bar (1e-4) on the real nets too.
+    An element further from 0 than `delta` whose sign differs is a real forward error and still fails the test."""
+
+    def __init__(self, oracle_mod, pairs, delta=1e-5):
+        """pairs: [(oracle net, hip net)] built by the same recipe (leaf order identical)."""
+        self.O = oracle_mod
+        self.delta = delta
+        self.map = {}
+        for rnet, hnet in pairs:
+            ra = [m for m in self._oleaves(rnet) if type(m).__name__ in ("LeakyReLU", "ReLU")]
+            ha = [m for m in hnet.leaves() if getattr(m, "act", None) in ("lrelu", "relu")]
+            assert len(ra) == len(ha), (len(ra), len(ha))
+            for a, b in zip(ra, ha):
+                self.map[id(b)] = a
+        self.rec = {}
+        self.pos = {}
+        self.touched = 0
+        self.checked = 0
+
+    def _oleaves(self, m):
+        if hasattr(m, "modules"):
+            out = []
+            for c in m.modules:
+                out += self._oleaves(c)
+            return out
+        return [m]
+
+    def oracle_step(self, fn):
+        """run fn() (the oracle's iteration) while recording its activations, pass by pass"""
+        self.O.Module.act_trace = []
+        try:
+            out = fn()
+        finally:
+            trace, self.O.Module.act_trace = self.O.Module.act_trace, None
+        self.rec, self.pos = {}, {}
+        for m, y in trace:
+            self.rec.setdefault(id(m), []).append(y)
+        return out
+
+    def __call__(self, a, y):                 # nn.Sequential.act_hook
+        ra = self.map.get(id(a))
+        if ra is None:
+            return
+        passes = self.rec[id(ra)]
+        k = self.pos.get(id(ra), 0)
+        ref = passes[k]
+        used = 1
+        if y.shape[0] != ref.shape[0]:        # netD's real and fake passes run as one batch of 2B on the HIP side
+            ref = np.concatenate([passes[k], passes[k + 1]], axis=0)
+            used = 2
+        self.pos[id(ra)] = k + used
+        assert tuple(y.shape) == ref.shape, (tuple(y.shape), ref.shape)
+        r = torch.from_numpy(ref).to(y.device)
+        near = r.abs() < self.delta * max(1.0, float(np.abs(ref).max()))
+        self.touched += int((near & (r != y)).sum().item())
+        self.checked += y.numel()
+        y.copy_(torch.where(near, r, y))
+
+    def hip_step(self, fn):
+        import video_filler_amd.nn as hnn
+        hnn.Sequential.act_hook = self
+        try:
+            return fn()
+        finally:
+            hnn.Sequential.act_hook = None
+        # every recorded pass must have been consumed

@@ -149,3 +149,27 @@ def test_hip_reproduces_iteration_vectors(kind, hipb):
     assert rel_err(fake[::mk.STRIDE], z["fake0_sample"]) < 1e-4
     # real (kinked) nets at batch 2: see tests/test_gpu_trainers.py for why gradients get 3e-2
     assert rel_err(to_np(tr.netG.reference_flat(grads=True))[::mk.STRIDE], z["gG0_sample"]) < 3e-2
+
+
+def test_oracle_reproduces_the_full_width_config0_fixture(oracle):
+    """tests/golden/full_center8.npz = BASELINE.json configs[0] (train.lua recipe, fineSize 128, batchSize 8, nBottleneck
+    4000, ONE iteration on the CPU): the oracle, rebuilt from the seeds, still lands on the committed numbers.  (The vid16
+    and wholeim fixtures take minutes of CPU time; `python tests/golden/make_golden_full.py` regenerates all three.)"""
+    from helpers import FastRng
+    spec = importlib.util.spec_from_file_location("make_golden_full", os.path.join(G, "make_golden_full.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    cfg = mk.CONFIGS["center8"]
+    z = np.load(os.path.join(G, "full_center8.npz"))
+    oracle.set_num_threads(8)
+    try:
+        tr = oracle.CenterTrainer(cfg["opt"], FastRng(cfg["wseed"]))
+        np.testing.assert_array_equal(tr.parametersG[::mk.STRIDE], z["pG_init_sample"])
+        assert [tr.parametersG.size, tr.parametersD.size] == list(z["n_params"])
+        tr.set_batch(*mk.batch_of(cfg))
+        r = tr.step()
+    finally:
+        oracle.set_num_threads(1)
+    np.testing.assert_allclose([r["errD"], r["errG"], r["errG_l2"]], z["losses"][:3], rtol=1e-6)
+    assert rel_err(tr.gradParametersG[::mk.STRIDE], z["gG_sample"]) < 1e-5
+    assert rel_err(tr.parametersD[::mk.STRIDE], z["pD_sample"]) < 1e-5

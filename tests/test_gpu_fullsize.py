@@ -1,5 +1,10 @@
-"""Full-size (BASELINE.json configs[1]: batchSize 64, nBottleneck 4000) checks through size-independent properties —
-the oracle would need minutes per layer at these sizes, the properties need none:
+"""Full-size checks of BASELINE.json's configurations — configs[1] (train.lua, batchSize 64, nBottleneck 4000), configs[2]
+(train_vid_weighted.lua:112-236, 16-frame clips = 48 channels, batchSize 16) and configs[4] (train_wholeim_input.lua:
+39-43,137-199,235-260: 27 -> 12 channels, nef = ngf = 192, ndf = 128, nBottleneck 6400, 629 MB bottleneck weight tensors,
+batchSize 4 per GPU) — through size-independent properties (the oracle would need minutes per layer at these sizes, the
+properties need none), through the committed full-width oracle fixtures (tests/golden/full_*.npz: one iteration each,
+computed in the build container by tests/golden/make_golden_full.py), and through run-time oracle comparisons at the
+largest sizes the oracle finishes in well under a minute:
 
   * adjointness:  <gy, conv(x; W)> = <conv_bwd_data(gy; W), x>          (forward and data-grad kernels are transposes)
   * bilinearity:  <gy, conv(x; W')> = <conv_bwd_weight(x, gy), W'>      (weight-grad kernel is the W-derivative)
@@ -16,11 +21,22 @@ import torch
 pytestmark = pytest.mark.gpu
 
 B = 64
-# every conv / full-conv of the train.lua nets at fineSize 128 (train.lua:87-199): (kind, Cin, H, Cout, stride, pad)
-LAYERS = [("conv", 3, 128, 64, 2, 1), ("conv", 64, 64, 64, 2, 1), ("conv", 64, 32, 128, 2, 1), ("conv", 128, 16, 256, 2, 1),
-          ("conv", 256, 8, 512, 2, 1), ("conv", 512, 4, 4000, 1, 0), ("full", 4000, 1, 512, 1, 0), ("full", 512, 4, 256, 2, 1),
-          ("full", 256, 8, 128, 2, 1), ("full", 128, 16, 64, 2, 1), ("full", 64, 32, 3, 2, 1),
-          ("conv", 3, 64, 64, 2, 1), ("conv", 512, 4, 1, 1, 0)]
+# every conv / full-conv of the train.lua nets at fineSize 128 (train.lua:87-199): (batch, kind, Cin, H, Cout, stride, pad)
+_CENTER = [("conv", 3, 128, 64, 2, 1), ("conv", 64, 64, 64, 2, 1), ("conv", 64, 32, 128, 2, 1), ("conv", 128, 16, 256, 2, 1),
+           ("conv", 256, 8, 512, 2, 1), ("conv", 512, 4, 4000, 1, 0), ("full", 4000, 1, 512, 1, 0), ("full", 512, 4, 256, 2, 1),
+           ("full", 256, 8, 128, 2, 1), ("full", 128, 16, 64, 2, 1), ("full", 64, 32, 3, 2, 1),
+           ("conv", 3, 64, 64, 2, 1), ("conv", 512, 4, 1, 1, 0)]
+# configs[2], batchSize 16: what train_vid_weighted.lua:112-236 adds to the list above (48-channel image side, the extra
+# ngf -> ngf decoder stage, netD's floor(ndf/2) first layer) plus two of the shared layers at this batch size
+_VID16 = [("conv", 48, 128, 64, 2, 1), ("full", 64, 32, 64, 2, 1), ("full", 64, 64, 48, 2, 1), ("conv", 48, 128, 32, 2, 1),
+          ("conv", 32, 64, 64, 2, 1), ("conv", 256, 8, 512, 2, 1), ("full", 512, 4, 256, 2, 1), ("conv", 512, 4, 4000, 1, 0)]
+# configs[4], batchSize 4: every layer of train_wholeim_input.lua:137-199 (netG) and :235-260 (netD)
+_WHOLEIM = [("conv", 27, 128, 192, 2, 1), ("conv", 192, 64, 192, 2, 1), ("conv", 192, 32, 384, 2, 1), ("conv", 384, 16, 768, 2, 1),
+            ("conv", 768, 8, 1536, 2, 1), ("conv", 1536, 4, 6400, 1, 0), ("full", 6400, 1, 1536, 1, 0), ("full", 1536, 4, 768, 2, 1),
+            ("full", 768, 8, 384, 2, 1), ("full", 384, 16, 192, 2, 1), ("full", 192, 32, 192, 2, 1), ("full", 192, 64, 12, 2, 1),
+            ("conv", 12, 128, 64, 2, 1), ("conv", 64, 64, 128, 2, 1), ("conv", 128, 32, 256, 2, 1), ("conv", 256, 16, 512, 2, 1),
+            ("conv", 512, 8, 1024, 2, 1), ("conv", 1024, 4, 1, 1, 0)]
+LAYERS = [(64,) + l for l in _CENTER] + [(16,) + l for l in _VID16] + [(4,) + l for l in _WHOLEIM]
 
 
 def _dot(a, b):
@@ -31,9 +47,9 @@ def _close(a, b, tol=2e-5):
     assert abs(a - b) <= tol * max(abs(a), abs(b), 1e-30), (a, b, abs(a - b) / max(abs(a), abs(b)))
 
 
-@pytest.mark.parametrize("layer", LAYERS, ids=lambda l: "%s%d-%d@%d" % (l[0], l[1], l[3], l[2]))
+@pytest.mark.parametrize("layer", LAYERS, ids=lambda l: "B%d-%s%d-%d@%d" % (l[0], l[1], l[2], l[4], l[3]))
 def test_conv_adjoint_bilinear_linear(layer, hipb):
-    kind, Cin, H, Cout, s, p = layer
+    B, kind, Cin, H, Cout, s, p = layer
     full = kind == "full"
     Ho = (H - 1) * s - 2 * p + 4 if full else (H + 2 * p - 4) // s + 1
     g = torch.Generator(device="cpu").manual_seed(Cin * 131 + Cout)
@@ -71,8 +87,10 @@ def test_conv_adjoint_bilinear_linear(layer, hipb):
     _close(_dot(gy, y2 * 0 + y), 0.5 * _dot(gw, w), 4e-5)
 
 
-@pytest.mark.parametrize("C,HW", [(64, 32), (128, 16), (256, 8), (512, 4), (4000, 1)])
-def test_batchnorm_invariants_full_size(C, HW, hipb):
+@pytest.mark.parametrize("B,C,HW", [(64, 64, 32), (64, 128, 16), (64, 256, 8), (64, 512, 4), (64, 4000, 1),
+                                    (16, 64, 64), (16, 128, 32), (4, 192, 64), (4, 384, 16), (4, 1536, 4), (4, 6400, 1),
+                                    (4, 256, 32), (4, 1024, 8)])
+def test_batchnorm_invariants_full_size(B, C, HW, hipb):
     g = torch.Generator(device="cpu").manual_seed(C)
     x = (torch.randn(B, HW, HW, C, generator=g) * 1.7 + 0.6).to(hipb.device).permute(0, 3, 1, 2)
     gy = torch.randn(B, HW, HW, C, generator=g).to(hipb.device).permute(0, 3, 1, 2)
@@ -123,3 +141,150 @@ def test_full_config_iteration_is_deterministic_and_finite(hipb):
             assert abs(v - runs[1][0][k]) <= 1e-12 * max(1.0, abs(v))
     l = runs[0][0]
     assert 0 < l["errG_l2"] < 1.0 and 0 < l["errD"] < 20 and 0 < l["errG"] < 40
+
+
+# ------------------------------------------------------------------------------------------------ configs[2] and configs[4]
+VID16_OPT = dict(nBottleneck=4000, predLen=16)                                                     # train_vid_weighted.lua, 48 channels
+WHOLEIM_OPT = dict(nBottleneck=6400, nc_in=27, nc_out=12, nef=192, ngf=192, ndf=128, weight_nomask=1, wtgdl=0.5)
+
+
+def _vid_batch(Bn, nc_in, nc_out, seed):
+    from oracle import oracle as O
+    return tuple(torch.from_numpy(a) for a in O.synth_vid_batch(Bn, np.random.default_rng(seed), nc_in, nc_out))
+
+
+@pytest.mark.parametrize("cfg", ["vid16", "wholeim", "wholeim-bf16"])
+def test_full_width_video_iterations_are_deterministic_and_finite(cfg, hipb):
+    """configs[2] at its batch size (16 clips of 48 channels) and configs[4] at its per-GPU batch size (4, with the GDL value
+    path on), three iterations, twice: finite, in range, bitwise repeatable.  `wholeim-bf16` is BASELINE.json's bf16 variant
+    of configs[4]: operands of the conv products rounded to bf16 (vf_ctx_set_mfma_mode 1), everything else fp32; its
+    losses must agree with the fp32-grade mode's within 2e-2 (stated tolerance of that mode at this depth: thirteen conv
+    layers between the input and the scalar, three parameter updates)."""
+    from video_filler_amd.trainers import VidTrainer
+    opt, Bn, nci, nco = (VID16_OPT, 16, 48, 48) if cfg == "vid16" else (WHOLEIM_OPT, 4, 27, 12)
+    batch = _vid_batch(Bn, nci, nco, 77)
+    modes = ["f32_3xbf16", "bf16"] if cfg == "wholeim-bf16" else ["f32_3xbf16", "f32_3xbf16"]
+    runs = []
+    try:
+        for mode in modes:
+            hipb.set_mfma_mode(mode)
+            tr = VidTrainer(opt, seed=7)
+            if cfg == "vid16":
+                assert tr.netG.n_parameters() > 71e6 and tr.netD.n_parameters() > 2.7e6
+            else:
+                # train_wholeim_input.lua: the two bottleneck tensors alone are 2 x 1536*16*6400 = 314.6 M parameters
+                assert tr.netG.n_parameters() > 330e6 and tr.netD.n_parameters() > 10e6
+            tr.set_batch(*batch)
+            for _ in range(3):
+                tr.step()
+            l = tr.losses()
+            assert all(np.isfinite(v) for v in l.values() if v is not None), l
+            assert 0 < l["errG_l2"] < 1.0 and 0 < l["errD"] < 20 and 0 < l["errG"] < 40
+            if opt.get("wtgdl"):
+                assert 0 < l["errG_gdl"] < 4.0
+            runs.append((l, tr.parametersG.clone(), tr.parametersD.clone()))
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        hipb.set_mfma_mode("f32_3xbf16")
+    if cfg == "wholeim-bf16":
+        for k, v in runs[0][0].items():
+            if v is not None:
+                assert abs(v - runs[1][0][k]) <= 2e-2 * max(1.0, abs(v)), (k, v, runs[1][0][k])
+        return
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    for k, v in runs[0][0].items():
+        if v is not None:
+            assert abs(v - runs[1][0][k]) <= 1e-12 * max(1.0, abs(v))
+
+
+def _golden_full():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_full.py")
+    spec = importlib.util.spec_from_file_location("make_golden_full", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m, os.path.dirname(path)
+
+
+@pytest.mark.parametrize("name", ["center8", "vid16", "wholeim"])
+def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb):
+    """One whole iteration (fDx + Adam + fGx + Adam) at FULL net width against the CPU oracle's result for the same seeds,
+    computed in the build container and committed (tests/golden/full_<name>.npz; `center8` is BASELINE.json configs[0]: the
+    train.lua recipe at batchSize 8, nBottleneck 4000).  Bars: losses 2e-5; generator output 1e-4 of its max; gradient
+    samples 2e-2 of the vector's max-norm — the kink effect of tests/test_gpu_trainers.py without the pin (a fixture
+    cannot carry the oracle's activations), at batch sizes 4-8; the updated parameters within 2% of one learning-rate step
+    wherever the gradient is significant."""
+    import os
+    from helpers import FastRng, fast_init_flat, rel_err, to_np
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+    mk, gdir = _golden_full()
+    cfg = mk.CONFIGS[name]
+    z = np.load(os.path.join(gdir, "full_%s.npz" % name))
+    tr = (CenterTrainer if cfg["kind"] == "center" else VidTrainer)(cfg["opt"])
+    rng = FastRng(cfg["wseed"])
+    dev = tr.parametersG.device
+    for net, key in ((tr.netG, "pG_init_sample"), (tr.netD, "pD_init_sample")):       # the oracle initialises G, then D
+        vec = fast_init_flat(net, rng)
+        np.testing.assert_array_equal(vec[::mk.STRIDE], z[key])                       # same weights as the fixture's run
+        net.load_reference_flat(torch.from_numpy(vec).to(dev))
+    assert [tr.netG.n_parameters(), tr.netD.n_parameters()] == list(z["n_params"])
+    tr.set_batch(*[torch.from_numpy(np.ascontiguousarray(a)) for a in mk.batch_of(cfg)])
+    tr.step()
+    got = tr.losses()
+    for k, w in zip(("errD", "errG", "errG_l2", "errG_gdl"), z["losses"]):
+        if got[k] is not None:
+            assert abs(got[k] - w) <= 2e-5 * max(1.0, abs(w)), (k, got[k], w)
+    fake = to_np(tr.netG.output).reshape(-1)[::mk.STRIDE]
+    assert rel_err(fake, z["fake_sample"]) < 1e-4
+    lrG, lrD = tr.optimStateG["learningRate"], tr.optimStateD["learningRate"]
+    for net, gk, pk, lr in ((tr.netG, "gG", "pG", lrG), (tr.netD, "gD", "pD", lrD)):
+        g = to_np(net.reference_flat(grads=True))
+        gs, want = g[::mk.STRIDE], z[gk + "_sample"]
+        # the samples' own max understates the vector's max-norm; the stored sum of squares gives its rms scale
+        scale = max(np.abs(want).max(), 1e-30)
+        assert np.abs(gs - want).max() <= 2e-2 * scale, (gk, np.abs(gs - want).max() / scale)
+        assert abs(float(g.astype(np.float64).sum()) - z[gk + "_sums"][0]) <= 2e-2 * np.sqrt(z[gk + "_sums"][1] * g.size)
+        p = to_np(net.reference_flat())[::mk.STRIDE]
+        sel = np.abs(want) > 1e-2 * scale
+        assert np.abs(p - z[pk + "_sample"])[sel].max() <= 0.02 * lr, (pk, np.abs(p - z[pk + "_sample"])[sel].max() / lr)
+
+
+@pytest.mark.parametrize("cfg", ["vid16", "wholeim-half"])
+def test_video_nets_against_the_oracle_at_run_time(cfg, oracle, hipb):
+    """The oracle itself beside the HIP path, from identical weights and batches, one iteration with every (Leaky)ReLU
+    kink pinned (helpers.KinkSync) so that gradients are held to 1e-4:
+      vid16         configs[2] at FULL width (48 channels, nBottleneck 4000), batchSize 4 of its 16;
+      wholeim-half  configs[4]'s nets at half width (27 -> 12 channels, nef = ngf = 96, ndf = 64, nBottleneck 1600), wtgdl 0.5,
+                    batchSize 4 — the full-width oracle iteration takes minutes and is the committed fixture above."""
+    from helpers import FastRng, KinkSync, rel_err, to_np
+    from video_filler_amd.trainers import VidTrainer
+    if cfg == "vid16":
+        opt, nci, nco = dict(VID16_OPT), 48, 48
+    else:
+        opt, nci, nco = dict(WHOLEIM_OPT, nef=96, ngf=96, ndf=64, nBottleneck=1600), 27, 12
+    oracle.set_num_threads(16)
+    try:
+        ref = oracle.VidTrainer(opt, FastRng(5))
+        tr = VidTrainer(opt)
+        dev = tr.parametersG.device
+        tr.netG.load_reference_flat(torch.from_numpy(ref.parametersG.copy()).to(dev))
+        tr.netD.load_reference_flat(torch.from_numpy(ref.parametersD.copy()).to(dev))
+        ctx, full, mask = oracle.synth_vid_batch(4, np.random.default_rng(6), nci, nco)
+        ref.set_batch(ctx, full, mask)
+        tr.set_batch(torch.from_numpy(ctx), torch.from_numpy(full), torch.from_numpy(mask))
+        ks = KinkSync(oracle, [(ref.netG, tr.netG), (ref.netD, tr.netD)])
+        ks.oracle_step(ref.step)
+        ks.hip_step(tr.step)
+    finally:
+        oracle.set_num_threads(1)
+    got = tr.losses()
+    for k in ("errD", "errG", "errG_l2", "errG_gdl"):
+        want = getattr(ref, k, None)
+        if want is not None:
+            assert abs(got[k] - want) <= 2e-5 * max(1.0, abs(want)), (k, got[k], want)
+    assert rel_err(to_np(tr.netG.output), ref.netG.output) < 1e-4
+    for net, gref, nm in ((tr.netD, ref.gradParametersD, "D"), (tr.netG, ref.gradParametersG, "G")):
+        e = rel_err(to_np(net.reference_flat(grads=True)), gref)
+        assert e <= 1e-4, "%s grad%s max-norm rel err %.3e" % (cfg, nm, e)

@@ -120,10 +120,19 @@ def test_tiles_gather_scatter_roundtrip_and_layout(groups, nc, oracle, hipb):
 
 
 def _small_netG(oracle, hipb, nc_in, nc_out, seed):
+    """A small generator whose OUTPUT DEPENDS ON ITS INPUT in evaluate() mode: with weights_init's N(0, 0.02) and running
+    variances near 1 the signal dies layer by layer and the net returns the same image whatever it is fed (a constant
+    function passes any gather / flip / fill-in test).  Convolution weights are therefore scaled to ~1/sqrt(fan_in)."""
     from video_filler_amd.trainers import build_netG
     rng = np.random.default_rng(seed)
     ref = oracle.build_netG(nc_in, nc_out, 8, 8, 32, True)
     oracle.weights_init(ref, rng)
+
+    def widen(m):
+        if "Convolution" in m.type_name():
+            m.weight *= np.float32(6.0)
+
+    ref.apply(widen)
     pref, _ = ref.getParameters()
     net = build_netG(nc_in, nc_out, 8, 8, 32, True)
     net.getParameters()
@@ -156,9 +165,27 @@ def test_whole_image_inpainting_matches_the_tile_loop(inputLen, with_init, oracl
     full = rng.uniform(-1, 1, (predLen * nc, H, W)).astype(np.float32)
     padmask = np.zeros((nc, H, W), np.uint8)
     padmask[:, 60:200, 100:420] = 1
-    want_out, want_inp, want_full = oracle.whole_image_inpaint(ref, full, padmask, predLen, inputLen, fs, nc, refI, padmask)
+    # the fill-in mask is NOT symmetric under a vertical flip inside the three flipped tiles of the top row, so a mask
+    # tile gathered with the image's flip (the reference slices it un-flipped, test_vid_wholeim.lua:183) is caught
+    mid_mask = np.zeros((nc, H, W), np.uint8)
+    mid_mask[:, 8:50, 20:330] = 1
+    mid_mask[:, 150:230, 300:480] = 1
+    want_out, want_inp, want_full = oracle.whole_image_inpaint(ref, full, padmask, predLen, inputLen, fs, nc, refI, mid_mask)
+    # the oracle's answer must react to its inputs by far more than the tolerance below, or this test tests nothing:
+    # (a) another image in one tile, (b) with the initializer path, the mask flipped inside the flipped tiles
+    full2 = full.copy()
+    full2[:, 128:256, 128:256] = rng.uniform(-1, 1, (predLen * nc, 128, 128)).astype(np.float32)
+    alt = oracle.whole_image_inpaint(ref, full2, padmask, predLen, inputLen, fs, nc, refI, mid_mask)[0]
+    assert rel_err(alt[:, :, 128:256, 128:256], want_out[:, :, 128:256, 128:256]) > 1e-2
+    if with_init:
+        mm2 = mid_mask.copy()
+        mm2[:, 0:128, 0:384] = mid_mask[:, 127::-1, 0:384]
+        alt = oracle.whole_image_inpaint(ref, full, padmask, predLen, inputLen, fs, nc, refI, mm2)[0]
+        assert rel_err(alt, want_out) > 1e-2
+        alt = oracle.whole_image_inpaint(ref, full, padmask, predLen, inputLen, fs, nc, None, None)[0]
+        assert rel_err(alt, want_out) > 1e-2
     run = WholeImageInpainter(net, predLen, inputLen, fs, nc, netI)
-    out, inp, fullv = run(torch.from_numpy(full), torch.from_numpy(padmask), torch.from_numpy(padmask))
+    out, inp, fullv = run(torch.from_numpy(full), torch.from_numpy(padmask), torch.from_numpy(mid_mask))
     assert tuple(out.shape) == (predLen, nc, H, W)
     assert rel_err(to_np(out), want_out) < 5e-5
     assert rel_err(to_np(inp), want_inp) < 5e-5

@@ -10,11 +10,14 @@ Stated fp32 tolerances
     update within 2% of one learning-rate step (m, v: 1e-4 max-norm) wherever |g| > 1e-3 max|g| — below that
     Adam's g/(|g|+eps') is ill-conditioned and the reference itself is summation-order dependent (DESIGN.md
     "Adam amplifies rounding").
-  * gradients, REAL nets: 3e-2 of the max-norm.  LeakyReLU/ReLU derivatives are discontinuous at 0 and every
-    128x128 batch puts tens of pre-activations within 1e-6 of 0 (scripts/debug_trainer.py prints them); a 1e-8
-    summation-order difference flips such an element's derivative between 1 and 0.2 and moves a small-batch
-    weight gradient by up to ~1e-2 of its norm.  The reference's own CPU and cudnn paths differ the same way.
-    The smooth run isolates everything else at fp32 precision.
+  * gradients and parameters, REAL nets: the SAME bars (1e-4 / 2% of lr), with the derivative choice of every
+    (Leaky)ReLU element that sits within 1e-5 (relative to its tensor's max) of the kink pinned to the oracle's
+    (`helpers.KinkSync`: the oracle runs first and records its activated tensors; during the HIP forward those few
+    elements are overwritten with the oracle's values, a perturbation of <= 1e-5 on a handful of elements).  Without
+    that pin a pre-activation within rounding distance of 0 takes slope 1 on one side and 0.2 on the other and moves a
+    small-batch weight gradient by up to ~1e-2 of its norm in ANY two fp32 implementations; with it, a wrong activation
+    mask anywhere (vf_conv2d_bwd_data_act, the BatchNorm-backward masking, vf_act_bwd) shows up at the 1e-4 bar.
+    Elements further than 1e-5 from the kink are never touched, so a forward error that flips them still fails.
   * between the two iterations the carried state (parameters, Adam m/v, BN running statistics) is first compared
     and then re-synchronised from the oracle: Adam's first steps turn 1e-8 gradient differences on
     near-zero-gradient weights into +-lr parameter differences, so un-synchronised trajectories drift apart at
@@ -24,7 +27,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_err, to_np
+from helpers import KinkSync, rel_err, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -74,24 +77,23 @@ def _check_iteration(ref, tr, it, lrG, lrD, tag, smooth):
             (tr.netG, ref.netG, ref.gradParametersG, ref.parametersG, tr.optimStateG, ref.optimStateG, lrG, "G")):
         g = to_np(net.reference_flat(grads=True))
         e = rel_err(g, gref)
-        assert e <= (1e-4 if smooth else 3e-2), "%s it%d grad%s max-norm rel err %.3e" % (tag, it, nm, e)
-        if smooth:
-            sel = np.abs(gref) > 1e-3 * np.abs(gref).max()
-            p = to_np(net.reference_flat())
-            d = np.abs(p - pref)[sel].max()
-            assert d <= 0.02 * lr, "%s it%d param%s: max |dp| %.3e > 2%% of lr %.1e" % (tag, it, nm, d, lr)
-            assert rel_err(_from_internal(net, st["m"]), rst["m"]) <= 1e-4, "%s it%d adam m %s" % (tag, it, nm)
-            assert rel_err(_from_internal(net, st["v"]), rst["v"]) <= 2e-4, "%s it%d adam v %s" % (tag, it, nm)
-            assert int(st["t_dev"][0].item()) == rst["t"] == it + 1
-            rb = [m for m in _leaves(rnet) if hasattr(m, "running_mean")]
-            hb = [m for m in net.leaves() if hasattr(m, "running_mean")]
-            assert len(rb) == len(hb)
-            for a, b in zip(rb, hb):
-                # means are compared on the scale of the channel spread (a decoder BN fed by a zero-mean
-                # bottleneck has running_mean ~ 1e-9, pure rounding noise)
-                scale = max(np.abs(a.running_mean).max(), np.sqrt(a.running_var).max())
-                assert np.abs(to_np(b.running_mean) - a.running_mean).max() <= 1e-4 * scale
-                assert rel_err(to_np(b.running_var), a.running_var) < 1e-4
+        assert e <= 1e-4, "%s it%d grad%s max-norm rel err %.3e" % (tag, it, nm, e)
+        sel = np.abs(gref) > 1e-3 * np.abs(gref).max()
+        p = to_np(net.reference_flat())
+        d = np.abs(p - pref)[sel].max()
+        assert d <= 0.02 * lr, "%s it%d param%s: max |dp| %.3e > 2%% of lr %.1e" % (tag, it, nm, d, lr)
+        assert rel_err(_from_internal(net, st["m"]), rst["m"]) <= 1e-4, "%s it%d adam m %s" % (tag, it, nm)
+        assert rel_err(_from_internal(net, st["v"]), rst["v"]) <= 2e-4, "%s it%d adam v %s" % (tag, it, nm)
+        assert int(st["t_dev"][0].item()) == rst["t"] == it + 1
+        rb = [m for m in _leaves(rnet) if hasattr(m, "running_mean")]
+        hb = [m for m in net.leaves() if hasattr(m, "running_mean")]
+        assert len(rb) == len(hb)
+        for a, b in zip(rb, hb):
+            # means are compared on the scale of the channel spread (a decoder BN fed by a zero-mean
+            # bottleneck has running_mean ~ 1e-9, pure rounding noise)
+            scale = max(np.abs(a.running_mean).max(), np.sqrt(a.running_var).max())
+            assert np.abs(to_np(b.running_mean) - a.running_mean).max() <= 1e-4 * scale
+            assert rel_err(to_np(b.running_var), a.running_var) < 1e-4
 
 
 def _resync(ref, tr):
@@ -126,12 +128,13 @@ def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle
     tr.set_batch_d(batch_d)
     _load(tr, ref)
     assert len([m for m in tr.netG.leaves() if hasattr(m, "running_mean")]) == 9
+    ks = KinkSync(oracle, [(ref.netG, tr.netG), (ref.netD, tr.netD)])
     for it in range(2):
         batch = oracle.synth_center_batch(3, np.random.default_rng(10 + it))
         ref.set_batch(batch)
         tr.set_batch(torch.from_numpy(batch))
-        ref.step()
-        tr.step()
+        ks.oracle_step(ref.step)
+        ks.hip_step(tr.step)
         _check_iteration(ref, tr, it, 0.002, 0.0002, "center fuse=%s smooth=%s" % (fuse, smooth), smooth)
         _resync(ref, tr)
 
@@ -149,12 +152,13 @@ def test_center_trainer_option_branches(variant, smooth, oracle, hipb):
     tr = CenterTrainer(opt, seed=4321)
     ref.noise_seed = 4321
     _load(tr, ref)
+    ks = KinkSync(oracle, [(ref.netG, tr.netG), (ref.netD, tr.netD)])
     for it in range(2):
         batch = oracle.synth_center_batch(3, np.random.default_rng(60 + it))
         ref.set_batch(batch)
         tr.set_batch(torch.from_numpy(batch))
-        ref.step()
-        tr.step()
+        ks.oracle_step(ref.step)
+        ks.hip_step(tr.step)
         if opt["noiseGen"]:
             assert np.abs(to_np(tr.noise).reshape(ref.noise.shape) - ref.noise).max() < 1e-5
         _check_iteration(ref, tr, it, 0.002, 0.0002, "center %s smooth=%s" % (variant, smooth), smooth)
@@ -195,15 +199,60 @@ def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
         hI.load_reference_flat(torch.from_numpy(pI.copy()).to(tr.parametersG.device))
         ref.netI = rI
         tr.set_initializer(hI)
+    ks = KinkSync(oracle, [(ref.netG, tr.netG), (ref.netD, tr.netD)] + ([(rI, hI)] if variant == "withInit" else []))
     for it in range(2):
         ctx, full, mask = oracle.synth_vid_batch(4, np.random.default_rng(20 + it), nc_in, nc_out)   # B = 4: BatchNorm over
         # the 1x1 bottleneck needs more than 2 samples to be well conditioned
         ref.set_batch(ctx, full, mask)
         tr.set_batch(torch.from_numpy(ctx), torch.from_numpy(full), torch.from_numpy(mask))
-        ref.step()
-        tr.step()
+        ks.oracle_step(ref.step)
+        ks.hip_step(tr.step)
         _check_iteration(ref, tr, it, 0.002, 0.0002, "vid %s smooth=%s" % (variant, smooth), smooth)
         _resync(ref, tr)
+
+
+def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hipb):
+    """Nothing is carried over from the oracle: after the common start both sides run three whole iterations on their
+    own parameters, Adam moments and BatchNorm running statistics.  Adam's first steps move a weight by up to one
+    learning rate whatever the size of its gradient, and the sign of a gradient that is pure rounding noise (conv biases
+    in front of BatchNorm: true gradient 0) is implementation-defined, so the trajectories are NOT expected to stay
+    within fp32 rounding; the stated drift bound is
+      * losses: 2e-3 relative after three iterations (they are continuous in the parameters);
+      * parameters whose oracle gradient is significant (|g| > 1e-3 max|g| in every iteration): within 10% of one
+        learning-rate step of the oracle's after three steps;
+      * every parameter: within 2 * lr * iterations (the worst case of Adam itself), and fewer than 2% of them further
+        than one learning-rate step apart."""
+    from video_filler_amd.trainers import CenterTrainer
+    opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
+    ref = oracle.CenterTrainer(opt, np.random.default_rng(1))
+    tr = CenterTrainer(opt)
+    _load(tr, ref)
+    ks = KinkSync(oracle, [(ref.netG, tr.netG), (ref.netD, tr.netD)])
+    sig = {"G": None, "D": None}
+    for it in range(3):
+        batch = oracle.synth_center_batch(3, np.random.default_rng(10 + it))
+        ref.set_batch(batch)
+        tr.set_batch(torch.from_numpy(batch))
+        ks.oracle_step(ref.step)
+        ks.hip_step(tr.step)
+        for nm, gref in (("G", ref.gradParametersG), ("D", ref.gradParametersD)):
+            s = np.abs(gref) > 1e-3 * np.abs(gref).max()
+            sig[nm] = s if sig[nm] is None else (sig[nm] & s)
+    got = tr.losses()
+    report = {}
+    for k in ("errD", "errG", "errG_l2"):
+        want = getattr(ref, k)
+        report[k] = abs(got[k] - want) / max(1.0, abs(want))
+        assert report[k] <= 2e-3, (k, got[k], want)
+    for net, pref, lr, nm in ((tr.netD, ref.parametersD, 0.0002, "D"), (tr.netG, ref.parametersG, 0.002, "G")):
+        d = np.abs(to_np(net.reference_flat()) - pref)
+        report["max_" + nm] = float(d.max() / lr)
+        report["sig_" + nm] = float(d[sig[nm]].max() / lr)
+        report["frac_" + nm] = float((d > lr).mean())
+        assert d.max() <= 2 * lr * 3
+        assert d[sig[nm]].max() <= 0.1 * lr, (nm, d[sig[nm]].max() / lr)
+        assert (d > lr).mean() < 0.02
+    print("drift after 3 un-synchronised iterations (units of lr):", report)
 
 
 def test_graph_replay_matches_eager(oracle, hipb):
@@ -367,3 +416,45 @@ def test_netG_evaluate_mode_forward(oracle, hipb):
     # evaluate mode must not touch the running statistics
     for a, b in zip(rb, hb):
         np.testing.assert_array_equal(to_np(b.running_mean), a.running_mean)
+
+
+def test_an_error_inside_a_backward_walk_does_not_poison_later_walks(hipb):
+    """nn.Sequential records the weight-gradient GEMMs of a backward walk and launches them together at its end
+    (vf_wgrad_group_begin/_end).  A raise in mid-walk must close that group (vf_wgrad_group_abort): otherwise every later
+    walk would skip begin/end while the library kept recording, and gradWeight would silently stay stale for ever."""
+    from video_filler_amd import nn
+    from video_filler_amd.trainers import build_netD, weights_init
+    gen = torch.Generator().manual_seed(11)
+    a, b = build_netD(16, 16, False), build_netD(16, 16, False)
+    weights_init(a, gen)
+    a.getParameters()
+    b.getParameters()
+    b.load_reference_flat(a.reference_flat())
+    x = (torch.rand((4, 16, 64, 64), generator=gen) * 2 - 1).to(hipb.device).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn((4, 1), generator=gen).to(hipb.device)
+    for net in (a, b):
+        net.forward(x)
+        net.zeroGradParameters()
+
+    class Boom(RuntimeError):
+        pass
+
+    first = a.leaves()[0]
+    orig = first.accGradParameters
+
+    def explode(*args, **kw):
+        raise Boom("injected")
+
+    first.accGradParameters = explode            # the LAST module the walk reaches: the layers above are already recorded
+    with pytest.raises(Boom):
+        a.backward(x, gy)
+    assert not nn.Sequential._group_open
+    first.accGradParameters = orig
+    a.forward(x)
+    a.zeroGradParameters()
+    a.backward(x, gy)
+    b.backward(x, gy)
+    torch.cuda.synchronize()
+    ga, gb = a.reference_flat(grads=True), b.reference_flat(grads=True)
+    assert float(gb.abs().max()) > 0
+    assert torch.equal(ga, gb)

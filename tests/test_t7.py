@@ -194,3 +194,41 @@ def test_reads_pre_2016_running_std(cpu_backend):
     seq = t7.TorchObject("nn.Sequential", dict(modules=[bn], train=True))
     net = t7.net_from_t7(t7.loads(t7.dumps(seq)))
     np.testing.assert_allclose(net.leaves()[0].running_var.numpy(), var, rtol=1e-5)
+
+
+def test_bare_long_storage_known_bytes_and_view_size_form():
+    """nn.View.size / nn.JoinTable.size are torch.LongStorage objects in Torch7 (View:resetSize, JoinTable.__init), not
+    LongTensors: a bare storage is `4, index, "V 1", "torch.LongStorage", int64 n, n x int64`."""
+    want = i32(4) + i32(1) + lstr("V 1") + lstr("torch.LongStorage") + i64(2) + i64(1) + i64(-1)
+    assert t7.dumps(t7.Storage(np.array([1, -1], np.int64))) == want
+    np.testing.assert_array_equal(t7.loads(want), [1, -1])
+
+
+def test_view_and_jointable_sizes_are_written_as_storages(cpu_backend):
+    from video_filler_amd import nn
+    from video_filler_amd.trainers import build_netD
+    tree = t7.net_to_t7(build_netD(3, 8, False, conditionAdv=True))
+    mods = [tree["modules"][i] for i in range(len(tree["modules"]))]
+    view = [m for m in mods if m.cls == "nn.View"][0]
+    join = [m for m in mods if m.cls == "nn.JoinTable"][0]
+    assert isinstance(view["size"], t7.Storage) and list(view["size"].arr) == [1]
+    assert isinstance(join["size"], t7.Storage) and len(join["size"]) == 0
+    data = t7.dumps(tree)
+    assert data.count(b"torch.LongStorage") == 2 and b"torch.LongTensor" not in data
+    back = t7.net_from_t7(t7.loads(data))
+    assert isinstance(back.modules[-1], nn.View) and back.modules[-1].sizes == (1,)
+
+
+def test_tensor_views_outside_their_storage_are_rejected():
+    """size / stride / offset are read from the file; a view that leaves its storage must raise, not read out of bounds."""
+    def tensor(size, stride, off, n):
+        b = i32(4) + i32(1) + lstr("V 1") + lstr("torch.FloatTensor") + i32(len(size))
+        b += b"".join(i64(v) for v in size) + b"".join(i64(v) for v in stride) + i64(off)
+        b += i32(4) + i32(2) + lstr("V 1") + lstr("torch.FloatStorage") + i64(n) + struct.pack("<%df" % n, *range(n))
+        return b
+    np.testing.assert_array_equal(t7.loads(tensor([2, 3], [3, 1], 1, 6)), np.arange(6, dtype=np.float32).reshape(2, 3))
+    np.testing.assert_array_equal(t7.loads(tensor([2, 2], [1, 2], 2, 6)), [[1, 3], [2, 4]])      # offset is 1-based
+    for bad in (tensor([2, 3], [3, 1], 2, 6), tensor([2, 3], [4, 1], 1, 6), tensor([7], [1], 1, 6), tensor([2], [1], 0, 6),
+                tensor([2], [-1], 1, 6)):
+        with pytest.raises(ValueError):
+            t7.loads(bad)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vf_conv2d_bwd_data_act": (i32, [vp, vp, vp, vp, vp, i32, f32, i32, i32, i32, i32, i32, i32, i32, i32]),
     "vf_wgrad_group_begin": (i32, [vp]),
     "vf_wgrad_group_end": (i32, [vp]),
+    "vf_wgrad_group_abort": (i32, [vp]),
     "vf_bias_grad_plan": (i32, [i64, i32, vp, vp, vp, vp]),
     "vf_bias_grad_multi": (i32, [vp, vp, i32, i32, i32]),
     "vf_center_prepare": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32]),

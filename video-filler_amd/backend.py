@@ -159,6 +159,9 @@ class HipBackend:
     def wgrad_group_end(self):
         self._c("vf_wgrad_group_end")
 
+    def wgrad_group_abort(self):
+        self._c("vf_wgrad_group_abort")
+
     # ---- all conv bias gradients of one backward walk in two launches (vf_bias_grad_multi)
     def bias_grad_multi(self, items):
         """items: [(gradOutput B x C x H x W channels-last, gradBias [C], beta)], C % 4 == 0.  The descriptor table is built

@@ -1605,6 +1605,14 @@ VF_API int vf_wgrad_group_begin(vf_ctx* ctx) {
   ctx->wg_active = 1;
   return 0;
 }
+VF_API int vf_wgrad_group_abort(vf_ctx* ctx) {
+  if (ctx->wg_rec) {
+    ((WgRecorder*)ctx->wg_rec)->recs.clear();
+    ((WgRecorder*)ctx->wg_rec)->ws_used = 0;
+  }
+  ctx->wg_active = 0;
+  return 0;
+}
 VF_API int vf_wgrad_group_end(vf_ctx* ctx) {
   VF_REQUIRE(ctx->wg_active, "vf_wgrad_group_end: no group is open");
   ctx->wg_active = 0;

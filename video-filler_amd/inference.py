@@ -61,7 +61,9 @@ class WholeImageInpainter:
             mid = self.netI.forward(tiles)
             mm = B.from_host(mid_mask).float().contiguous()
             tmask = nhwc_empty(TY * TX, nc, fs, fs, full.device)
-            B.tiles_gather(mm, tmask, 1, flips)       # the mask tile follows its (possibly flipped) image tile ...
+            # :183-189 — the mask tile is sliced UN-flipped (`mid_mask[{{}, {h, h+fs-1}, {w, w+fs-1}}]`) and applied to the
+            # flipped patch: the script flips the image tile only, and so does this
+            B.tiles_gather(mm, tmask, 1, None)
             tmask = tmask.repeat_interleave(G, dim=0).contiguous(memory_format=torch.channels_last)
             filled = torch.empty_like(tiles)
             B.masked_compose(filled, tiles, mid, tmask)

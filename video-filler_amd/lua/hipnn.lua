@@ -66,6 +66,7 @@ int vf_adam_prep(vf_ctx*, double lr, double beta1, double beta2, int32_t* t_dev)
 int vf_adam_apply(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
+int vf_wgrad_group_abort(vf_ctx* ctx);
 int vf_bias_grad_plan(int64_t P, int C, int* cq, int* rows_per_block, int* gx, int* gy);
 int vf_bias_grad_multi(vf_ctx*, const void* desc_dev, int n, int blocks1, int blocks2);
 int vf_center_prepare(vf_ctx*, const float* batch_nchw, float* ctx_nhwc, float* center_nhwc, const float* fill, int B, int C, int fs, int overlapPred);
@@ -99,6 +100,7 @@ function hipnn.setMfmaMode(mode) check(C.vf_ctx_set_mfma_mode(hipnn.ctx, mode)) 
 -- every weight gradient recorded between these two runs as one grouped launch (wrap net:backward with them)
 function hipnn.beginBackward() check(C.vf_wgrad_group_begin(hipnn.ctx)) end
 function hipnn.endBackward() check(C.vf_wgrad_group_end(hipnn.ctx)) end
+function hipnn.abortBackward() check(C.vf_wgrad_group_abort(hipnn.ctx)) end   -- after an error inside a backward walk
 
 local function fptr(t) return ffi.cast('float*', t:data()) end
 

@@ -538,6 +538,10 @@ _NO_BN_GROUPS = bool(__import__("os").environ.get("VF_NO_BN_GROUPS"))
 class Sequential(Module):
     _type = "nn.Sequential"
     _group_open = False       # a backward walk has a weight-gradient group open (single-threaded host code)
+    # parity-test aid: act_hook(act_module, activated_tensor) runs after every (Leaky)ReLU of a forward pass, fused or not;
+    # tests/test_gpu_trainers.py uses it to pin the derivative choice of pre-activations that sit within rounding
+    # distance of the kink to the oracle's.  None (always, outside that test): no call, no cost.
+    act_hook = None
 
     def __init__(self, fuse=True, lazy_zero=True):
         super().__init__()
@@ -605,9 +609,13 @@ class Sequential(Module):
                 before[1]()
             if a is None:
                 cur = m.updateOutput(cur)
+                if Sequential.act_hook is not None and isinstance(m, _Act) and m.act in ("lrelu", "relu"):
+                    Sequential.act_hook(m, cur)
             else:
                 cur = m.updateOutput(cur, a.act, a.slope)
                 a.output = cur
+                if Sequential.act_hook is not None and a.act in ("lrelu", "relu"):
+                    Sequential.act_hook(a, cur)
         self.output = cur
         return cur
 
@@ -629,63 +637,71 @@ class Sequential(Module):
             Sequential._group_open = True
         hi = len(plan) if hi is None else hi
         act_done = self._act_done_at == hi if hi < len(plan) else False
-        for idx in range(hi - 1, lo - 1, -1):
-            m, a = plan[idx]
-            x = input if idx == 0 else plan[idx - 1][0].output
-            mout = m.output
-            gbuf = "gradInput"
-            if group is not None:
-                gi, G = group
-                gbuf = "gradInput_g"
-                h = mout.shape[0] // G
-                mout = mout[gi * h:(gi + 1) * h]
-                if idx > 0:
-                    x = x[gi * h:(gi + 1) * h]
-            want_gx = need_input_grad or idx > 0
-            if isinstance(m, ParallelTable):
-                assert group is None, "group passes are built for plain chains"
-                g = m.walk(x, g, want_gx, want_gp)
+        try:
+            for idx in range(hi - 1, lo - 1, -1):
+                m, a = plan[idx]
+                x = input if idx == 0 else plan[idx - 1][0].output
+                mout = m.output
+                gbuf = "gradInput"
+                if group is not None:
+                    gi, G = group
+                    gbuf = "gradInput_g"
+                    h = mout.shape[0] // G
+                    mout = mout[gi * h:(gi + 1) * h]
+                    if idx > 0:
+                        x = x[gi * h:(gi + 1) * h]
+                want_gx = need_input_grad or idx > 0
+                if isinstance(m, ParallelTable):
+                    assert group is None, "group passes are built for plain chains"
+                    g = m.walk(x, g, want_gx, want_gp)
+                    act_done = False
+                    continue
+                if isinstance(m, SpatialBatchNormalization):
+                    gsel = None if group is None else group[0]
+                    if a is None:
+                        g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf)
+                    else:
+                        a.gradInput = g
+                        g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, mout, group=gsel, buf=gbuf)
+                else:
+                    if a is not None:
+                        if not act_done:
+                            B.act_bwd(mout, g, g, a.act, a.slope)   # in place on the incoming gradient
+                        a.gradInput = g
+                    # the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this
+                    # module's data-gradient epilogue (x IS that activated output)
+                    in_act = None
+                    if (self.fuse and want_gx and idx > 0 and type(m) is SpatialConvolution and m.dH == 2 and m.kH == 4 and m.padH == 1 and hasattr(B, "conv2d_bwd_data_act")):
+                        pm, pa = plan[idx - 1]
+                        if pa is not None and pa.act in ("lrelu", "relu") and not isinstance(pm, SpatialBatchNormalization):
+                            in_act = (pa.act, pa.slope)
+                    if isinstance(m, SpatialConvolution):
+                        upd = lambda: m.updateGradInput(x, g, in_act, gbuf)
+                    elif group is not None and isinstance(m, _Act):
+                        upd = lambda: m.updateGradInput(x, g, mout)
+                    else:
+                        upd = lambda: m.updateGradInput(x, g)
+                    if want_gp and self.side is not None and m.parameters():
+                        # dW/db only read x and g; nothing on the main stream writes either before the join below
+                        with self.side.on():
+                            self._acc(m, x, g, deferred)
+                        used_side = True
+                        gin = upd() if want_gx else None
+                    else:
+                        gin = upd() if want_gx else None
+                        if want_gp:
+                            self._acc(m, x, g, deferred)
+                    g = gin
+                    act_done = in_act is not None
+                    continue
                 act_done = False
-                continue
-            if isinstance(m, SpatialBatchNormalization):
-                gsel = None if group is None else group[0]
-                if a is None:
-                    g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf)
-                else:
-                    a.gradInput = g
-                    g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, mout, group=gsel, buf=gbuf)
-            else:
-                if a is not None:
-                    if not act_done:
-                        B.act_bwd(mout, g, g, a.act, a.slope)   # in place on the incoming gradient
-                    a.gradInput = g
-                # the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this
-                # module's data-gradient epilogue (x IS that activated output)
-                in_act = None
-                if (self.fuse and want_gx and idx > 0 and type(m) is SpatialConvolution and m.dH == 2 and m.kH == 4 and m.padH == 1 and hasattr(B, "conv2d_bwd_data_act")):
-                    pm, pa = plan[idx - 1]
-                    if pa is not None and pa.act in ("lrelu", "relu") and not isinstance(pm, SpatialBatchNormalization):
-                        in_act = (pa.act, pa.slope)
-                if isinstance(m, SpatialConvolution):
-                    upd = lambda: m.updateGradInput(x, g, in_act, gbuf)
-                elif group is not None and isinstance(m, _Act):
-                    upd = lambda: m.updateGradInput(x, g, mout)
-                else:
-                    upd = lambda: m.updateGradInput(x, g)
-                if want_gp and self.side is not None and m.parameters():
-                    # dW/db only read x and g; nothing on the main stream writes either before the join below
-                    with self.side.on():
-                        self._acc(m, x, g, deferred)
-                    used_side = True
-                    gin = upd() if want_gx else None
-                else:
-                    gin = upd() if want_gx else None
-                    if want_gp:
-                        self._acc(m, x, g, deferred)
-                g = gin
-                act_done = in_act is not None
-                continue
-            act_done = False
+        except BaseException:
+            # a raise in mid-walk (shape assert, VF_REQUIRE through _lib.check) must not leave the group open: later walks
+            # would skip begin/end while the library kept recording, and no weight gradient would ever be launched again
+            if grouped:
+                Sequential._group_open = False
+                B.wgrad_group_abort()
+            raise
         if grouped:
             Sequential._group_open = False
             B.wgrad_group_end()

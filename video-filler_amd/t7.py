@@ -31,6 +31,17 @@ _TENSOR = {"torch.FloatTensor": ("torch.FloatStorage", np.float32), "torch.Doubl
 _STORAGE = {s: d for s, d in _TENSOR.values()}
 
 
+class Storage:
+    """A bare torch.XStorage (not wrapped in a tensor): nn.View.size and nn.JoinTable.size are torch.LongStorage in
+    Torch7 (View:resetSize, JoinTable.__init), and View:updateOutput calls storage methods on them."""
+
+    def __init__(self, arr):
+        self.arr = np.ascontiguousarray(arr).reshape(-1)
+
+    def __len__(self):
+        return self.arr.size
+
+
 class TorchObject:
     """An instance of a torch class without a payload of its own (nn modules): class name + field table."""
 
@@ -100,6 +111,13 @@ class Reader:
                 if storage is None or nd == 0:
                     arr = np.zeros((0,), _TENSOR[cls][1])
                 else:
+                    # size / stride / offset come from the file: a view that leaves the storage is a malformed checkpoint
+                    if off < 0 or any(n < 0 for n in size) or any(st < 0 for st in stride):
+                        raise ValueError("tensor with negative size, stride or offset at byte %d" % self.pos)
+                    last = off + sum((n - 1) * st for n, st in zip(size, stride)) if all(n > 0 for n in size) else off
+                    if all(n > 0 for n in size) and last >= len(storage):
+                        raise ValueError("tensor view [offset %d, last element %d] exceeds its storage of %d elements"
+                                         % (off, last, len(storage)))
                     arr = np.lib.stride_tricks.as_strided(storage[off:], shape=size, strides=[s * storage.itemsize for s in stride]).copy()
                 self.memo[idx] = arr
                 return arr
@@ -204,6 +222,18 @@ class Writer:
                 self._string(_TENSOR[cls][0])
                 self._put("q", storage.size)
                 self.out.append(storage.astype(storage.dtype.newbyteorder("<")).tobytes())
+        elif isinstance(obj, Storage):
+            cls = {np.dtype(np.float32): "torch.FloatStorage", np.dtype(np.float64): "torch.DoubleStorage",
+                   np.dtype(np.int64): "torch.LongStorage", np.dtype(np.int32): "torch.IntStorage",
+                   np.dtype(np.uint8): "torch.ByteStorage"}[obj.arr.dtype]
+            self._put("i", TYPE_TORCH)
+            idx, first = self._index(obj)
+            self._put("i", idx)
+            if first:
+                self._string("V 1")
+                self._string(cls)
+                self._put("q", obj.arr.size)
+                self.out.append(obj.arr.astype(obj.arr.dtype.newbyteorder("<")).tobytes())
         elif isinstance(obj, TorchObject):
             self._put("i", TYPE_TORCH)
             idx, first = self._index(obj)
@@ -254,7 +284,7 @@ def net_to_t7(net):
         if isinstance(m, nn.ParallelTable):         # train.lua:115,168 (noiseGen / conditionAdv nets)
             return base(m, "nn.ParallelTable", modules=[conv(c) for c in m.modules])
         if isinstance(m, nn.JoinTable):
-            return base(m, "nn.JoinTable", dimension=m.dimension, size=np.zeros((0,), np.int64))
+            return base(m, "nn.JoinTable", dimension=m.dimension, size=Storage(np.zeros((0,), np.int64)))
         if isinstance(m, nn.SpatialFullConvolution) or isinstance(m, nn.SpatialConvolution):
             f = dict(nInputPlane=m.nInputPlane, nOutputPlane=m.nOutputPlane, kW=m.kW, kH=m.kH, dW=m.dW, dH=m.dH, padW=m.padW,
                      padH=m.padH, weight=host(m.weight), bias=host(m.bias))
@@ -274,7 +304,7 @@ def net_to_t7(net):
         if isinstance(m, nn.Sigmoid):
             return base(m, "nn.Sigmoid")
         if isinstance(m, nn.View):
-            return base(m, "nn.View", size=np.asarray(m.sizes, np.int64), numElements=int(np.prod([s for s in m.sizes if s > 0])),
+            return base(m, "nn.View", size=Storage(np.asarray(m.sizes, np.int64)), numElements=int(np.prod([s for s in m.sizes if s > 0])),
                         numInputDims=getattr(m, "numInputDims", None))
         raise TypeError("no Torch7 form for %r" % m)
 
