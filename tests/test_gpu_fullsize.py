@@ -111,7 +111,19 @@ def test_batchnorm_invariants_full_size(B, C, HW, hipb):
     hipb.bn_bwd(x, None, gy, gx, gg, gb, gamma, sm, si, sums, "none", 0.0, 0.0)
     scale = float(gy.abs().max())
     assert float(gx.double().sum(dim=(0, 2, 3)).abs().max()) / n < 1e-6 * scale      # sum_p gx = 0
-    assert float((gx.double() * yd).sum(dim=(0, 2, 3)).abs().max()) / n < 1e-5 * scale   # sum_p gx*xhat = 0
+    # sum_p gx*(x-mean) = invstd*gamma*dotp * eps/(var+eps): zero up to the eps term, which only matters for channels whose
+    # batch variance is tiny (n = 4 samples at the 1x1 bottleneck: some of 6400 channels have var ~ 1e-2)
+    xd = x.double()
+    mu = xd.mean(dim=(0, 2, 3), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(0, 2, 3), keepdim=True)
+    istd = 1.0 / torch.sqrt(var + 1e-5)
+    gd = gy.double()
+    dotp = ((xd - mu) * gd).sum(dim=(0, 2, 3), keepdim=True)
+    resid = (gx.double() * (xd - mu)).sum(dim=(0, 2, 3), keepdim=True) - istd * dotp * 1e-5 / (var + 1e-5)
+    assert float(resid.abs().max()) / n < 1e-5 * scale
+    # and the whole tensor against the THNN formula evaluated in double
+    want = (gd - gd.mean(dim=(0, 2, 3), keepdim=True) - (xd - mu) * istd * istd * dotp / n) * istd
+    assert float((gx.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     assert float((gb.double() - gy.double().sum(dim=(0, 2, 3))).abs().max()) < 1e-3 * (n ** 0.5)
 
 
@@ -175,22 +187,37 @@ def test_full_width_video_iterations_are_deterministic_and_finite(cfg, hipb):
                 # train_wholeim_input.lua: the two bottleneck tensors alone are 2 x 1536*16*6400 = 314.6 M parameters
                 assert tr.netG.n_parameters() > 330e6 and tr.netD.n_parameters() > 10e6
             tr.set_batch(*batch)
-            for _ in range(3):
+            first = None
+            for it in range(3):
                 tr.step()
+                if it == 0:
+                    first = tr.losses()
             l = tr.losses()
             assert all(np.isfinite(v) for v in l.values() if v is not None), l
             assert 0 < l["errG_l2"] < 1.0 and 0 < l["errD"] < 20 and 0 < l["errG"] < 40
             if opt.get("wtgdl"):
                 assert 0 < l["errG_gdl"] < 4.0
-            runs.append((l, tr.parametersG.clone(), tr.parametersD.clone()))
+            runs.append((l, tr.parametersG.clone(), tr.parametersD.clone(), first))
             del tr
             torch.cuda.empty_cache()
     finally:
         hipb.set_mfma_mode("f32_3xbf16")
     if cfg == "wholeim-bf16":
+        import json
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "wholeim_bf16_vs_f32.json"), "w") as fh:
+            json.dump(dict(f32_first=runs[0][3], bf16_first=runs[1][3], f32_third=runs[0][0], bf16_third=runs[1][0]), fh)
+        # stated tolerance of the bf16-operand mode at this depth (13 conv layers between input and scalar): the FIRST
+        # iteration's losses — same weights on both sides — within 2e-2; after three parameter updates the reconstruction
+        # terms within 2e-2 still, the adversarial terms (a GAN's D/G balance amplifies any perturbation) within 2e-1
+        for k, v in runs[0][3].items():
+            if v is not None:
+                assert abs(v - runs[1][3][k]) <= 2e-2 * max(1.0, abs(v)), ("first iteration", k, v, runs[1][3][k])
         for k, v in runs[0][0].items():
             if v is not None:
-                assert abs(v - runs[1][0][k]) <= 2e-2 * max(1.0, abs(v)), (k, v, runs[1][0][k])
+                tol = 2e-2 if k in ("errG_l2", "errG_gdl") else 2e-1
+                assert abs(v - runs[1][0][k]) <= tol * max(1.0, abs(v)), ("third iteration", k, v, runs[1][0][k])
         return
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
     for k, v in runs[0][0].items():

@@ -666,7 +666,15 @@ class Sequential(Module):
                 else:
                     if a is not None:
                         if not act_done:
-                            B.act_bwd(mout, g, g, a.act, a.slope)   # in place on the incoming gradient
+                            if a.inplace:
+                                B.act_bwd(mout, g, g, a.act, a.slope)   # in place on the incoming gradient, as Torch7's
+                            else:                                       # in-place modules do; Tanh / Sigmoid own theirs
+                                bufs = a.__dict__.setdefault("_gfused", {})      # one per shape (full batch / one group)
+                                gb_ = bufs.get(tuple(g.shape))
+                                if gb_ is None:
+                                    gb_ = bufs[tuple(g.shape)] = torch.empty_like(g)
+                                B.act_bwd(mout, g, gb_, a.act, a.slope)
+                                g = gb_
                         a.gradInput = g
                     # the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this
                     # module's data-gradient epilogue (x IS that activated output)
