@@ -136,6 +136,29 @@ int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, const floa
                      float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
                      double* sums, int64_t npix_per_group, int C, int groups, int act, float slope, float pbeta);
 
+/* BatchNorm statistics as a by-product of the convolution that produces the tensor (train.lua:91-92: every BatchNorm of the
+ * nets follows a convolution).  vf_bn_fuse_next_fwd / _bwd attach a request to the context; the NEXT vf_conv2d_fwd /
+ * vf_deconv2d_fwd (fwd) or vf_conv2d_bwd_data / vf_deconv2d_bwd_data (bwd) on it leaves per-tile partial sums in `part`
+ * ([groups][rows][2][C] doubles, rows <= part_rows_cap / groups) from its epilogue (or from its split-K combine), and
+ * vf_bn_fuse_result says how many rows per group it wrote — 0 when that launch could not (thin or generic shapes, tiles
+ * that straddle a batch group): the caller then runs the plain vf_bn_train_fwd / vf_bn_bwd.
+ *   fwd: sums of (v - shift), (v - shift)^2 of the conv output v, shift = running_mean[C]  -> vf_bn_train_fwd_pre
+ *   bwd: the data-gradient pass stores its output ALREADY MASKED by the derivative of the activation fused behind the
+ *        BatchNorm (act, y_act = the activated BatchNorm output; nn.LeakyReLU / nn.ReLU:updateGradInput) and sums
+ *        g and g * (x - save_mean), x = the BatchNorm's input                                   -> vf_bn_bwd_pre
+ * The _pre calls are vf_bn_train_fwd_groups / vf_bn_bwd_groups without their statistics pass (g_masked: no activation). */
+int vf_bn_fuse_next_fwd(vf_ctx* ctx, const float* shift, double* part, int part_rows_cap, int groups);
+int vf_bn_fuse_next_bwd(vf_ctx* ctx, const float* x, const float* y_act, int act, float slope, const float* save_mean,
+                        double* part, int part_rows_cap, int groups);
+int vf_bn_fuse_result(vf_ctx* ctx, int* rows_per_group);
+int vf_bn_train_fwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, float* y, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                        double* sums, int64_t npix_per_group, int C, int groups, float momentum, float eps, int act,
+                        float slope);
+int vf_bn_bwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, const float* g_masked, float* gx,
+                  float* ggamma, float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
+                  double* sums, int64_t npix_per_group, int C, int groups, float pbeta);
+
 /* ---- pointwise modules (nn.LeakyReLU / ReLU / Tanh / Sigmoid; train.lua:90,146,196) --------- */
 int vf_act_fwd(vf_ctx* ctx, const float* x, float* y, int64_t n, int act, float slope); /* y may alias x */
 /* gx = gy * act'(.) evaluated from the ACTIVATED output y (in-place semantics); gx may alias gy */

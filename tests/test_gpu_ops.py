@@ -450,3 +450,70 @@ def test_weight_gradient_group_equals_individual_launches(oracle, hipb):
     c = run(True)
     for u, v in zip(a, c):
         np.testing.assert_array_equal(u, v)
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm statistics from the neighbouring GEMMs
+def _fused_bn_net(kind, widths, hipb, seed):
+    from video_filler_amd import nn
+    from video_filler_amd.trainers import weights_init
+    net = nn.Sequential()
+    mk = (lambda a, b: nn.SpatialFullConvolution(a, b, 4, 4, 2, 2, 1, 1)) if kind == "full" else (
+        lambda a, b: nn.SpatialConvolution(a, b, 4, 4, 2, 2, 1, 1))
+    for i in range(len(widths) - 1):
+        net.add(mk(widths[i], widths[i + 1])).add(nn.SpatialBatchNormalization(widths[i + 1]))
+        net.add(nn.ReLU(True) if kind == "full" else nn.LeakyReLU(0.2, True))
+    weights_init(net, torch.Generator().manual_seed(seed))
+    for m in net.leaves():          # non-trivial conv biases and BatchNorm shifts
+        if m.parameters() and m.bias is not None:
+            m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=torch.Generator().manual_seed(seed + 1)).to(hipb.device))
+    net.getParameters()
+    return net
+
+
+@pytest.mark.parametrize("kind,widths,Bn,H,groups", [
+    ("conv", (64, 64, 128, 256), 16, 64, 1),       # epilogue statistics (one launch per layer)
+    ("conv", (64, 128, 256, 512), 16, 32, 2),      # two batch groups (netD's real + fake passes as one batch); deeper layers split K
+    ("full", (512, 256, 128, 64), 16, 4, 1),       # transposed passes: four output-parity classes per row tile; split-K combine
+    ("conv", (32, 48, 96), 6, 32, 1),              # channel counts that are not powers of two (C % 16 == 0 still)
+    ("conv", (16, 20, 40), 3, 16, 1),              # C % 16 != 0: the scalar-gather tiles carry the same epilogue
+])
+def test_batchnorm_statistics_from_the_neighbouring_gemms(kind, widths, Bn, H, groups, hipb):
+    """nn.Sequential lets the convolution in front of a BatchNorm sum that BatchNorm's forward statistics in its own
+    epilogue (or split-K combine), and the data-gradient pass behind it sum its backward statistics and store the
+    gradient already masked by the activation's derivative (vf_bn_fuse_next_fwd / _bwd, vf_bn_*_pre).  Same arithmetic
+    per element, another summation order: everything agrees with the separate statistics passes to fp32 rounding, and
+    the separate passes are really gone from the launch list."""
+    from video_filler_amd import nn
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((Bn, widths[0], H, H), generator=g).to(hipb.device).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for fused in (False, True):
+        nn._NO_BN_FUSE = not fused
+        try:
+            net = _fused_bn_net(kind, widths, hipb, 3)
+            net.setBatchGroups(groups)
+            net.zeroGradParameters()
+            hipb.prof_begin()
+            y = net.forward(x).clone()
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(hipb.device).contiguous(memory_format=torch.channels_last)
+            gx = net.backward(x, gy).clone()
+            names = hipb.prof_end()
+        finally:
+            nn._NO_BN_FUSE = False
+        bns = [m for m in net.leaves() if isinstance(m, nn.SpatialBatchNormalization)]
+        res[fused] = dict(y=y, gx=gx, g=net.reference_flat(grads=True).clone(), rm=torch.cat([m.running_mean for m in bns]),
+                          rv=torch.cat([m.running_var for m in bns]), names=names)
+    a, b = res[False], res[True]
+    nb = len(widths) - 1
+    assert "bn_stats" in a["names"] and "bn_bwd_stats" in a["names"]
+    fin = b["names"].get("bn_finalize", {}).get("launches", 0)
+    bfin = b["names"].get("bn_bwd_finalize", {}).get("launches", 0)
+    if widths[1] % 4 == 0 and min(widths) >= 32:
+        assert fin == nb and "bn_stats" not in b["names"], b["names"].keys()
+        # backward: every BatchNorm but the top one has a data-gradient pass above it
+        assert bfin == nb - 1 and b["names"].get("bn_bwd_stats", {}).get("launches", 0) == 1
+    else:
+        assert fin >= 1 and bfin >= 1        # thin layers may fall back; the result must agree either way
+    for k, tol in (("y", 2e-5), ("gx", 1e-4), ("g", 1e-4), ("rm", 2e-5), ("rv", 2e-5)):
+        e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-30))
+        assert e <= tol, (k, e)

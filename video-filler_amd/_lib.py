@@ -47,6 +47,11 @@ SIGNATURES = {
     "vf_bn_bwd": (i32, [vp] * 11 + [i64, i32, i32, f32, f32]),
     "vf_bn_train_fwd_groups": (i32, [vp] * 10 + [i64, i32, i32, f32, f32, i32, f32]),
     "vf_bn_bwd_groups": (i32, [vp] * 11 + [i64, i32, i32, i32, f32, f32]),
+    "vf_bn_fuse_next_fwd": (i32, [vp, vp, vp, i32, i32]),
+    "vf_bn_fuse_next_bwd": (i32, [vp, vp, vp, i32, f32, vp, vp, i32, i32]),
+    "vf_bn_fuse_result": (i32, [vp, C.POINTER(i32)]),
+    "vf_bn_train_fwd_pre": (i32, [vp, vp, i32] + [vp] * 9 + [i64, i32, i32, f32, f32, i32, f32]),
+    "vf_bn_bwd_pre": (i32, [vp, vp, i32] + [vp] * 9 + [i64, i32, i32, f32]),
     "vf_act_fwd": (i32, [vp, vp, vp, i64, i32, f32]),
     "vf_act_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32]),
     "vf_axpby": (i32, [vp, f32, vp, f32, vp, i64]),

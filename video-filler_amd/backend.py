@@ -247,6 +247,33 @@ class HipBackend:
         self._c("vf_bn_bwd_groups", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
                 _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, ACT[act], slope, pbeta)
 
+    # ---- BatchNorm statistics as a by-product of the producing convolution (vf_bn_fuse_next_* / vf_bn_*_pre)
+    def bn_fuse_next_fwd(self, shift, part, groups=1):
+        """the next conv / full-conv forward on this backend also sums (v - shift), (v - shift)^2 per channel into `part`
+        (float64, rows x 2C); bn_fuse_result() afterwards: rows per group, 0 = that launch could not"""
+        self._c("vf_bn_fuse_next_fwd", _ptr(shift), _ptr(part), part.numel() // (2 * shift.numel()), groups)
+
+    def bn_fuse_next_bwd(self, x, y_act, act, slope, save_mean, part, groups=1):
+        Cc = x.shape[1]
+        self._c("vf_bn_fuse_next_bwd", _ptr(x), _ptr(y_act), ACT[act], slope, _ptr(save_mean), _ptr(part),
+                part.numel() // (2 * Cc), groups)
+
+    def bn_fuse_result(self):
+        rows = C.c_int(0)
+        self._c("vf_bn_fuse_result", C.byref(rows))
+        return rows.value
+
+    def bn_train_fwd_pre(self, part, rows, x, y, gamma, beta, rm, rv, save_mean, save_invstd, sums, groups, momentum, eps,
+                         act="none", slope=0.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_train_fwd_pre", _ptr(part), rows, _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
+                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, momentum, eps, ACT[act], slope)
+
+    def bn_bwd_pre(self, part, rows, x, g_masked, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, groups, pbeta=1.0):
+        B, Cc, H, W = x.shape
+        self._c("vf_bn_bwd_pre", _ptr(part), rows, _ptr(x), _ptr(g_masked), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
+                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, pbeta)
+
     def bn_eval_fwd(self, x, y, gamma, beta, rm, rv, eps, act="none", slope=0.0):
         B, Cc, H, W = x.shape
         self._c("vf_bn_eval_fwd", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), B * H * W, Cc, eps,

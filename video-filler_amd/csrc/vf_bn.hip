@@ -638,6 +638,40 @@ VF_API int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, con
                              npix_per_group, C, groups, act, slope, pbeta);
 }
 
+// ---- statistics already summed per tile by the GEMM that produced the tensor (vf_bn_fuse_next_fwd / _bwd, VfBnSt):
+// `part` = [groups][rows_per_group][2][C] doubles.  Forward: finalize (+ running statistics) and normalise, two launches;
+// backward: column totals and the gradient pass, two launches — the tensor is never read just to be summed.
+VF_API int vf_bn_train_fwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, float* y, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                               double* sums, int64_t npix_per_group, int C, int groups, float momentum, float eps, int act,
+                               float slope) {
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  VF_REQUIRE(part && rows_per_group > 0 && groups >= 1 && groups <= 64, "vf_bn_train_fwd_pre: bad partials");
+  {
+    VfProf prof(ctx, "bn_finalize", 0.0, 8.0 * (double)rows_per_group * 2 * C * groups);
+    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 2)), dim3(256), 0, ctx->stream, part, rows_per_group, 2 * C, sums,
+                       running_mean, running_var, save_mean, save_invstd, (double)npix_per_group, momentum, eps, (float*)nullptr, 0.f,
+                       groups);
+    VF_LAUNCH_CHECK();
+  }
+  return bn_apply_groups(ctx, x, y, gamma, beta, save_mean, save_invstd, npix_per_group, C, groups, act, slope);
+}
+VF_API int vf_bn_bwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, const float* g_masked, float* gx,
+                         float* ggamma, float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
+                         double* sums, int64_t npix_per_group, int C, int groups, float pbeta) {
+  VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  VF_REQUIRE(part && rows_per_group > 0 && groups >= 1 && groups <= 64, "vf_bn_bwd_pre: bad partials");
+  {
+    VfProf prof(ctx, "bn_bwd_finalize", 0.0, 8.0 * (double)rows_per_group * 2 * C * groups);
+    hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4), groups), dim3(256), 0, ctx->stream, part, rows_per_group,
+                       2 * C, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.0, 0.f, 0.f, (float*)nullptr,
+                       0.f, 1);
+    VF_LAUNCH_CHECK();
+  }
+  return bn_bwd_apply_groups(ctx, x, nullptr, g_masked, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix_per_group,
+                             npix_per_group, C, groups, VF_ACT_NONE, 0.f, pbeta);
+}
+
 // ---- all bias gradients of a backward walk (see VfColsumDesc)
 VF_API int vf_bias_grad_plan(int64_t P, int C, int* cq, int* rows_per_block, int* gx, int* gy) {
   VF_REQUIRE(P > 0 && C > 0 && C % 4 == 0, "vf_bias_grad_plan: C must be a positive multiple of 4 (got %d)", C);

@@ -12,6 +12,20 @@
 
 #define VF_API extern "C" __attribute__((visibility("default")))
 
+// BatchNorm statistics as a by-product of the GEMM that produces the tensor (vf_bn_fuse_next_fwd / _bwd): the epilogue (or
+// the split-K slab reduce) of the NEXT conv-like launch leaves per-tile partial sums that vf_bn_train_fwd_pre /
+// vf_bn_bwd_pre finalize, so the tensor is not read again just to be summed.
+struct VfBnSt {
+  int mode;               // 0 none; 1 forward: s1 = sum(v - shift), s2 = sum((v - shift)^2); 2 backward: s1 = sum(g), s2 = sum(g*(x - mean)),
+                          //   g = the launch's output masked by the activation derivative (the output IS stored masked)
+  const float* vec;       // mode 1: [C] shift (running_mean); mode 2: [groups][C] save_mean
+  const float* x;         // mode 2: the BatchNorm input at the output's index
+  double* part;           // [groups][rows_per_group][2][C]
+  int rows_per_group;     // partial rows each group ends up with (what the finalize kernels walk)
+  int tiles_per_group;    // GEMM epilogue: row tiles per batch group; slab reduce: blocks per group
+  int zpar;               // GEMM epilogue: output-parity classes sharing a row tile (1 or 4)
+};
+
 struct vf_ctx {
   int device;
   hipStream_t stream;
@@ -21,6 +35,13 @@ struct vf_ctx {
   int mfma_bf16;    // 0: native f32 MFMA; 1: operands rounded to bf16; 3 (default): exact three-plane bf16 split
   int wg_active;    // a weight-gradient group is being recorded (vf_wgrad_group_begin .. _end)
   void* wg_rec;     // the recorder (vf_conv.hip)
+  // one-shot attachment for the next conv-like launch (vf_bn_fuse_next_*), and what that launch made of it
+  VfBnSt bnf;
+  const float* bnf_yact;  // mode 2: activated BatchNorm output (the derivative mask), its activation
+  int bnf_act;
+  float bnf_slope;
+  int bnf_groups, bnf_rows_cap;
+  int bnf_result_rows;    // rows_per_group of the fused launch; 0: not fused
 };
 void vf_internal_wg_free(vf_ctx* ctx);
 

@@ -121,7 +121,40 @@ struct IGemm {
   const float* dmask;              // optional: out = act'(dmask[same index]) * out — the backward of the in-place activation
   int dact;                        // that produced this pass's output tensor's forward twin (nn.LeakyReLU:updateGradInput)
   float dslope;
+  VfBnSt st;                       // BatchNorm statistics of the output as a by-product of the epilogue (mode 0: none)
 };
+
+// Per-channel partial sums of one block's output tile -> one partial row (see VfBnSt).  Lane l of a wave holds column
+// l % 32 of its 32-wide fragments and 16 rows per fragment: the per-lane sums over those rows are combined across the two
+// lane halves with a shuffle, across the waves stacked in M through LDS in a fixed order (deterministic), and the block
+// writes doubles.  `red` = 2 * WAVES_M * BN floats of LDS that nothing else uses any more.
+template <int NT, int WAVES_M, int BN>
+__device__ __forceinline__ void vf_bn_tile_partials(const VfBnSt& st, float (&s1)[NT], float (&s2)[NT], float* red, int wave_m,
+                                                    int wn, int lane, int tid, int n0, int N, int bx, int pz) {
+  const int lr = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    s1[nt] += __shfl_xor(s1[nt], 32, 64);
+    s2[nt] += __shfl_xor(s2[nt], 32, 64);
+    if (lane < 32) {
+      red[(wave_m * 2 + 0) * BN + wn + nt * 32 + lr] = s1[nt];
+      red[(wave_m * 2 + 1) * BN + wn + nt * 32 + lr] = s2[nt];
+    }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < N) {
+    double a = 0, b = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES_M; ++w) {
+      a += (double)red[(w * 2 + 0) * BN + tid];
+      b += (double)red[(w * 2 + 1) * BN + tid];
+    }
+    const int g = bx / st.tiles_per_group, local = bx - g * st.tiles_per_group;
+    double* o = st.part + ((int64_t)(g * st.rows_per_group + local * st.zpar + pz) * 2) * N;
+    o[n0 + tid] = a;
+    o[N + n0 + tid] = b;
+  }
+}
 
 // V = 2: 16-byte loads for A and B (C % 16 == 0);  V = 1: 16-byte A, scalar B (k-major B with N % 4 != 0);
 // V = 0: scalar loads with a flattened (tap, c) K index (first/last layers: C = 3, 12, 27 ...).
@@ -684,11 +717,16 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
   const bool fin = p.ksplit == 1;
-  float bv[NT];
+  const int stm = fin ? p.st.mode : 0;      // with split-K the statistics come out of the slab reduce instead
+  float bv[NT], sv[NT], st1[NT], st2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + wn + nt * 32 + lr;
     bv[nt] = (fin && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    // statistics: the shift (forward) or the saved mean of this row tile's batch group (backward)
+    sv[nt] = (stm && n < p.N) ? p.st.vec[(stm == 2 ? (bx / p.st.tiles_per_group) * p.N : 0) + n] : 0.f;
+    st1[nt] = 0.f;
+    st2[nt] = 0.f;
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -707,12 +745,23 @@ __global__ __launch_bounds__(256) void k_igemm(const IGemm p) {
           if (fin) {
             v = vf_act_apply(v + bv[nt], p.act, p.slope);
             if (p.dmask) v = vf_act_grad(p.dmask[pix * p.N + n], v, p.dact, p.dslope);
+            if (stm == 1) {
+              const float d = v - sv[nt];
+              st1[nt] += d;
+              st2[nt] += d * d;
+            } else if (stm == 2) {
+              st1[nt] += v;
+              st2[nt] += v * (p.st.x[pix * p.N + n] - sv[nt]);
+            }
           }
           out[pix * p.N + n] = v;
         }
       }
     }
   }
+  if (stm)      // (uniform over the block; the K loop ended on a barrier, so the tile memory is free)
+    vf_bn_tile_partials<NT, BM / WM, BN>(p.st, st1, st2, smem, wave / WAVES_N, wn, lane, tid, n0, p.N, bx,
+                                         p.parity ? ((ph << 1) | pw) : 0);
   if (p.stamps && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);     // stores retired (vmcnt 0)
     p.stamps[8 * blockIdx.x + 3] = wall_clock64();
@@ -772,6 +821,96 @@ __global__ __launch_bounds__(256) void k_slab_reduce4(const float* __restrict__ 
     }
     ((f32x4*)dst)[i4] = t;
   }
+}
+// Split-K combine that also leaves BatchNorm statistics partials (VfBnSt): the output [M][N] is walked as units of 256
+// consecutive floats (64 float4 lanes); a block owns one 256-wide column chunk (blockIdx.y; N <= 256: the unit holds 256 / N
+// whole rows) and a run of `units_per_block` row units, 4 row lanes deep, every thread summing its element's slabs in
+// slab order.  A thread always sees the same four channels, so its statistics stay in registers until the end; the lanes
+// that alias a channel (4 row lanes; 256 / N column lanes when N < 256) meet in LDS in a fixed order.  Requires
+// total % 256 == 0 and (256 % N == 0 or N % 256 == 0) — every layer the nets pair with a BatchNorm.
+__global__ __launch_bounds__(256) void k_slab_reduce_st(const float* __restrict__ slab, float* __restrict__ dst,
+                                                        const float* __restrict__ bias, int64_t total4, int N, int ksplit, int act,
+                                                        float slope, const float* __restrict__ dmask, int dact, float dslope,
+                                                        int units_per_block, int64_t row_units, int ncc, const VfBnSt st) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int cc = blockIdx.y;
+  const int ch0 = (N <= 256 ? (tx * 4) % N : cc * 256 + tx * 4);      // first of this thread's four channels
+  const int g = blockIdx.x / st.tiles_per_group;                        // batch group of this block's rows
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *(const f32x4*)(bias + ch0);
+  if (st.mode) sv = *(const f32x4*)(st.vec + (st.mode == 2 ? g * N : 0) + ch0);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t u0 = (int64_t)blockIdx.x * units_per_block, u1 = min(row_units, u0 + units_per_block);
+  for (int64_t ru = u0 + ty; ru < u1; ru += 4) {
+    const int64_t i4 = (ru * ncc + cc) * 64 + tx;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < ksplit; ++k) t += ((const f32x4*)slab)[(int64_t)k * total4 + i4];
+    t += bv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = vf_act_apply(t[e], act, slope);
+    if (dmask) {
+      const f32x4 m = ((const f32x4*)dmask)[i4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = vf_act_grad(m[e], t[e], dact, dslope);
+    }
+    if (st.mode == 1) {
+      const f32x4 d = t - sv;
+      s1 += d;
+      s2 += d * d;
+    } else if (st.mode == 2) {
+      const f32x4 xv = ((const f32x4*)st.x)[i4];
+      s1 += t;
+      s2 += t * (xv - sv);
+    }
+    ((f32x4*)dst)[i4] = t;
+  }
+  if (!st.mode) return;
+  __shared__ f32x4 red[2][256];
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  const int lanes = N <= 256 ? N / 4 : 64;        // distinct float4 channel columns in this block
+  if ((int)threadIdx.x < lanes) {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    for (int t = threadIdx.x; t < 256; t += lanes) {     // (t % 64) % lanes == threadIdx.x: same channels (lanes divides 64)
+      const f32x4 u = red[0][t], w = red[1][t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] += (double)u[e];
+        b[e] += (double)w[e];
+      }
+    }
+    const int local = blockIdx.x - g * st.tiles_per_group;
+    double* o = st.part + ((int64_t)(g * st.rows_per_group + local) * 2) * N;
+    const int c0 = (N <= 256 ? 0 : cc * 256) + threadIdx.x * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[c0 + e] = a[e];
+      o[N + c0 + e] = b[e];
+    }
+  }
+}
+// plan of that launch: (units_per_block, blocks per group); false: the shape does not fit (caller keeps the plain reduce)
+static bool slab_st_plan(int64_t total, int N, int groups, int rows_cap, int* units_per_block, int* blocks_per_group, int* ncc_out,
+                         int64_t* row_units_out) {
+  if (total % 256 != 0 || N % 4 != 0 || !((N <= 256 && 256 % N == 0) || (N > 256 && N % 256 == 0))) return false;
+  const int ncc = N <= 256 ? 1 : N / 256;
+  const int64_t row_units = total / 256 / ncc;
+  if (row_units % groups != 0) return false;
+  const int64_t per_group = row_units / groups;
+  // ~512 blocks over the whole launch, at least 4 row units (one per row lane) each, a divisor of the group's units
+  int64_t upb = std::max<int64_t>(4, vf_cdiv(row_units * ncc, 512));
+  while (upb < per_group && per_group % upb != 0) ++upb;
+  if (upb > per_group) upb = per_group;
+  if (per_group % upb != 0) return false;
+  const int64_t bpg = per_group / upb;
+  if (bpg > rows_cap) return false;
+  *units_per_block = (int)upb;
+  *blocks_per_group = (int)bpg;
+  *ncc_out = ncc;
+  *row_units_out = row_units;
+  return true;
 }
 static int launch_slab_reduce(vf_ctx* ctx, const float* slab, float* dst, const float* bias, int64_t total, int N, int ksplit,
                               int act, float slope, float beta, const float* dmask = nullptr, int dact = 0,
@@ -1250,8 +1389,9 @@ static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, 
     launch_igemm_tile_m<BM, BN, WM, WN, 0>(ctx, g, grid, bkm, v, name, flops);
 }
 
-// vecA / vecB: 16-byte loads legal for the A / B operand
-static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
+// vecA / vecB: 16-byte loads legal for the A / B operand.  top: this launch writes the pass's output tensor itself (an inner
+// GEMM into a column buffer does not), so a pending BatchNorm-statistics attachment (vf_bn_fuse_next_*) applies to it.
+static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB, bool top = true) {
   const int zpar = g.parity ? 4 : 1;
   const bool bkm = g.wsN == 1 && g.wsC != 1;
   const int64_t a_elems = (int64_t)(g.M >> (g.lgMh + g.lgMw)) * g.Hi * g.Wi * g.C;
@@ -1307,6 +1447,41 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
   }
   g.ksplit = ksplit;
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
+  // ---- BatchNorm statistics as a by-product (one-shot attachment): from the epilogue, or from the slab reduce under split-K
+  g.st.mode = 0;
+  bool slab_st = false;
+  int st_upb = 0, st_bpg = 0, st_ncc = 0;
+  int64_t st_units = 0;
+  if (top && ctx->bnf.mode) {
+    const int groups = ctx->bnf_groups;
+    VfBnSt st = ctx->bnf;
+    bool fused = false;
+    if (ksplit == 1) {
+      if (g.M % groups == 0 && (g.M / groups) % t.bm == 0 && (int64_t)(gm / groups) * zpar <= ctx->bnf_rows_cap) {
+        st.tiles_per_group = gm / groups;
+        st.zpar = zpar;
+        st.rows_per_group = (gm / groups) * zpar;
+        g.st = st;
+        fused = true;
+      }
+    } else if (g.out_elems % 4 == 0 && slab_st_plan(g.out_elems, g.N, groups, ctx->bnf_rows_cap, &st_upb, &st_bpg, &st_ncc, &st_units)) {
+      st.tiles_per_group = st_bpg;
+      st.zpar = 1;
+      st.rows_per_group = st_bpg;
+      g.st = st;            // (the GEMM kernel ignores it under split-K; launch_slab_reduce_st gets it)
+      slab_st = true;
+      fused = true;
+    }
+    if (fused) {
+      ctx->bnf_result_rows = st.rows_per_group;
+      if (st.mode == 2) {   // the output is stored masked by the activation derivative: what BatchNorm's backward sums
+        g.dmask = ctx->bnf_yact;
+        g.dact = ctx->bnf_act;
+        g.dslope = ctx->bnf_slope;
+      }
+    }
+    ctx->bnf.mode = 0;
+  }
   static const int tune_dbg = getenv("VF_IGEMM_DBG") ? atoi(getenv("VF_IGEMM_DBG")) : 0;
   g.dbg = tune_dbg;
   static const int tune_klin = getenv("VF_NO_KLIN") ? 0 : 1;
@@ -1369,9 +1544,53 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB) {
     }
   }
   if (ksplit > 1) {
-    VfProf prof(ctx, "slab_reduce_igemm", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+    VfProf prof(ctx, slab_st ? "slab_reduce_igemm_bnstats" : "slab_reduce_igemm", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+    if (slab_st) {
+      hipLaunchKernelGGL(k_slab_reduce_st, dim3((unsigned)(st_bpg * ctx->bnf_groups), (unsigned)st_ncc), dim3(256), 0, ctx->stream,
+                         (const float*)g.slab, g.Y, g.bias, g.out_elems / 4, g.N, ksplit, g.act, g.slope, g.dmask, g.dact, g.dslope,
+                         st_upb, st_units, st_ncc, g.st);
+      VF_LAUNCH_CHECK();
+      return 0;
+    }
     return launch_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, 0.f, g.dmask, g.dact, g.dslope);
   }
+  return 0;
+}
+
+// ---- BatchNorm statistics attachment (see VfBnSt; consumed by the next conv-like launch of this context)
+VF_API int vf_bn_fuse_next_fwd(vf_ctx* ctx, const float* shift, double* part, int part_rows_cap, int groups) {
+  VF_REQUIRE(shift && part && part_rows_cap > 0 && groups >= 1 && groups <= 64, "vf_bn_fuse_next_fwd: bad arguments");
+  memset(&ctx->bnf, 0, sizeof(ctx->bnf));
+  ctx->bnf.mode = 1;
+  ctx->bnf.vec = shift;
+  ctx->bnf.part = part;
+  ctx->bnf_groups = groups;
+  ctx->bnf_rows_cap = part_rows_cap / groups;
+  ctx->bnf_result_rows = 0;
+  return 0;
+}
+VF_API int vf_bn_fuse_next_bwd(vf_ctx* ctx, const float* x, const float* y_act, int act, float slope, const float* save_mean,
+                               double* part, int part_rows_cap, int groups) {
+  VF_REQUIRE(x && save_mean && part && part_rows_cap > 0 && groups >= 1 && groups <= 64, "vf_bn_fuse_next_bwd: bad arguments");
+  VF_REQUIRE(act == VF_ACT_NONE || y_act != nullptr, "vf_bn_fuse_next_bwd: the activation derivative needs the activated output");
+  memset(&ctx->bnf, 0, sizeof(ctx->bnf));
+  ctx->bnf.mode = 2;
+  ctx->bnf.vec = save_mean;
+  ctx->bnf.x = x;
+  ctx->bnf.part = part;
+  ctx->bnf_yact = act == VF_ACT_NONE ? nullptr : y_act;
+  ctx->bnf_act = act;
+  ctx->bnf_slope = slope;
+  ctx->bnf_groups = groups;
+  ctx->bnf_rows_cap = part_rows_cap / groups;
+  ctx->bnf_result_rows = 0;
+  return 0;
+}
+VF_API int vf_bn_fuse_result(vf_ctx* ctx, int* rows_per_group) {
+  VF_REQUIRE(rows_per_group != nullptr, "vf_bn_fuse_result: NULL");
+  *rows_per_group = ctx->bnf_result_rows;
+  ctx->bnf_result_rows = 0;
+  ctx->bnf.mode = 0;      // an attachment no launch took (thin or generic shapes) does not linger
   return 0;
 }
 
@@ -1447,7 +1666,7 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
       q.outH = 1; q.outW = 1; q.osy = 1; q.osx = 1;
       q.out_elems = Mi * 16 * N;
       q.act = VF_ACT_NONE;
-      const int rc = launch_igemm(ctx, q, true, true);
+      const int rc = launch_igemm(ctx, q, true, true, false);
       ctx->ws_front = 0;
       if (rc) return rc;
       const int64_t total = Mi * 4 * N;
@@ -1489,7 +1708,8 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
     g.bias = nullptr;
     g.act = VF_ACT_NONE;
   }
-  if (int rc = launch_igemm(ctx, g, vecA, vecB)) return rc;
+  // (the 1x1 -> 4x4 form's GEMM columns are (kh, kw, n): not one channel per column, so no statistics by-product there)
+  if (int rc = launch_igemm(ctx, g, vecA, vecB, stride == 2)) return rc;
   if (stride == 1 && real_bias) {
     const int64_t total = (int64_t)B * 16 * N;
     const int nb = (int)std::min<int64_t>(vf_cdiv(total, 256), 4096);

@@ -35,6 +35,13 @@ VF_API int vf_ctx_create(vf_ctx** out, int device, void* stream) {
   c->ws_front = 0;
   c->wg_active = 0;
   c->wg_rec = nullptr;
+  memset(&c->bnf, 0, sizeof(c->bnf));
+  c->bnf_yact = nullptr;
+  c->bnf_act = 0;
+  c->bnf_slope = 0.f;
+  c->bnf_groups = 1;
+  c->bnf_rows_cap = 0;
+  c->bnf_result_rows = 0;
   c->mfma_bf16 = 3;      // fp32 operands as three exact bf16 planes (see vf_ctx_set_mfma_mode)
   *out = c;
   return 0;

@@ -212,12 +212,39 @@ class SpatialBatchNormalization(Module):
         self.groups = 1
         self._gsave = None
 
-    def updateOutput(self, input, act="none", slope=0.0):
+    # -- statistics summed by the convolution that produces / consumes the tensor (backend.bn_fuse_next_*): the container
+    #    attaches the request to that convolution and tells this module how many partial rows it left (0: none, run the
+    #    plain statistics pass)
+    def fusable(self):
+        return self.train and self.sync_world == 1 and self.nOutputPlane % 4 == 0 and not _NO_BN_FUSE
+
+    def part_buffer(self, npix):
+        """[rows][2C] float64 partials: one row per 64-pixel output tile of the producing GEMM (or per block of its
+        split-K combine, at most ~512)"""
+        rows = max(npix // 64, 512) + 8 * self.groups
+        need = rows * 2 * self.nOutputPlane
+        if getattr(self, "_part", None) is None or self._part.numel() < need:
+            self._part = get_backend().zeros(need, dtype=torch.float64)
+        return self._part
+
+    def _stat_bufs(self):
+        if self.groups > 1:
+            self._group_state()
+            return self._gmean, self._gstd, self._gsums
+        return self.save_mean, self.save_std, self._sums
+
+    def updateOutput(self, input, act="none", slope=0.0, pre_rows=0):
         B = get_backend()
         input = to_nhwc(input)
         Bn, Cc, H, W = input.shape
         assert Cc == self.nOutputPlane
         y = self._buf("output", Bn, Cc, H, W)
+        if pre_rows > 0:
+            assert self.fusable() and Bn % self.groups == 0
+            sm, ss, su = self._stat_bufs()
+            B.bn_train_fwd_pre(self._part, pre_rows, input, y, self.weight, self.bias, self.running_mean, self.running_var, sm, ss,
+                               su, self.groups, self.momentum, self.eps, act, slope)
+            return y
         if self.train and self.groups > 1:
             assert self.sync_world == 1 and Bn % self.groups == 0
             h = Bn // self.groups
@@ -262,9 +289,12 @@ class SpatialBatchNormalization(Module):
                             self._gsums[g * 2 * n:(g + 1) * 2 * n]) for g in range(G)]
         return self._gsave
 
-    def _bwd(self, input, gradOutput, want_gx, want_gp, act="none", slope=0.0, y_act=None, group=None, buf="gradInput"):
+    def _bwd(self, input, gradOutput, want_gx, want_gp, act="none", slope=0.0, y_act=None, group=None, buf="gradInput",
+             pre_rows=0):
         """group = g: `input` / `gradOutput` / `y_act` hold group g's samples only (a pass over one of the concatenated
-        batches); group = None with groups > 1: all groups, one after the other."""
+        batches); group = None with groups > 1: all groups, one after the other.
+        pre_rows > 0: gradOutput arrives ALREADY MASKED by the activation's derivative and its sums sit in the partial
+        buffer (the data-gradient pass above left both: backend.bn_fuse_next_bwd)."""
         assert self.train, "the reference never back-propagates through BN in evaluate mode"
         B = get_backend()
         input, gradOutput = to_nhwc(input), to_nhwc(gradOutput)
@@ -274,6 +304,12 @@ class SpatialBatchNormalization(Module):
         if want_gp:
             pbeta = 0.0 if self._fresh else 1.0
             self._fresh = False
+        if pre_rows > 0:
+            assert group is None and self.fusable()
+            sm, ss, su = self._stat_bufs()
+            B.bn_bwd_pre(self._part, pre_rows, input, gradOutput, gx, self.gradWeight if want_gp else None,
+                         self.gradBias if want_gp else None, self.weight, sm, ss, su, self.groups, pbeta)
+            return gx
         if self.groups > 1:
             assert self.sync_world == 1
             state = self._group_state()
@@ -533,6 +569,7 @@ class ParallelTable(Module):
 _NO_DEFER_BIAS = bool(__import__("os").environ.get("VF_NO_DEFER_BIAS"))      # A/B switches (timing experiments)
 _NO_WG_GROUP = bool(__import__("os").environ.get("VF_NO_WG_GROUP"))
 _NO_BN_GROUPS = bool(__import__("os").environ.get("VF_NO_BN_GROUPS"))
+_NO_BN_FUSE = bool(__import__("os").environ.get("VF_NO_BN_FUSE"))       # BatchNorm statistics from the neighbouring GEMMs
 
 
 class Sequential(Module):
@@ -552,6 +589,7 @@ class Sequential(Module):
         self._flat = None
         self.side = None      # optional side backend (backend.fork()): weight gradients overlap the data-grad chain
         self._act_done_at = -1
+        self._bn_pre_at = None
 
     def add(self, m):
         self.modules.append(m)
@@ -604,9 +642,29 @@ class Sequential(Module):
         whose weights a side stream is still updating)."""
         plan = self._plan or self._build_plan()
         cur = input
+        B = get_backend()
+        fuse_bn = self.fuse and hasattr(B, "bn_fuse_next_fwd")
+        pre_rows = 0
         for idx, (m, a) in enumerate(plan):
             if before is not None and idx == before[0]:
                 before[1]()
+            nxt = plan[idx + 1][0] if idx + 1 < len(plan) else None
+            if (fuse_bn and a is None and isinstance(m, SpatialConvolution) and isinstance(nxt, SpatialBatchNormalization)
+                    and nxt.fusable() and nxt.nOutputPlane == m.nOutputPlane):
+                # the BatchNorm behind this convolution gets its statistics from the convolution's own epilogue
+                Ho, Wo = m.out_hw(cur.shape[2], cur.shape[3])
+                B.bn_fuse_next_fwd(nxt.running_mean, nxt.part_buffer(cur.shape[0] * Ho * Wo), nxt.groups)
+                cur = m.updateOutput(cur)
+                pre_rows = B.bn_fuse_result()
+                continue
+            if isinstance(m, SpatialBatchNormalization):
+                rows, pre_rows = pre_rows, 0
+                cur = m.updateOutput(cur, *((a.act, a.slope) if a is not None else ("none", 0.0)), pre_rows=rows)
+                if a is not None:
+                    a.output = cur
+                    if Sequential.act_hook is not None and a.act in ("lrelu", "relu"):
+                        Sequential.act_hook(a, cur)
+                continue
             if a is None:
                 cur = m.updateOutput(cur)
                 if Sequential.act_hook is not None and isinstance(m, _Act) and m.act in ("lrelu", "relu"):
@@ -637,6 +695,10 @@ class Sequential(Module):
             Sequential._group_open = True
         hi = len(plan) if hi is None else hi
         act_done = self._act_done_at == hi if hi < len(plan) else False
+        bn_pre, pre = 0, [0]      # partial rows the data-gradient pass above left for the BatchNorm about to be walked
+        if hi < len(plan) and self._bn_pre_at is not None and self._bn_pre_at[0] == hi:
+            bn_pre = self._bn_pre_at[1]      # a walk cut between a convolution and the BatchNorm below it resumes here
+        self._bn_pre_at = None
         try:
             for idx in range(hi - 1, lo - 1, -1):
                 m, a = plan[idx]
@@ -658,11 +720,12 @@ class Sequential(Module):
                     continue
                 if isinstance(m, SpatialBatchNormalization):
                     gsel = None if group is None else group[0]
+                    rows, bn_pre = bn_pre, 0
                     if a is None:
-                        g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf)
+                        g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf, pre_rows=rows)
                     else:
                         a.gradInput = g
-                        g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, mout, group=gsel, buf=gbuf)
+                        g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, mout, group=gsel, buf=gbuf, pre_rows=rows)
                 else:
                     if a is not None:
                         if not act_done:
@@ -683,7 +746,27 @@ class Sequential(Module):
                         pm, pa = plan[idx - 1]
                         if pa is not None and pa.act in ("lrelu", "relu") and not isinstance(pm, SpatialBatchNormalization):
                             in_act = (pa.act, pa.slope)
-                    if isinstance(m, SpatialConvolution):
+                    # the module below is a BatchNorm (+ activation): this module's data-gradient pass also sums what that
+                    # BatchNorm's backward needs, and stores its output masked by the activation's derivative
+                    fuse_below = None
+                    if (self.fuse and want_gx and idx > 1 and group is None and isinstance(m, SpatialConvolution)
+                            and hasattr(B, "bn_fuse_next_bwd")):
+                        pm, pa = plan[idx - 1]
+                        if (isinstance(pm, SpatialBatchNormalization) and pm.fusable() and (pa is None or pa.act in ("lrelu", "relu"))
+                                and pm.nOutputPlane == m.nInputPlane):
+                            fuse_below = (pm, pa)
+                    if fuse_below is not None:
+                        def upd(m=m, x=x, g=g, fb=fuse_below, idx=idx):
+                            pm, pa = fb
+                            xbn = plan[idx - 2][0].output            # the BatchNorm's input: the convolution below it
+                            sm, _, _ = pm._stat_bufs()
+                            B.bn_fuse_next_bwd(xbn, pm.output if pa is not None else None, pa.act if pa is not None else "none",
+                                               pa.slope if pa is not None else 0.0, sm, pm.part_buffer(xbn.shape[0] * xbn.shape[2] * xbn.shape[3]),
+                                               pm.groups)
+                            out = m.updateGradInput(x, g, None, gbuf)
+                            pre[0] = B.bn_fuse_result()
+                            return out
+                    elif isinstance(m, SpatialConvolution):
                         upd = lambda: m.updateGradInput(x, g, in_act, gbuf)
                     elif group is not None and isinstance(m, _Act):
                         upd = lambda: m.updateGradInput(x, g, mout)
@@ -701,6 +784,7 @@ class Sequential(Module):
                             self._acc(m, x, g, deferred)
                     g = gin
                     act_done = in_act is not None
+                    bn_pre, pre[0] = pre[0], 0
                     continue
                 act_done = False
         except BaseException:
@@ -718,6 +802,7 @@ class Sequential(Module):
         if used_side:
             self.side.join()
         self._act_done_at = lo if act_done else -1       # a partial walk resumes at `lo` (backward_range)
+        self._bn_pre_at = (lo, bn_pre) if (bn_pre and lo > 0) else None
         if lo == 0:
             self.gradInput = g
         return g
