@@ -94,6 +94,35 @@ int vf_deconv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, float* gx
 int vf_deconv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H,
                            int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 
+/* ---- the same passes from PRE-SPLIT operands (vf_pgemm.hip) ----------------------------------
+ * The default product mode forms every fp32 product from three bf16 planes per operand (x = hi + mid + lo, exact: see
+ * vf_ctx_set_mfma_mode).  The entry points above split their fp32 operands inside the GEMM, in every pass that reads
+ * them; these take operands split ONCE by whoever produced them — `planes` = bf16 [3][n], plane q at q * n elements:
+ *   vf_planes_split    any fp32 tensor of n elements (n % 4 == 0)
+ *   vf_weight_planes   a conv / full-conv weight, physical [d0][16][d1]: native planes [3][d0][16][d1] and (optional)
+ *                      transposed planes [3][d1][16][d0] — the data-gradient / full-conv forward passes walk the transpose
+ *   vf_bn_train_fwd_pre / vf_bn_bwd_pre write the planes of their output beside it (y_planes / gx_planes, may be NULL)
+ * and compute bit for bit the six-term products of mode 3 (another summation order over K: same parity tolerances).
+ * 4x4, stride 2, pad 1 only, channel counts of the gathered operand % 32 == 0, output channels >= 32 and % 4 == 0, more
+ * than 64 GEMM rows (vf_pconv_supported says; everything else stays with the entry points above).
+ *   vf_pconv_gather    conv forward (ap = x planes [B][H][W][Cin], wp = native planes of w [Cout][16][Cin]) and full-conv
+ *                      data-gradient (ap = gy planes, wp = native planes of the full-conv weight [Cin_full][16][Cout_full])
+ *   vf_pconv_scatter   conv data-gradient (ap = gy planes on the LOW-res grid H x W, wp = transposed planes [Cin][16][Cout];
+ *                      dmask/dact/dslope as vf_conv2d_bwd_data_act) and full-conv forward (ap = x planes, wp = transposed
+ *                      planes of the full-conv weight [Cout_full][16][Cin_full], bias, act); output is 2H x 2W
+ * Both honour a pending vf_bn_fuse_next_* attachment like the entry points above. */
+int vf_planes_split(vf_ctx* ctx, const float* x, void* planes, int64_t n);
+int vf_weight_planes(vf_ctx* ctx, const float* w, void* planes_native, void* planes_transposed, int d0, int d1);
+/* the same for n weights in one launch: desc_dev = device array of n records {const float* w; void* native; void* transposed;
+ * int d0, d1, gx = ceil(d0/32), gz = ceil(d1/32), blk_off (first block of the record: running sum of gx*16*gz), pad;} (48 bytes
+ * each); blocks = the total.  A net refreshes its weight planes once per parameter update (optim.adam, train.lua:421-424). */
+int vf_weight_planes_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks);
+int vf_pconv_supported(int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int transposed);
+int vf_pconv_gather(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                    int Cout, int act, float slope);
+int vf_pconv_scatter(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                     int Cout, int act, float slope, const float* dmask, int dact, float dslope);
+
 /* ---- nn.SpatialBatchNormalization (THNN/THCUNN BatchNormalization; train.lua:92) ------------ */
 /* Training forward in two phases so a data-parallel caller can all-reduce `sums` in between:
  *   vf_bn_stats     : sums[0..C) = sum(x - shift), sums[C..2C) = sum((x - shift)^2)  (DOUBLE), shift = running_mean
@@ -146,7 +175,9 @@ int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, const floa
  *   bwd: the data-gradient pass stores its output ALREADY MASKED by the derivative of the activation fused behind the
  *        BatchNorm (act, y_act = the activated BatchNorm output; nn.LeakyReLU / nn.ReLU:updateGradInput) and sums
  *        g and g * (x - save_mean), x = the BatchNorm's input                                   -> vf_bn_bwd_pre
- * The _pre calls are vf_bn_train_fwd_groups / vf_bn_bwd_groups without their statistics pass (g_masked: no activation). */
+ * The _pre calls are vf_bn_train_fwd_groups / vf_bn_bwd_groups without their statistics pass (g_masked: no activation);
+ * y_planes / gx_planes (may be NULL): the three bf16 planes of the output, [3][groups * npix_per_group * C], written beside
+ * it for a vf_pconv_* consumer. */
 int vf_bn_fuse_next_fwd(vf_ctx* ctx, const float* shift, double* part, int part_rows_cap, int groups);
 int vf_bn_fuse_next_bwd(vf_ctx* ctx, const float* x, const float* y_act, int act, float slope, const float* save_mean,
                         double* part, int part_rows_cap, int groups);
@@ -154,10 +185,10 @@ int vf_bn_fuse_result(vf_ctx* ctx, int* rows_per_group);
 int vf_bn_train_fwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, float* y, const float* gamma,
                         const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                         double* sums, int64_t npix_per_group, int C, int groups, float momentum, float eps, int act,
-                        float slope);
+                        float slope, void* y_planes);
 int vf_bn_bwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, const float* g_masked, float* gx,
                   float* ggamma, float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
-                  double* sums, int64_t npix_per_group, int C, int groups, float pbeta);
+                  double* sums, int64_t npix_per_group, int C, int groups, float pbeta, void* gx_planes);
 
 /* ---- pointwise modules (nn.LeakyReLU / ReLU / Tanh / Sigmoid; train.lua:90,146,196) --------- */
 int vf_act_fwd(vf_ctx* ctx, const float* x, float* y, int64_t n, int act, float slope); /* y may alias x */

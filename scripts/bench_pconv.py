@@ -1,0 +1,47 @@
+"""Single-pass timing of the planes GEMM (vf_pgemm.hip) beside the in-kernel-split kernels (vf_conv.hip) on the layers of
+BASELINE.json configs[1]: back-to-back launches, one event pair around 50 of them.   python scripts/bench_pconv.py [B]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from video_filler_amd.backend import get_backend
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+hb = get_backend()
+# (name, gathered channels, gather grid H, output channels)   conv-like: x [B][H][H][Cin] -> [B][H/2][H/2][Cout]
+LAYERS = [("E2", 64, 64, 64), ("E3", 64, 32, 128), ("E4", 128, 16, 256), ("E5", 256, 8, 512), ("C1@2B", 64, 32, 128)]
+
+
+only = os.environ.get("ONLY", "")
+LAYERS = [l for l in LAYERS if not only or l[0] in only.split(",")]
+
+
+def timeit(fn, nb=int(os.environ.get("NB", "50"))):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nb):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / nb * 1e3
+
+
+for name, Cin, H, Cout in LAYERS:
+    Bn = 2 * B if "@2B" in name else B
+    x = hb.empty_act(Bn, Cin, H, H).normal_()
+    y = hb.empty_act(Bn, Cout, H // 2, H // 2).normal_()
+    gx = hb.empty_act(Bn, Cin, H, H)
+    w = (hb.empty(Cout, 4, 4, Cin).normal_() * 0.02).permute(0, 3, 1, 2)
+    xp, yp = hb.planes_split(x), hb.planes_split(y)
+    wn, wt = hb.weight_planes(w)
+    fl = 2.0 * Bn * (H // 2) ** 2 * Cout * Cin * 16
+    t_old = timeit(lambda: hb.conv2d_fwd(x, w, None, y, 4, 2, 1))
+    t_new = timeit(lambda: hb.pconv_gather(xp, wn, None, y, Bn, H, H, Cin, Cout))
+    print("%-6s gather  B=%3d  old %7.1f us %6.1f TF   planes %7.1f us %6.1f TF   x%.2f" % (name, Bn, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new))
+    t_old = timeit(lambda: hb.conv2d_bwd_data(y, w, gx, 4, 2, 1))
+    t_new = timeit(lambda: hb.pconv_scatter(yp, wt, None, gx, Bn, H // 2, H // 2, Cout, Cin))
+    print("%-6s scatter B=%3d  old %7.1f us %6.1f TF   planes %7.1f us %6.1f TF   x%.2f" % (name, Bn, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new))
+t = timeit(lambda: hb.planes_split(x, xp))
+print("planes_split of %d elements: %.1f us (%.0f GB/s)" % (x.numel(), t, 10.0 * x.numel() / t / 1e3))

@@ -1,0 +1,110 @@
+"""The convolution passes from operands pre-split into three bf16 planes (csrc/vf_pgemm.hip) against the kernels that split
+inside the GEMM (csrc/vf_conv.hip, themselves checked against the oracle in test_gpu_ops.py / test_gpu_conv_sweep.py):
+the two form the same six-term products and differ only in the order the K dimension is summed in, so they agree to fp32
+rounding — 2e-6 of the output's max-norm — and both sit within 2e-5 of an fp64 evaluation of the same convolution."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, dev, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def _act(Bn, C, H, seed, dev):
+    return _rand((Bn, H, H, C), seed, dev).permute(0, 3, 1, 2)
+
+
+def test_planes_are_an_exact_three_way_split(hipb):
+    x = _rand((1 << 16,), 1, hipb.device)
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -1.1754944e-38, 1e-30, 123456.789])
+    x[8:4104] = x[8:4104] * torch.logspace(-30, 30, 4096).to(hipb.device)
+    pl = hipb.planes_split(x)
+    f = pl.float()
+    assert torch.equal((f[0] + f[1]) + f[2], x)                  # hi + mid + lo == x, bit for bit
+    assert torch.equal(f[0], (x.view(torch.int32) & -65536).view(torch.float32))      # hi = the top 16 bits
+    # each plane carries at most 8 significant bits of what the planes before it left over
+    assert float((f[1].abs() > f[0].abs() * 2.0 ** -7).sum()) == 0
+
+
+def test_weight_planes_native_and_transposed(hipb):
+    w = (_rand((96, 4, 4, 40), 2, hipb.device, 0.05)).permute(0, 3, 1, 2)          # logical [d0][d1][4][4]
+    nat, tr = hipb.weight_planes(w)
+    phys = w.permute(0, 2, 3, 1).contiguous()                                         # [d0][4][4][d1]
+    f = nat.float().view(3, 96, 16, 40)
+    assert torch.equal((f[0] + f[1]) + f[2], phys.view(96, 16, 40))
+    t = tr.float().view(3, 40, 16, 96)
+    assert torch.equal((t[0] + t[1]) + t[2], phys.view(96, 16, 40).permute(2, 1, 0).contiguous())
+
+
+CASES = [(8, 64, 64, 64), (8, 64, 32, 128), (16, 128, 16, 256), (16, 256, 8, 512), (4, 192, 32, 384), (6, 32, 32, 96),
+         (64, 64, 32, 128), (3, 96, 16, 36)]
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout", CASES, ids=lambda v: str(v))
+def test_gather_pass_matches_the_in_kernel_split(Bn, Cin, H, Cout, hipb):
+    """conv forward (with bias + LeakyReLU) and full-conv data-gradient"""
+    dev = hipb.device
+    x = _act(Bn, Cin, H, 3, dev)
+    w = _rand((Cout, 4, 4, Cin), 4, dev, 0.05).permute(0, 3, 1, 2)
+    bias = _rand((Cout,), 5, dev, 0.1)
+    assert hipb.pconv_supported(Bn, H, H, Cin, Cout, 4, 2, 1, False)
+    want = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+    hipb.conv2d_fwd(x, w, bias, want, 4, 2, 1, "lrelu", 0.2)
+    xp = hipb.planes_split(x)
+    wp, _ = hipb.weight_planes(w, want_transposed=False)
+    got = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+    hipb.pconv_gather(xp, wp, bias, got, Bn, H, H, Cin, Cout, "lrelu", 0.2)
+    e = float((got - want).abs().max() / want.abs().max())
+    assert e <= 2e-6, e
+    if Bn * H * H * Cin <= 1 << 21:
+        ref = torch.nn.functional.conv2d(x.double().cpu().contiguous(), w.double().cpu().contiguous(), bias.double().cpu(), stride=2, padding=1)
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+        assert float((got.cpu().double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout", CASES, ids=lambda v: str(v))
+def test_scatter_pass_matches_the_in_kernel_split(Bn, Cin, H, Cout, hipb):
+    """conv data-gradient (plain and with the activation-derivative epilogue) and full-conv forward (bias + ReLU): the
+    low-res operand has Cout channels on an H/2 grid, the result Cin channels on the H grid"""
+    dev = hipb.device
+    Hl = H // 2
+    gy = _act(Bn, Cout, Hl, 6, dev)
+    w = _rand((Cout, 4, 4, Cin), 7, dev, 0.05).permute(0, 3, 1, 2)                   # conv weight [Cout][Cin][4][4]
+    if not hipb.pconv_supported(Bn, Hl, Hl, Cout, Cin, 4, 2, 1, True):
+        pytest.skip("the gathered operand's channel count is not a multiple of 32")
+    want = hipb.empty_act(Bn, Cin, H, H)
+    hipb.conv2d_bwd_data(gy, w, want, 4, 2, 1)
+    gp = hipb.planes_split(gy)
+    _, wt = hipb.weight_planes(w)                                                     # transposed planes [Cin][16][Cout]
+    got = hipb.empty_act(Bn, Cin, H, H)
+    hipb.pconv_scatter(gp, wt, None, got, Bn, Hl, Hl, Cout, Cin)
+    e = float((got - want).abs().max() / want.abs().max())
+    assert e <= 2e-6, e
+    if Bn * H * H * Cin <= 1 << 21:
+        ref = torch.nn.functional.conv_transpose2d(gy.double().cpu().contiguous(), w.double().cpu().contiguous(), None, stride=2, padding=1)
+        assert float((got.cpu().double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+    # the derivative mask of the (leaky) ReLU that produced this conv's input, in the epilogue
+    xact = _act(Bn, Cin, H, 8, dev)
+    hipb.conv2d_bwd_data_act(gy, w, want, xact, "lrelu", 0.2, 4, 2, 1)
+    hipb.pconv_scatter(gp, wt, None, got, Bn, Hl, Hl, Cout, Cin, dmask=xact, dact="lrelu", dslope=0.2)
+    assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
+    # full-conv forward: weight [Cin_full = Cout here][Cout_full = Cin here]: the same physical tensor read the other way
+    bias = _rand((Cin,), 9, dev, 0.1)
+    hipb.deconv2d_fwd(gy, w, bias, want, 4, 2, 1, "relu", 0.0)
+    hipb.pconv_scatter(gp, wt, bias, got, Bn, Hl, Hl, Cout, Cin, "relu", 0.0)
+    assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
+
+
+def test_unsupported_shapes_are_reported(hipb):
+    assert not hipb.pconv_supported(8, 64, 64, 3, 64, 4, 2, 1, False)       # thin input
+    assert not hipb.pconv_supported(8, 64, 64, 48, 64, 4, 2, 1, False)      # 48 channels: not a multiple of 32
+    assert not hipb.pconv_supported(8, 32, 32, 64, 3, 4, 2, 1, True)        # thin output
+    assert not hipb.pconv_supported(64, 4, 4, 512, 4000, 4, 1, 0, False)    # the bottleneck GEMMs
+    assert not hipb.pconv_supported(1, 8, 8, 64, 64, 4, 2, 1, False)        # 16 GEMM rows
+    x = hipb.zeros(4 * 8 * 8 * 48)
+    with pytest.raises(RuntimeError):
+        hipb.pconv_gather(hipb.planes_split(x), hipb.planes_split(hipb.zeros(64 * 16 * 48)), None, hipb.zeros(4 * 4 * 4 * 64), 4, 8, 8, 48, 64)

@@ -37,6 +37,12 @@ SIGNATURES = {
     "vf_deconv2d_fwd": (i32, [vp, vp, vp, vp, vp] + [i32] * 8 + [i32, f32]),
     "vf_deconv2d_bwd_data": (i32, [vp, vp, vp, vp] + [i32] * 8),
     "vf_deconv2d_bwd_weight": (i32, [vp, vp, vp, vp, vp] + [i32] * 8 + [f32]),
+    "vf_planes_split": (i32, [vp, vp, vp, i64]),
+    "vf_weight_planes": (i32, [vp, vp, vp, vp, i32, i32]),
+    "vf_weight_planes_multi": (i32, [vp, vp, i32, i32]),
+    "vf_pconv_supported": (i32, [i32] * 9),
+    "vf_pconv_gather": (i32, [vp, vp, vp, vp, vp] + [i32] * 5 + [i32, f32]),
+    "vf_pconv_scatter": (i32, [vp, vp, vp, vp, vp] + [i32] * 5 + [i32, f32, vp, i32, f32]),
     "vf_bn_stats": (i32, [vp, vp, vp, vp, i64, i32]),
     "vf_bn_finalize": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32]),
     "vf_bn_apply": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, f32]),
@@ -50,8 +56,8 @@ SIGNATURES = {
     "vf_bn_fuse_next_fwd": (i32, [vp, vp, vp, i32, i32]),
     "vf_bn_fuse_next_bwd": (i32, [vp, vp, vp, i32, f32, vp, vp, i32, i32]),
     "vf_bn_fuse_result": (i32, [vp, C.POINTER(i32)]),
-    "vf_bn_train_fwd_pre": (i32, [vp, vp, i32] + [vp] * 9 + [i64, i32, i32, f32, f32, i32, f32]),
-    "vf_bn_bwd_pre": (i32, [vp, vp, i32] + [vp] * 9 + [i64, i32, i32, f32]),
+    "vf_bn_train_fwd_pre": (i32, [vp, vp, i32] + [vp] * 9 + [i64, i32, i32, f32, f32, i32, f32, vp]),
+    "vf_bn_bwd_pre": (i32, [vp, vp, i32] + [vp] * 9 + [i64, i32, i32, f32, vp]),
     "vf_act_fwd": (i32, [vp, vp, vp, i64, i32, f32]),
     "vf_act_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32]),
     "vf_axpby": (i32, [vp, f32, vp, f32, vp, i64]),

@@ -16,6 +16,9 @@ ACT = {"none": 0, "lrelu": 1, "relu": 2, "tanh": 3, "sigmoid": 4}
 # struct VfColsumDesc of csrc/vf_bn.hip (64 bytes)
 COLSUM_DESC = [("g", "<u8"), ("gb", "<u8"), ("part", "<u8"), ("P", "<i8"), ("C", "<i4"), ("cq", "<i4"), ("rows_per_block", "<i4"),
                ("gx", "<i4"), ("gy", "<i4"), ("blk1_off", "<i4"), ("blk2_off", "<i4"), ("beta", "<f4")]
+# struct VfWpDesc of csrc/vf_pgemm.hip (48 bytes)
+WPLANES_DESC = [("w", "<u8"), ("nat", "<u8"), ("tr", "<u8"), ("d0", "<i4"), ("d1", "<i4"), ("gx", "<i4"), ("gz", "<i4"),
+                ("blk_off", "<i4"), ("pad", "<i4")]
 MFMA_MODES = {"f32": 0, "bf16": 1, "f32_3xbf16": 3}
 DEFAULT_MFMA_MODE = "f32_3xbf16"
 
@@ -213,6 +216,53 @@ class HipBackend:
         self._c("vf_deconv2d_bwd_weight", _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), B, H, W, Cin, gw.shape[1], k, stride,
                 pad, beta)
 
+    # ---- operands pre-split into three bf16 planes (vf_pgemm.hip).  `planes`: torch.bfloat16 [3, n]
+    def planes_split(self, x, planes=None):
+        n = x.numel()
+        if planes is None:
+            planes = torch.empty((3, n), dtype=torch.bfloat16, device=self.device)
+        self._c("vf_planes_split", _ptr(x), _ptr(planes), n)
+        return planes
+
+    def weight_planes(self, w, native=None, transposed=None, want_transposed=True):
+        """w: a conv / full-conv weight (logical [d0][d1][4][4], physical [d0][4][4][d1]) -> (native, transposed) planes"""
+        d0, d1 = w.shape[0], w.shape[1]
+        n = w.numel()
+        if native is None:
+            native = torch.empty((3, n), dtype=torch.bfloat16, device=self.device)
+        if transposed is None and want_transposed:
+            transposed = torch.empty((3, n), dtype=torch.bfloat16, device=self.device)
+        self._c("vf_weight_planes", _ptr(w), _ptr(native), _ptr(transposed), d0, d1)
+        return native, transposed
+
+    def weight_planes_multi(self, items):
+        """items: [(w, native planes, transposed planes)] -> one launch; returns the plan (kept by the caller: the table lives on
+        the device and is reused every iteration)"""
+        import numpy as np
+        desc = np.zeros(len(items), dtype=WPLANES_DESC)
+        blocks = 0
+        for i, (w, nat, tr) in enumerate(items):
+            d0, d1 = w.shape[0], w.shape[1]
+            gx, gz = (d0 + 31) // 32, (d1 + 31) // 32
+            desc[i] = (w.data_ptr(), nat.data_ptr(), tr.data_ptr(), d0, d1, gx, gz, blocks, 0)
+            blocks += gx * 16 * gz
+        dev = torch.from_numpy(desc.view(np.uint8).copy()).to(self.device)
+        return (dev, len(items), blocks, tuple(w.data_ptr() for w, _, _ in items))
+
+    def weight_planes_run(self, plan):
+        dev, n, blocks, _ = plan
+        self._c("vf_weight_planes_multi", _ptr(dev), n, blocks)
+
+    def pconv_supported(self, B, H, W, Cin, Cout, k, stride, pad, transposed):
+        return bool(self.lib.vf_pconv_supported(B, H, W, Cin, Cout, k, stride, pad, 1 if transposed else 0))
+
+    def pconv_gather(self, ap, wp, bias, y, B, H, W, Cin, Cout, act="none", slope=0.0):
+        self._c("vf_pconv_gather", _ptr(ap), _ptr(wp), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, ACT[act], slope)
+
+    def pconv_scatter(self, ap, wp, bias, y, B, H, W, Cin, Cout, act="none", slope=0.0, dmask=None, dact="none", dslope=0.0):
+        self._c("vf_pconv_scatter", _ptr(ap), _ptr(wp), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, ACT[act], slope, _ptr(dmask),
+                ACT[dact], dslope)
+
     # ---- batch norm
     def bn_stats(self, x, shift, sums):
         B, Cc, H, W = x.shape
@@ -264,15 +314,17 @@ class HipBackend:
         return rows.value
 
     def bn_train_fwd_pre(self, part, rows, x, y, gamma, beta, rm, rv, save_mean, save_invstd, sums, groups, momentum, eps,
-                         act="none", slope=0.0):
+                         act="none", slope=0.0, y_planes=None):
         B, Cc, H, W = x.shape
         self._c("vf_bn_train_fwd_pre", _ptr(part), rows, _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv),
-                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, momentum, eps, ACT[act], slope)
+                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, momentum, eps, ACT[act], slope,
+                _ptr(y_planes))
 
-    def bn_bwd_pre(self, part, rows, x, g_masked, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, groups, pbeta=1.0):
+    def bn_bwd_pre(self, part, rows, x, g_masked, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, groups, pbeta=1.0,
+                   gx_planes=None):
         B, Cc, H, W = x.shape
         self._c("vf_bn_bwd_pre", _ptr(part), rows, _ptr(x), _ptr(g_masked), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
-                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, pbeta)
+                _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, pbeta, _ptr(gx_planes))
 
     def bn_eval_fwd(self, x, y, gamma, beta, rm, rv, eps, act="none", slope=0.0):
         B, Cc, H, W = x.shape

@@ -16,6 +16,28 @@
 #include "vf_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Exact three-way split of four fp32 values into bf16 planes (hi + mid + lo == x bit for bit; the arithmetic of
+// vf_pgemm.hip's pg_split4): the BatchNorm apply / backward passes write the planes of their output beside it, so the
+// convolution that consumes it (vf_pconv_*) finds its operand already split.  plane q of element i: planes[q * pstride + i].
+__device__ __forceinline__ void bn_store_planes(unsigned short* __restrict__ planes, int64_t pstride, int64_t i, f32x4 v) {
+  float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1), u2 = __float_as_uint(r2), u3 = __float_as_uint(r3);
+    u32x2 o;
+    o[0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    o[1] = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+    *(u32x2*)(planes + q * pstride + i) = o;
+    if (q < 2) {
+      r0 -= __uint_as_float(u0 & 0xffff0000u);
+      r1 -= __uint_as_float(u1 & 0xffff0000u);
+      r2 -= __uint_as_float(u2 & 0xffff0000u);
+      r3 -= __uint_as_float(u3 & 0xffff0000u);
+    }
+  }
+}
 
 struct BnGeom {
   int cq;              // float4 columns per block (power of two <= 64)
@@ -96,10 +118,12 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, c
 }
 
 // Second stage of every two-stage reduction: partial[slab][ncol] (double) -> per-column totals.
-// 4 columns per block, one wave (64 slab lanes) per column, 4 independent loads in flight per lane, then a fixed
-// shuffle tree: deterministic, and short enough (~16 loads per lane) to sit at the launch floor.
+// A block owns 16 columns x 16 slab lanes: lane (cx, ry) walks rows ry, ry + 16, ... of its column with four independent
+// sums in flight (128-byte row segments, coalesced over cx), the 16 slab lanes of a column meet in LDS in a fixed order:
+// deterministic.  (The first form — one wave per column, its 64 lanes a partial row apart — read one cache line per lane
+// and took 5-9 us for the 512-1024 rows the GEMM epilogues leave; this one is bounded by the launch.)
 //   EPI 0: sums[col] = total                                   (two-phase BN API, backward statistics)
-//   EPI 1: BatchNorm finalize fused: the block owns 2 channels = columns {c, C+c}; writes save_mean/save_invstd and
+//   EPI 1: BatchNorm finalize fused: the block owns 8 channels = columns {c, C+c}; writes save_mean/save_invstd and
 //          updates the running statistics (THNN BatchNormalization_updateOutput, train branch); also stores sums
 //   EPI 2: bias gradient: gb[col] = beta*gb[col] + total
 template <int EPI>
@@ -108,7 +132,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
                                                          float* __restrict__ save_invstd, double n, float momentum, float eps,
                                                          float* __restrict__ gb, float beta, int groups) {
-  const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   if constexpr (EPI == 0) {       // blockIdx.y = batch group: its own partials and totals
     part += (int64_t)blockIdx.y * nslab * ncol;
     sums += (int64_t)blockIdx.y * ncol;
@@ -117,53 +141,58 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
   bool ok;
   if constexpr (EPI == 1) {
     const int C = ncol >> 1;
-    const int c = blockIdx.x * 2 + (slot >> 1);
+    const int c = blockIdx.x * 8 + (cx & 7);
     ok = c < C;
-    col = (slot & 1) * C + c;
+    col = (cx >> 3) * C + c;
   } else {
-    col = blockIdx.x * 4 + slot;
+    col = blockIdx.x * 16 + cx;
     ok = col < ncol;
   }
-  auto column_total = [&](const double* pbase) {
+  __shared__ double red[16][17];
+  auto column_total = [&](const double* pbase) {      // valid in the threads with ry == 0
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (ok) {
       const double* p = pbase + col;
-      int k = lane;
-      for (; k + 192 < nslab; k += 256) {
+      int k = ry;
+      for (; k + 48 < nslab; k += 64) {
         s0 += p[(int64_t)k * ncol];
-        s1 += p[(int64_t)(k + 64) * ncol];
-        s2 += p[(int64_t)(k + 128) * ncol];
-        s3 += p[(int64_t)(k + 192) * ncol];
+        s1 += p[(int64_t)(k + 16) * ncol];
+        s2 += p[(int64_t)(k + 32) * ncol];
+        s3 += p[(int64_t)(k + 48) * ncol];
       }
-      for (; k < nslab; k += 64) s0 += p[(int64_t)k * ncol];
+      for (; k < nslab; k += 16) s0 += p[(int64_t)k * ncol];
     }
-    double t = (s0 + s1) + (s2 + s3);
+    __syncthreads();                                   // (the previous group's totals have been read)
+    red[ry][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    double t = 0;
+    if (ry == 0) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+      for (int j = 0; j < 16; ++j) t += red[j][cx];
+    }
     return t;
   };
   if constexpr (EPI == 0) {
     const double t = column_total(part);
-    if (lane == 0 && ok) sums[col] = t;
+    if (ry == 0 && ok) sums[col] = t;
   } else if constexpr (EPI == 2) {
     const double t = column_total(part);
-    if (lane == 0 && ok) gb[col] = (beta != 0.f ? beta * gb[col] : 0.f) + (float)t;
+    if (ry == 0 && ok) gb[col] = (beta != 0.f ? beta * gb[col] : 0.f) + (float)t;
   } else {
     // groups > 1: the batch groups are finalized one after the other, as separate forward calls would — every group's
     // sums were taken about the SAME shift (the running mean before the first update), the running averages move once
     // per group in group order
-    __shared__ double tot[4];
+    __shared__ double tot[16];
     const int C = ncol >> 1;
-    const int c = blockIdx.x * 2 + (slot >> 1);
+    const int c = blockIdx.x * 8 + (cx & 7);
     double shift = 0;
     if (ok) shift = running_mean[c];
     for (int g = 0; g < groups; ++g) {
       const double t = column_total(part + (int64_t)g * nslab * ncol);
+      if (ry == 0) tot[cx] = t;
       __syncthreads();
-      if (lane == 0) tot[slot] = t;
-      __syncthreads();
-      if (lane == 0 && ok && (slot & 1) == 0) {
-        const double q1 = tot[slot], q2 = tot[slot + 1];
+      if (ry == 0 && ok && cx < 8) {
+        const double q1 = tot[cx], q2 = tot[cx + 8];
         if (sums) {
           sums[(int64_t)g * ncol + c] = q1;
           sums[(int64_t)g * ncol + C + c] = q2;
@@ -249,9 +278,11 @@ __global__ void k_bn_finalize(const double* __restrict__ sums, float* __restrict
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, float* __restrict__ y,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                  int64_t npix, int C, int cq, int rows_per_block, int act, float slope) {
+                                                  int64_t npix, int C, int cq, int rows_per_block, int act, float slope,
+                                                  unsigned short* __restrict__ planes, int64_t pstride) {
   x += (int64_t)blockIdx.z * npix * C;        // batch group z: its rows, its statistics
   y += (int64_t)blockIdx.z * npix * C;
+  if (planes) planes += (int64_t)blockIdx.z * npix * C;
   mean += (int64_t)blockIdx.z * C;
   invstd += (int64_t)blockIdx.z * C;
   const int rp = 256 / cq;
@@ -268,6 +299,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, f
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = vf_act_apply(v[e], act, slope);
     *(f32x4*)(y + r * C + 4 * c4) = v;
+    if (planes) bn_store_planes(planes, pstride, r * C + 4 * c4, v);
   }
 }
 
@@ -341,7 +373,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const double* __restrict__ sums,
                                                       int64_t npix, double n, int C, int cq, int rows_per_block, int act,
-                                                      float slope, float pbeta) {
+                                                      float slope, float pbeta, unsigned short* __restrict__ planes, int64_t pstride) {
   const int rp = 256 / cq;
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
   const int c4 = blockIdx.y * cq + tx;
@@ -369,6 +401,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     gy += go;
     gx += go;
     if (yact) yact += go;
+    if (planes) planes += go;
     mean += (int64_t)blockIdx.z * C;
     invstd += (int64_t)blockIdx.z * C;
     sums += (int64_t)blockIdx.z * 2 * C;
@@ -392,7 +425,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
       for (int e = 0; e < 4; ++e) g[e] = vf_act_grad(ya[e], g[e], act, slope);
     }
     const f32x4 xv = *(const f32x4*)(x + o);
-    *(f32x4*)(gx + o) = (g - gm - (xv - mu) * kk) * is * ga;
+    const f32x4 out = (g - gm - (xv - mu) * kk) * is * ga;
+    *(f32x4*)(gx + o) = out;
+    if (planes) bn_store_planes(planes, pstride, o, out);
   }
 }
 
@@ -464,7 +499,7 @@ __global__ __launch_bounds__(256) void k_reduce_bias_multi(const VfColsumDesc* _
 
 // ================================================================================================ host
 static int run_stats(vf_ctx* ctx, const BnGeom& g, double* sums, int C, int groups = 1) {
-  hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4), groups), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 16), groups), dim3(256), 0, ctx->stream,
                      (const double*)vf_ws_ptr(ctx), g.gx, 2 * C, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                      (float*)nullptr, 0.0, 0.f, 0.f, (float*)nullptr, 0.f, 1);
   VF_LAUNCH_CHECK();
@@ -488,7 +523,7 @@ int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C,
     hipLaunchKernelGGL(k_colsum1, dim3(nslab, C), dim3(256), 0, ctx->stream, g, part, P, C, (int)rpb);
   }
   VF_LAUNCH_CHECK();
-  hipLaunchKernelGGL((k_reduce_partials<2>), dim3((int)vf_cdiv(C, 4)), dim3(256), 0, ctx->stream, (const double*)part, nslab,
+  hipLaunchKernelGGL((k_reduce_partials<2>), dim3((int)vf_cdiv(C, 16)), dim3(256), 0, ctx->stream, (const double*)part, nslab,
                      C, (double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.0, 0.f, 0.f,
                      gb, beta, 1);
   VF_LAUNCH_CHECK();
@@ -520,18 +555,18 @@ VF_API int vf_bn_apply(vf_ctx* ctx, const float* x, float* y, const float* gamma
   const BnGeom g = bn_geom(npix, C);
   VfProf prof(ctx, "bn_apply", 0.0, 8.0 * (double)npix * C);
   hipLaunchKernelGGL(k_bn_apply, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y, gamma, beta, mean, invstd, npix, C, g.cq,
-                     g.rows_per_block, act, slope);
+                     g.rows_per_block, act, slope, (unsigned short*)nullptr, (int64_t)0);
   VF_LAUNCH_CHECK();
   return 0;
 }
 
 static int bn_apply_groups(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta, const float* mean,
-                           const float* invstd, int64_t npix, int C, int groups, int act, float slope) {
+                           const float* invstd, int64_t npix, int C, int groups, int act, float slope, void* planes = nullptr) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   const BnGeom g = bn_geom(npix, C);
-  VfProf prof(ctx, "bn_apply", 0.0, 8.0 * (double)npix * C * groups);
+  VfProf prof(ctx, planes ? "bn_apply_planes" : "bn_apply", 0.0, (planes ? 14.0 : 8.0) * (double)npix * C * groups);
   hipLaunchKernelGGL(k_bn_apply, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, y, gamma, beta, mean, invstd, npix, C,
-                     g.cq, g.rows_per_block, act, slope);
+                     g.cq, g.rows_per_block, act, slope, (unsigned short*)planes, npix * C * groups);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -549,7 +584,7 @@ static int bn_train_fwd_groups(vf_ctx* ctx, const float* x, float* y, const floa
                        (double*)vf_ws_ptr(ctx), npix, C, g.cq, g.rows_per_block);
     VF_LAUNCH_CHECK();
     // second stage + finalize in one launch (the single-device path needs no hook between them)
-    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 2)), dim3(256), 0, ctx->stream, (const double*)vf_ws_ptr(ctx),
+    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 8)), dim3(256), 0, ctx->stream, (const double*)vf_ws_ptr(ctx),
                        g.gx, 2 * C, sums, running_mean, running_var, save_mean, save_invstd, (double)npix, momentum, eps,
                        (float*)nullptr, 0.f, groups);
     VF_LAUNCH_CHECK();
@@ -600,12 +635,15 @@ static int bn_bwd_stats_groups(vf_ctx* ctx, const float* x, const float* y_act, 
 static int bn_bwd_apply_groups(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
                                float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
                                const double* sums, int64_t npix, int64_t n_total, int C, int groups, int act, float slope,
-                               float pbeta) {
+                               float pbeta, void* planes = nullptr) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
+  VF_REQUIRE(!planes || gx, "gradient planes go with the gradient itself");
   const BnGeom g = bn_geom(npix, C);
-  VfProf prof(ctx, "bn_bwd_apply", 0.0, gx ? 4.0 * (double)npix * C * groups * (act != VF_ACT_NONE ? 4 : 3) : 0.0);
+  VfProf prof(ctx, planes ? "bn_bwd_apply_planes" : "bn_bwd_apply", 0.0,
+              gx ? (double)npix * C * groups * (4.0 * (act != VF_ACT_NONE ? 4 : 3) + (planes ? 6.0 : 0.0)) : 0.0);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, y_act, gy, gx, ggamma, gbeta, gamma,
-                     save_mean, save_invstd, sums, npix, (double)n_total, C, g.cq, g.rows_per_block, act, slope, pbeta);
+                     save_mean, save_invstd, sums, npix, (double)n_total, C, g.cq, g.rows_per_block, act, slope, pbeta,
+                     (unsigned short*)planes, npix * C * groups);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -644,32 +682,32 @@ VF_API int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, con
 VF_API int vf_bn_train_fwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, float* y, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                                double* sums, int64_t npix_per_group, int C, int groups, float momentum, float eps, int act,
-                               float slope) {
+                               float slope, void* y_planes) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   VF_REQUIRE(part && rows_per_group > 0 && groups >= 1 && groups <= 64, "vf_bn_train_fwd_pre: bad partials");
   {
     VfProf prof(ctx, "bn_finalize", 0.0, 8.0 * (double)rows_per_group * 2 * C * groups);
-    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 2)), dim3(256), 0, ctx->stream, part, rows_per_group, 2 * C, sums,
+    hipLaunchKernelGGL((k_reduce_partials<1>), dim3((int)vf_cdiv(C, 8)), dim3(256), 0, ctx->stream, part, rows_per_group, 2 * C, sums,
                        running_mean, running_var, save_mean, save_invstd, (double)npix_per_group, momentum, eps, (float*)nullptr, 0.f,
                        groups);
     VF_LAUNCH_CHECK();
   }
-  return bn_apply_groups(ctx, x, y, gamma, beta, save_mean, save_invstd, npix_per_group, C, groups, act, slope);
+  return bn_apply_groups(ctx, x, y, gamma, beta, save_mean, save_invstd, npix_per_group, C, groups, act, slope, y_planes);
 }
 VF_API int vf_bn_bwd_pre(vf_ctx* ctx, const double* part, int rows_per_group, const float* x, const float* g_masked, float* gx,
                          float* ggamma, float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd,
-                         double* sums, int64_t npix_per_group, int C, int groups, float pbeta) {
+                         double* sums, int64_t npix_per_group, int C, int groups, float pbeta, void* gx_planes) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   VF_REQUIRE(part && rows_per_group > 0 && groups >= 1 && groups <= 64, "vf_bn_bwd_pre: bad partials");
   {
     VfProf prof(ctx, "bn_bwd_finalize", 0.0, 8.0 * (double)rows_per_group * 2 * C * groups);
-    hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 4), groups), dim3(256), 0, ctx->stream, part, rows_per_group,
+    hipLaunchKernelGGL((k_reduce_partials<0>), dim3((int)vf_cdiv(2 * C, 16), groups), dim3(256), 0, ctx->stream, part, rows_per_group,
                        2 * C, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.0, 0.f, 0.f, (float*)nullptr,
                        0.f, 1);
     VF_LAUNCH_CHECK();
   }
   return bn_bwd_apply_groups(ctx, x, nullptr, g_masked, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix_per_group,
-                             npix_per_group, C, groups, VF_ACT_NONE, 0.f, pbeta);
+                             npix_per_group, C, groups, VF_ACT_NONE, 0.f, pbeta, gx_planes);
 }
 
 // ---- all bias gradients of a backward walk (see VfColsumDesc)

@@ -95,6 +95,16 @@ bool vf_prof_ext(const char* name, double flops, double bytes, hipEvent_t* e0, h
       hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);                                \
   } while (0)
 
+// compile-time loop: f(VfIntC<0>{}) ... f(VfIntC<N-1>{}) — the index is a constant inside the body
+template <int I> struct VfIntC { static constexpr int value = I; };
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void vf_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(VfIntC<I>{});
+    vf_static_for<N, I + 1>(f);
+  }
+}
+
 static inline int vf_ilog2(int v) {  // v must be a power of two
   int l = 0;
   while ((1 << l) < v) ++l;

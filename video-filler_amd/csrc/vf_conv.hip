@@ -1557,6 +1557,27 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB, bool top = 
   return 0;
 }
 
+// the split-K combine for vf_pgemm.hip's launches (plain, or leaving BatchNorm statistics partials)
+bool vf_internal_slab_st_ok(int64_t total, int N, int groups, int rows_cap, int* blocks_per_group) {
+  int upb = 0, ncc = 0;
+  int64_t units = 0;
+  return total % 4 == 0 && slab_st_plan(total, N, groups, rows_cap, &upb, blocks_per_group, &ncc, &units);
+}
+int vf_internal_slab_reduce(vf_ctx* ctx, const float* slab, float* dst, const float* bias, int64_t total, int N, int ksplit, int act,
+                            float slope, const float* dmask, int dact, float dslope, const VfBnSt* st, int st_groups) {
+  if (st) {
+    int upb = 0, bpg = 0, ncc = 0;
+    int64_t units = 0;
+    VF_REQUIRE(total % 4 == 0 && slab_st_plan(total, N, st_groups, st->rows_per_group, &upb, &bpg, &ncc, &units) && bpg == st->rows_per_group,
+               "vf_internal_slab_reduce: the statistics plan changed between the GEMM and its combine");
+    hipLaunchKernelGGL(k_slab_reduce_st, dim3((unsigned)(bpg * st_groups), (unsigned)ncc), dim3(256), 0, ctx->stream, slab, dst, bias,
+                       total / 4, N, ksplit, act, slope, dmask, dact, dslope, upb, units, ncc, *st);
+    VF_LAUNCH_CHECK();
+    return 0;
+  }
+  return launch_slab_reduce(ctx, slab, dst, bias, total, N, ksplit, act, slope, 0.f, dmask, dact, dslope);
+}
+
 // ---- BatchNorm statistics attachment (see VfBnSt; consumed by the next conv-like launch of this context)
 VF_API int vf_bn_fuse_next_fwd(vf_ctx* ctx, const float* shift, double* part, int part_rows_cap, int groups) {
   VF_REQUIRE(shift && part && part_rows_cap > 0 && groups >= 1 && groups <= 64, "vf_bn_fuse_next_fwd: bad arguments");

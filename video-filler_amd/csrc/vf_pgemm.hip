@@ -1,0 +1,933 @@
+// vf_pgemm.hip — the 4x4 stride-2 convolution passes as implicit GEMMs whose operands arrive PRE-SPLIT into bf16 planes.
+//
+// vf_conv.hip's mode-3 kernels split every fp32 operand element into three bf16 planes (x = hi + mid + lo, exact) on its
+// way into LDS: 22 vector instructions per staged float4, in every pass that reads the tensor, next to 12 MFMAs per K
+// step — the matrix pipe was 30 % busy and the kernel issue-bound.  Here the split happens ONCE, where the tensor is
+// produced (BatchNorm apply / BatchNorm backward write the planes beside the fp32 tensor; weights are split once per
+// update; anything else by vf_planes_split), in a pass that is HBM-bound and has the vector slots to spare.  The GEMM's K
+// step is then: 6 16-byte loads, 6 ds_write_b128, 12 ds_read_b128 and 12 v_mfma_f32_32x32x16_bf16 per wave, a handful
+// of address instructions — and bit for bit the same six-term product (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid,
+// smallest first, fp32 accumulation) as mode 3.
+//
+// Planes layout: bf16 [3][elements], plane q at q * plane_stride; activations NHWC per plane, weights row-major
+// [n][16 taps][c] per plane (vf_weight_planes also writes the [c][16][n] transpose the data-gradient passes walk).
+//
+// Reference call sites: nn.SpatialConvolution / nn.SpatialFullConvolution updateOutput, updateGradInput
+// (train.lua:89-146,183-196; THNN SpatialConvolutionMM.c, SpatialFullConvolution.c).
+#include <algorithm>
+#include <cstdlib>
+
+#include "vf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define VF_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ int pg_xcd_remap(int h, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = h & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (h >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------ plane producers
+// Exact three-way split by truncation (the same arithmetic as vf_conv.hip's vf_split3): plane q = top 16 bits of the
+// running residual; every residual subtraction is exact in fp32, after two steps at most 8 significant bits are left.
+__device__ __forceinline__ void pg_split4(f32x4 v, u32x2 (&o)[3]) {
+  float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1), u2 = __float_as_uint(r2), u3 = __float_as_uint(r3);
+    o[q][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    o[q][1] = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+    if (q < 2) {
+      r0 -= __uint_as_float(u0 & 0xffff0000u);
+      r1 -= __uint_as_float(u1 & 0xffff0000u);
+      r2 -= __uint_as_float(u2 & 0xffff0000u);
+      r3 -= __uint_as_float(u3 & 0xffff0000u);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_planes_split(const float* __restrict__ x, __bf16* __restrict__ planes, int64_t n4,
+                                                      int64_t pstride) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    u32x2 o[3];
+    pg_split4(((const f32x4*)x)[i], o);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *(u32x2*)(planes + q * pstride + 4 * i) = o[q];
+  }
+}
+// weights: w physical [d0][16][d1] fp32 -> native planes [3][d0][16][d1] and transposed planes [3][d1][16][d0].
+// One block per (d0 tile of 32, tap, d1 tile of 32): the transpose goes through LDS so that both images are written in
+// whole 64-byte rows.
+__global__ __launch_bounds__(256) void k_weight_planes(const float* __restrict__ w, __bf16* __restrict__ nat, __bf16* __restrict__ tr,
+                                                       int d0, int d1, int64_t pstride) {
+  __shared__ float tile[32][33];
+  const int t0 = blockIdx.x * 32, tap = blockIdx.y, u0 = blockIdx.z * 32;      // d0 tile, tap, d1 tile
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int a = t0 + j, b = u0 + tx;
+    float v = 0.f;
+    if (a < d0 && b < d1) v = w[((int64_t)a * 16 + tap) * d1 + b];
+    tile[j][tx] = v;
+    if (a < d0 && b < d1) {
+      float r = v;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const unsigned u = __float_as_uint(r) & 0xffff0000u;
+        ((unsigned short*)nat)[q * pstride + ((int64_t)a * 16 + tap) * d1 + b] = (unsigned short)(u >> 16);
+        r -= __uint_as_float(u);
+      }
+    }
+  }
+  if (!tr) return;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int b = u0 + j, a = t0 + tx;
+    if (a < d0 && b < d1) {
+      float r = tile[tx][j];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const unsigned u = __float_as_uint(r) & 0xffff0000u;
+        ((unsigned short*)tr)[q * pstride + ((int64_t)b * 16 + tap) * d0 + a] = (unsigned short)(u >> 16);
+        r -= __uint_as_float(u);
+      }
+    }
+  }
+}
+
+// every weight of a net in ONE launch (the nets refresh their weight planes once per parameter update: three launches per
+// training iteration instead of one per layer).  Descriptor table on the device, mirrored by backend.WPLANES_DESC.
+struct VfWpDesc {
+  const float* w;        // physical [d0][16][d1]
+  void* nat;             // planes [3][d0][16][d1]
+  void* tr;              // planes [3][d1][16][d0]
+  int d0, d1;
+  int gx, gz;            // 32-wide tiles over d0 and d1
+  int blk_off;           // first block of this weight
+  int pad;
+};
+static_assert(sizeof(VfWpDesc) == 48, "descriptor layout is shared with the host mirror");
+__global__ __launch_bounds__(256) void k_weight_planes_multi(const VfWpDesc* __restrict__ d, int n) {
+  int l = 0;
+  while (l + 1 < n && (int)blockIdx.x >= d[l + 1].blk_off) ++l;
+  const VfWpDesc L = d[l];
+  const int local = (int)blockIdx.x - L.blk_off;
+  const int bx = local % L.gx, tap = (local / L.gx) % 16, bz = local / (L.gx * 16);
+  const int d0 = L.d0, d1 = L.d1;
+  const int64_t pstride = (int64_t)d0 * 16 * d1;
+  // one 32 x 32 tile of (d0, d1) at one tap: split on the way into LDS, then both images leave in 8-byte pieces (four
+  // consecutive d1 for the native rows, four consecutive d0 for the transposed ones)
+  __shared__ unsigned short t[3][32][36];
+  const int t0 = bx * 32, u0 = bz * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int a = t0 + j, b = u0 + tx;
+    float r = (a < d0 && b < d1) ? L.w[((int64_t)a * 16 + tap) * d1 + b] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned u = __float_as_uint(r) & 0xffff0000u;
+      t[q][j][tx] = (unsigned short)(u >> 16);
+      r -= __uint_as_float(u);
+    }
+  }
+  __syncthreads();
+  const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+  const bool whole = (d0 % 4 == 0) && (d1 % 4 == 0);
+  {      // native: row = d0 index, c4 = d1 offset
+    const int a = t0 + row, b = u0 + c4;
+    if (a < d0 && b < d1) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        unsigned short* dst = (unsigned short*)L.nat + q * pstride + ((int64_t)a * 16 + tap) * d1 + b;
+        if (whole) {
+          u32x2 o;
+          o[0] = t[q][row][c4] | ((unsigned)t[q][row][c4 + 1] << 16);
+          o[1] = t[q][row][c4 + 2] | ((unsigned)t[q][row][c4 + 3] << 16);
+          *(u32x2*)dst = o;
+        } else {
+          for (int e = 0; e < 4 && b + e < d1; ++e) dst[e] = t[q][row][c4 + e];
+        }
+      }
+    }
+  }
+  {      // transposed: row = d1 index, c4 = d0 offset
+    const int b = u0 + row, a = t0 + c4;
+    if (a < d0 && b < d1) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        unsigned short* dst = (unsigned short*)L.tr + q * pstride + ((int64_t)b * 16 + tap) * d0 + a;
+        if (whole) {
+          u32x2 o;
+          o[0] = t[q][c4][row] | ((unsigned)t[q][c4 + 1][row] << 16);
+          o[1] = t[q][c4 + 2][row] | ((unsigned)t[q][c4 + 3][row] << 16);
+          *(u32x2*)dst = o;
+        } else {
+          for (int e = 0; e < 4 && a + e < d0; ++e) dst[e] = t[q][c4 + e][row];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ the GEMM
+struct PGemm {
+  const void* A;         // activation planes [3][pixels][C] bf16
+  const void* W;         // weight planes [3][N][16][C] bf16
+  unsigned a_bytes, w_bytes;     // extent of the three planes together (buffer descriptors)
+  unsigned a_ps, w_ps;           // plane strides in bytes
+  const float* bias;
+  float* Y;
+  float* slab;
+  int64_t out_elems;
+  int M, lgMh, lgMw;     // GEMM rows = B << (lgMh + lgMw), decoded as (b, my, mx)
+  int Hi, Wi, C, N;
+  int sy, oy0, sx, ox0;  // window origin (iy0, ix0) = (my*sy + oy0 (+ph), mx*sx + ox0 (+pw)); taps step +1 from there
+  int lgTW;              // taps per window row: 4 (lgTW 2; 16 taps) or 2 (lgTW 1; the 4 taps of one output-parity class)
+  int kh0, khs, kw0, kws;      // filter tap of window tap (th, tw): (kh0 + th*khs, kw0 + tw*kws); parity: kh0 = 3 - ph, khs = -2
+  int parity;
+  int outH, outW, osy, ooy0, osx, oox0;
+  int gm, gn, gz, ksplit, nchunks;   // nchunks = C / (channels per K step)
+  int act;
+  float slope;
+  const float* dmask;
+  int dact;
+  float dslope;
+  int dbg;               // timing experiments only (VF_PG_DBG; wrong results): 1 = no operand loads after the first step,
+                         // 2 = no LDS writes after the first step, 4 = no MFMAs
+  VfBnSt st;
+};
+
+// per-channel partial sums of one block's output tile (see vf_conv.hip vf_bn_tile_partials: same layout, same order)
+template <int NT, int WAVES_M, int BN>
+__device__ __forceinline__ void pg_bn_tile_partials(const VfBnSt& st, float (&s1)[NT], float (&s2)[NT], float* red, int wave_m, int wn,
+                                                    int lane, int tid, int n0, int N, int bx, int pz) {
+  const int lr = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    s1[nt] += __shfl_xor(s1[nt], 32, 64);
+    s2[nt] += __shfl_xor(s2[nt], 32, 64);
+    if (lane < 32) {
+      red[(wave_m * 2 + 0) * BN + wn + nt * 32 + lr] = s1[nt];
+      red[(wave_m * 2 + 1) * BN + wn + nt * 32 + lr] = s2[nt];
+    }
+  }
+  __syncthreads();
+  if (tid < BN && n0 + tid < N) {
+    double a = 0, b = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES_M; ++w) {
+      a += (double)red[(w * 2 + 0) * BN + tid];
+      b += (double)red[(w * 2 + 1) * BN + tid];
+    }
+    const int g = bx / st.tiles_per_group, local = bx - g * st.tiles_per_group;
+    double* o = st.part + ((int64_t)(g * st.rows_per_group + local * st.zpar + pz) * 2) * N;
+    o[n0 + tid] = a;
+    o[N + n0 + tid] = b;
+  }
+}
+
+// ---- epilogue shared by the GEMM kernels below: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// The store loop is instantiated per (derivative mask present, statistics mode) and the (leaky) ReLU is a select of the
+// multiplier, so the 16 * MT * NT element bodies are straight-line code (with the activation as a per-element switch and
+// the statistics mode as per-element branches the epilogue was a quarter of vf_conv.hip's igemm kernels).
+// `red`: LDS the tile loop no longer needs (2 * WAVES_M * BN floats), for the statistics partials.
+template <int MT, int NT, int WAVES_M, int BN>
+__device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT], float* red, int m0, int n0, int wm, int wn, int lane,
+                                            int tid, int wave_m, int bx, int ks, int ooy0, int oox0, int ph, int pw, bool tile_ok) {
+  const int lr = lane & 31, lh = lane >> 5;
+  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
+  float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
+  const bool fin = p.ksplit == 1;
+  const int stm = fin ? p.st.mode : 0;
+  float bv[NT], sv[NT], st1[NT], st2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + wn + nt * 32 + lr;
+    bv[nt] = (fin && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    sv[nt] = (stm && n < p.N) ? p.st.vec[(stm == 2 ? (bx / p.st.tiles_per_group) * p.N : 0) + n] : 0.f;
+    st1[nt] = 0.f;
+    st2[nt] = 0.f;
+  }
+  // y = v * (v > 0 ? 1 : neg): neg = 1 (none), slope (LeakyReLU), 0 (ReLU) — NaN-propagating like `v > 0 ? v : v * slope`
+  const float neg = !fin ? 1.f : (p.act == VF_ACT_LRELU ? p.slope : (p.act == VF_ACT_RELU ? 0.f : 1.f));
+  const float dneg = p.dact == VF_ACT_LRELU ? p.dslope : (p.dact == VF_ACT_RELU ? 0.f : 1.f);
+  const bool smooth_act = fin && (p.act == VF_ACT_TANH || p.act == VF_ACT_SIGMOID);
+  auto store_all = [&](auto HAS_DMASK, auto STM) {
+    constexpr bool has_dmask = decltype(HAS_DMASK)::value != 0;
+    constexpr int sm = decltype(STM)::value;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+        const int64_t pix = ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = n0 + wn + nt * 32 + lr;
+          if (n < p.N) {
+            float v = acc[mt][nt][r] + bv[nt];
+            v = v * (v > 0.f ? 1.f : neg);
+            if constexpr (has_dmask) v = v * (p.dmask[pix * p.N + n] > 0.f ? 1.f : dneg);
+            if constexpr (sm == 1) {
+              const float d = v - sv[nt];
+              st1[nt] += d;
+              st2[nt] += d * d;
+            } else if constexpr (sm == 2) {
+              st1[nt] += v;
+              st2[nt] += v * (p.st.x[pix * p.N + n] - sv[nt]);
+            }
+            out[pix * p.N + n] = v;
+          }
+        }
+      }
+    }
+  };
+  if (smooth_act) {                 // Tanh / Sigmoid behind a convolution: the image-side layers, not this kernel's business —
+#pragma unroll                      // kept for completeness, generic form
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+        const int64_t pix = ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int n = n0 + wn + nt * 32 + lr;
+          if (n < p.N) out[pix * p.N + n] = vf_act_apply(acc[mt][nt][r] + bv[nt], p.act, p.slope);
+        }
+      }
+  } else if (fin && p.dmask) {
+    if (stm == 2) store_all(VfIntC<1>{}, VfIntC<2>{});
+    else store_all(VfIntC<1>{}, VfIntC<0>{});
+  } else {
+    if (stm == 1) store_all(VfIntC<0>{}, VfIntC<1>{});
+    else if (stm == 2) store_all(VfIntC<0>{}, VfIntC<2>{});
+    else store_all(VfIntC<0>{}, VfIntC<0>{});
+  }
+  if (stm)
+    pg_bn_tile_partials<NT, WAVES_M, BN>(p.st, st1, st2, red, wave_m, wn, lane, tid, n0, tile_ok ? p.N : 0, bx,
+                                         p.parity ? ((ph << 1) | pw) : 0);
+}
+
+// BM x BN block tile, 4 waves of WM x WN (32x32 MFMA tiles), one K step = ONE window tap x CH channels, K walked channel
+// chunk outer / tap inner (the taps of a chunk touch the same input window, so the re-reads stay in L1/L2).
+// CH = 64 wherever C % 64 == 0: a row segment is then a whole 128-byte line per plane.  With 32-channel steps the
+// other half of every fetched line was wanted 16 taps later, long after a 32 KB L1 had dropped it: the loads ran at 26
+// bytes per clock and CU (an L2 -> L1 fill stream of twice the useful bytes) and the whole kernel at their pace — with
+// the MFMAs ablated it took 97 % of its time, with the loads ablated 66 %.
+// LDS: 3 planes x (A, B) tiles, rows of CH bf16 with the 16-byte k-octets XOR-swizzled ((row >> 2) & 3 for 64-byte rows,
+// (row >> 1) & 7 for 128-byte rows: conflict-free ds_read_b128 fragments and ds_write_b128 pieces).
+//   CH = 32: two buffers; per step the loads of step s+1 are issued, the MFMAs of step s run, the pieces go to the other
+//            buffer, one barrier.
+//   CH = 64: one buffer (48 KB for 64x64: three blocks per CU); loads of step s+1 issued, MFMAs of step s, barrier,
+//            pieces to LDS, barrier — half the steps, the same number of barriers per K.
+// PAIR: a workgroup of 512 threads = TWO such tiles (threads 0-255 and 256-511, each with its own LDS tile buffers) whose
+// steps run in ANTI-PHASE: between two consecutive workgroup barriers one half issues its loads and runs its MFMAs while
+// the other waits for its loads and writes them to LDS.  Two independent 256-thread blocks on one CU drift into lockstep
+// (both in the load wait, then both in the MFMAs, then both in the LDS writes — a K step of the pair took the SUM of the
+// phases: matrix pipe 25 %, TA 33 %, LDS 25 % busy, waves a third of their time in s_waitcnt); the pairing pins the
+// complementary schedule.
+template <int BM, int BN, int WM, int WN, int NTAPS, int CH, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256) void k_pconv(const PGemm p) {
+  constexpr int MT = WM / 32, NT = WN / 32, WAVES_N = BN / WN;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+  static_assert(CH == 32 || CH == 64, "K step of 32 or 64 channels");
+  constexpr int OC = CH / 8;                                   // 16-byte octets per row
+  constexpr int A_CH = BM * OC / 256, B_CH = BN * OC / 256;    // 16-byte pieces per thread and plane
+  static_assert(A_CH >= 1 && B_CH >= 1, "tiles of at least 64 rows");
+  constexpr int AH_SZ = BM * CH, BH_SZ = BN * CH, PL_SZ = AH_SZ + BH_SZ;      // bf16 elements
+  constexpr int BUF_SZ = 3 * PL_SZ;
+  constexpr int NBUF = CH == 32 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) __bf16 smem_all[(PAIR ? 2 : 1) * NBUF * BUF_SZ];
+  const int sub = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // which tile of the pair (wave-uniform)
+  __bf16* smem = smem_all + sub * (NBUF * BUF_SZ);
+  auto sw_off = [](int row, int octet) {
+    if constexpr (CH == 32) return row * 32 + ((octet ^ ((row >> 2) & 3)) << 3);
+    else return row * 64 + ((octet ^ ((row >> 1) & 7)) << 3);
+  };
+
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+  const int ntiles = p.gm * p.gn * p.gz;
+  int lid = PAIR ? 2 * pg_xcd_remap(blockIdx.x, gridDim.x) + sub : pg_xcd_remap(blockIdx.x, ntiles);
+  const bool tile_ok = lid < ntiles;       // (an odd tile count leaves the last pair's second half idle: it keeps the barriers)
+  if (!tile_ok) lid = 0;
+  int ph = 0, pw = 0;
+  if (p.parity) {
+    ph = (lid >> 1) & 1;
+    pw = lid & 1;
+    lid >>= 2;
+  }
+  const int bx = lid % p.gm, byz = lid / p.gm;
+  const int m0 = tile_ok ? bx * BM : p.M, n0 = (byz % p.gn) * BN;      // idle half: every row out of range
+  const int ks = byz / p.gn;
+  const int cps = (p.nchunks + p.ksplit - 1) / p.ksplit;          // channel chunks per split
+  const int ch0 = ks * cps, ch1 = min(p.nchunks, ch0 + cps);
+  const int oy0 = p.oy0 + ph, ox0 = p.ox0 + pw;
+  const int kh0 = p.parity ? (3 - ph) : p.kh0, kw0 = p.parity ? (3 - pw) : p.kw0;
+  const int ooy0 = p.ooy0 + ph, oox0 = p.oox0 + pw;
+  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
+  constexpr int TWm = NTAPS == 16 ? 3 : 1, lgTW = NTAPS == 16 ? 2 : 1;
+
+  // ---- per-thread operand pieces: (row, octet) fixed for the whole loop
+  unsigned a_byte[A_CH], a_mask[A_CH], w_byte[B_CH];
+  int a_lds[A_CH], b_lds[B_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int id = tid + 256 * i, row = id / OC, oct = id % OC;
+    const int m = m0 + row;
+    const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+    const int iy0 = my * p.sy + oy0, ix0 = mx * p.sx + ox0;
+    a_byte[i] = 2u * (unsigned)(((b * p.Hi + iy0) * p.Wi + ix0) * p.C + 8 * oct);      // (wraps for border rows; masked)
+    unsigned ym = 0, xm = 0;
+#pragma unroll
+    for (int t = 0; t <= TWm; ++t) {
+      if ((unsigned)(iy0 + t) < (unsigned)p.Hi) ym |= 1u << t;
+      if ((unsigned)(ix0 + t) < (unsigned)p.Wi) xm |= 1u << t;
+    }
+    unsigned mk = 0;
+#pragma unroll
+    for (int t = 0; t <= TWm; ++t)
+      if ((ym >> t) & 1u) mk |= xm << (t << lgTW);
+    a_mask[i] = m < p.M ? mk : 0u;
+    a_lds[i] = sw_off(row, oct);
+  }
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int id = tid + 256 * i, row = id / OC, oct = id % OC;
+    const int n = n0 + row;
+    w_byte[i] = n < p.N ? 2u * (unsigned)(n * 16 * p.C + 8 * oct) : VF_OOB;
+    b_lds[i] = AH_SZ + sw_off(row, oct);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = pg_rsrc(p.A, p.a_bytes), rsW = pg_rsrc(p.W, p.w_bytes);
+  // wave-uniform byte offsets of window tap (th, tw): th * row + tw * col (+ the filter tap's base for the weights); th and
+  // tw are compile-time constants at every use, so each offset is two scalar multiply-adds (a table of 2 x 16 offsets held
+  // in SGPRs spilled: 106 SGPRs, 36-68 bytes of scratch per lane)
+  int rowA = 2 * p.Wi * p.C, colA = 2 * p.C;
+  int w0 = 2 * (kh0 * 4 + kw0) * p.C, rowW = 8 * p.khs * p.C, colW = 2 * p.kws * p.C;
+
+  u32x4 ra[A_CH][3], rb[B_CH][3];
+  auto load_step = [&](int ch, auto TAP, bool live) {
+    // step index -> window tap.  The 16 taps of the gather form are walked one input-parity class after the other —
+    // (th, tw) = (g>>1 + 2*(j>>1), g&1 + 2*(j&1)) for step 4g + j: the four taps of a class read the SAME quarter of the
+    // input pixels (each for a different output pixel), so a line is re-read one step after it was fetched instead of
+    // two (x shifts) or eight (y shifts) steps later, by which time the 64 tiles that share an XCD's 4 MB L2 had pushed it
+    // out: TCC hit rate 64 % and 141 MB of fabric reads per launch for a 25 MB operand in row-major tap order
+    constexpr int s_ = decltype(TAP)::value;
+    constexpr int th = NTAPS == 16 ? (((s_ >> 3) & 1) + 2 * ((s_ >> 1) & 1)) : (s_ >> 1);
+    constexpr int tw = NTAPS == 16 ? (((s_ >> 2) & 1) + 2 * (s_ & 1)) : (s_ & 1);
+    constexpr int t = (th << lgTW) | tw;                              // bit of the validity mask
+    const unsigned cb = (unsigned)(2 * CH) * (unsigned)ch;            // CH channels * 2 bytes
+    const unsigned tA = (unsigned)(th * rowA + tw * colA) + cb, tW = (unsigned)(w0 + th * rowW + tw * colW) + cb;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const bool ok = live && ((a_mask[i] >> t) & 1u);
+      const unsigned off = ok ? a_byte[i] + tA : VF_OOB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) ra[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, q * p.a_ps, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned off = live ? w_byte[i] : VF_OOB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) rb[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, q * p.w_ps + tW, 0);
+    }
+  };
+  auto store_step = [&](int buf) {
+    __bf16* base = smem + buf * BUF_SZ;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) *(u32x4*)(base + q * PL_SZ + a_lds[i]) = ra[i][q];
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) *(u32x4*)(base + q * PL_SZ + b_lds[i]) = rb[i][q];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // fragment reads run one 16-deep group AHEAD of the MFMAs that consume them (two fragment sets): left to itself the
+  // compiler issues "reads of group g, wait, six MFMAs of group g, reads of group g+1, wait ..." and every group starts
+  // with the LDS latency exposed
+  auto compute_step = [&](int buf) {
+    const __bf16* base = smem + buf * BUF_SZ;
+    constexpr int G = CH / 16;
+    bf16x8 a[2][3][MT], b[2][3][NT];
+    auto read_frag = [&](int g, int set) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[set][q][mt] = *(const bf16x8*)(base + q * PL_SZ + sw_off(wm + mt * 32 + lr, 2 * g + lh));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[set][q][nt] = *(const bf16x8*)(base + q * PL_SZ + AH_SZ + sw_off(wn + nt * 32 + lr, 2 * g + lh));
+      }
+    };
+    read_frag(0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int cs = g & 1;
+      if (g + 1 < G) read_frag(g + 1, cs ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {      // smallest terms first (the order of vf_conv.hip's mode 3)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1][mt], b[cs][1][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0][mt], b[cs][2][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2][mt], b[cs][0][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0][mt], b[cs][1][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1][mt], b[cs][0][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0][mt], b[cs][0][nt], acc[mt][nt], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- main loop: NTAPS steps per channel chunk, fully unrolled over the taps
+  if (ch0 < ch1) {
+    load_step(ch0, VfIntC<0>{}, true);
+    store_step(0);
+  }
+  __syncthreads();
+  static_assert(NTAPS % 2 == 0, "the two LDS buffers alternate with the tap parity");
+  static_assert(!PAIR || NBUF == 1, "the paired schedule is built on the single-buffered (64-channel) step");
+  if (PAIR && sub == 1) __syncthreads();              // the second half runs one phase behind the first
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const bool more = ch + 1 < ch1;
+    // (the five multipliers pass through an empty asm each iteration: left alone, the compiler hoists all 2 x NTAPS tap
+    //  offsets out of the loop into SGPRs it does not have)
+    asm volatile("" : "+s"(rowA), "+s"(colA), "+s"(w0), "+s"(rowW), "+s"(colW));
+    vf_static_for<NTAPS>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      constexpr int buf = NBUF == 2 ? (t & 1) : 0;
+      if (!(p.dbg & 1)) {
+        if constexpr (t + 1 < NTAPS)
+          load_step(ch, VfIntC<t + 1>{}, true);
+        else
+          load_step(ch + 1, VfIntC<0>{}, more);
+      }
+      if (!(p.dbg & 4)) compute_step(buf);
+      if constexpr (NBUF == 1) __syncthreads();       // everyone has read the tile before it is overwritten
+      if (!(p.dbg & 2)) store_step(NBUF == 2 ? (buf ^ 1) : 0);
+      __syncthreads();
+    });
+  }
+  if (PAIR && sub == 0) __syncthreads();              // (the barrier that pairs with the second half's last one)
+
+  pg_epilogue<MT, NT, BM / WM, BN>(p, acc, (float*)smem, m0, n0, wm, wn, lane, tid, wave / WAVES_N, bx, ks, ooy0, oox0, ph, pw, tile_ok);
+}
+
+// ------------------------------------------------------------------------------------------------ the same GEMM fed by LDS-DMA
+// k_pconv stages its operands global -> registers -> ds_write_b128 -> LDS.  Ablated, that kernel without ANY global load
+// still took 30 of its 36 us on the 4.3 GFLOP layers (10 us of MFMAs at the pipe's rate): 48 KB of ds_write_b128 per block
+// and K step move at ~80 bytes per clock and CU, with a barrier on either side.  Here the tiles go global -> LDS directly
+// (`buffer_load_dwordx4 ... lds`: 1 KB = 8 rows x 128 bytes per wave-instruction, no VGPRs, no ds_write, out-of-range
+// lanes — padding taps — write zeros: scripts/probe/lds_dma_oob.hip), two LDS stages, ONE barrier per K step:
+//     wait for this wave's DMAs of stage s | barrier | issue the DMAs of stage s+1 into the other buffer | MFMAs of stage s
+// BM x BN x 64-channel stages, (BM/32) x (BN/32) waves of one 32x32 MFMA tile each (128x64: 8 waves, 144 KB of LDS, one
+// block per CU, two waves per SIMD).  The LDS image is lane-linear per DMA instruction, so the XOR swizzle of the k-octets
+// sits in the per-lane SOURCE address.  The DMA is issued from inline asm with its own s_waitcnt: to the compiler it is
+// no LDS store, so it puts no vmcnt(0) in front of the fragment reads.
+__device__ __forceinline__ void pg_dma16(unsigned lds_byte, unsigned voffset, __amdgpu_buffer_rsrc_t rsrc, unsigned soffset) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_byte), "v"(voffset), "s"(rsrc), "s"(soffset)
+               : "memory");
+}
+
+template <int BM, int BN, int NTAPS>
+__global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const PGemm p) {
+  constexpr int CH = 64, WAVES_N = BN / 32, WAVES_M = BM / 32, NW = WAVES_M * WAVES_N;
+  constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;                 // 8-row groups (one DMA instruction per plane) per wave
+  static_assert(AG * NW * 8 == BM && BG * NW * 8 == BN, "row groups must divide over the waves");
+  constexpr int AH_SZ = BM * CH, BH_SZ = BN * CH, PL_SZ = AH_SZ + BH_SZ, BUF_SZ = 3 * PL_SZ;      // bf16 elements
+  __shared__ __attribute__((aligned(1024))) __bf16 smem[2 * BUF_SZ];
+  auto sw_off = [](int row, int octet) { return row * 64 + ((octet ^ ((row >> 1) & 7)) << 3); };
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave / WAVES_N) * 32, wn = (wave % WAVES_N) * 32;
+  const int ntiles = p.gm * p.gn * p.gz;
+  int lid = pg_xcd_remap(blockIdx.x, ntiles);
+  int ph = 0, pw = 0;
+  if (p.parity) {
+    ph = (lid >> 1) & 1;
+    pw = lid & 1;
+    lid >>= 2;
+  }
+  const int bx = lid % p.gm, byz = lid / p.gm;
+  const int m0 = bx * BM, n0 = (byz % p.gn) * BN;
+  const int ks = byz / p.gn;
+  const int cps = p.nchunks / p.ksplit;          // channel chunks per split (the host makes it exact)
+  const int ch0 = ks * cps, ch1 = ch0 + cps;
+  const int oy0 = p.oy0 + ph, ox0 = p.ox0 + pw;
+  const int kh0 = p.parity ? (3 - ph) : p.kh0, kw0 = p.parity ? (3 - pw) : p.kw0;
+  const int ooy0 = p.ooy0 + ph, oox0 = p.oox0 + pw;
+  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
+  constexpr int TWm = NTAPS == 16 ? 3 : 1, lgTW = NTAPS == 16 ? 2 : 1;
+
+  // ---- this lane's share of every stage: row (8 * group + lane / 8), LDS slot lane % 8 = global octet slot ^ swizzle(row)
+  unsigned a_byte[AG], a_mask[AG], w_byte[BG];
+  unsigned a_lds[AG], b_lds[BG];          // wave-uniform LDS byte offsets of the groups inside a plane
+#pragma unroll
+  for (int i = 0; i < AG; ++i) {
+    const int grp = wave + NW * i, row = 8 * grp + (lane >> 3);
+    const int oct = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+    const int iy0 = my * p.sy + oy0, ix0 = mx * p.sx + ox0;
+    a_byte[i] = 2u * (unsigned)(((b * p.Hi + iy0) * p.Wi + ix0) * p.C + 8 * oct);
+    unsigned ym = 0, xm = 0;
+#pragma unroll
+    for (int t = 0; t <= TWm; ++t) {
+      if ((unsigned)(iy0 + t) < (unsigned)p.Hi) ym |= 1u << t;
+      if ((unsigned)(ix0 + t) < (unsigned)p.Wi) xm |= 1u << t;
+    }
+    unsigned mk = 0;
+#pragma unroll
+    for (int t = 0; t <= TWm; ++t)
+      if ((ym >> t) & 1u) mk |= xm << (t << lgTW);
+    a_mask[i] = m < p.M ? mk : 0u;
+    a_lds[i] = 2u * (unsigned)(grp * 8 * 64);
+  }
+#pragma unroll
+  for (int i = 0; i < BG; ++i) {
+    const int grp = wave + NW * i, row = 8 * grp + (lane >> 3);
+    const int oct = (lane & 7) ^ ((row >> 1) & 7);
+    const int n = n0 + row;
+    w_byte[i] = n < p.N ? 2u * (unsigned)(n * 16 * p.C + 8 * oct) : VF_OOB;
+    b_lds[i] = 2u * (unsigned)(AH_SZ + grp * 8 * 64);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = pg_rsrc(p.A, p.a_bytes), rsW = pg_rsrc(p.W, p.w_bytes);
+  int rowA = 2 * p.Wi * p.C, colA = 2 * p.C;
+  int w0 = 2 * (kh0 * 4 + kw0) * p.C, rowW = 8 * p.khs * p.C, colW = 2 * p.kws * p.C;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;      // LDS byte address of the buffers
+
+  auto dma_step = [&](int ch, auto TAP, int buf, bool live) {
+    constexpr int s_ = decltype(TAP)::value;
+    constexpr int th = NTAPS == 16 ? (((s_ >> 3) & 1) + 2 * ((s_ >> 1) & 1)) : (s_ >> 1);
+    constexpr int tw = NTAPS == 16 ? (((s_ >> 2) & 1) + 2 * (s_ & 1)) : (s_ & 1);
+    constexpr int t = (th << lgTW) | tw;
+    const unsigned cb = (unsigned)(2 * CH) * (unsigned)ch;
+    const unsigned tA = (unsigned)(th * rowA + tw * colA) + cb, tW = (unsigned)(w0 + th * rowW + tw * colW) + cb;
+    const unsigned base = lds0 + 2u * (unsigned)(buf * BUF_SZ);
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const bool ok = live && ((a_mask[i] >> t) & 1u);
+      const unsigned off = ok ? a_byte[i] + tA : VF_OOB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + a_lds[i], off, rsA, q * p.a_ps);
+    }
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+      const unsigned off = live ? w_byte[i] : VF_OOB;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + b_lds[i], off, rsW, q * p.w_ps + tW);
+    }
+  };
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  const int lr = lane & 31, lh = lane >> 5;
+  auto compute_step = [&](int buf) {
+    const __bf16* base = smem + buf * BUF_SZ;
+    bf16x8 a[2][3], b[2][3];
+    auto read_frag = [&](int g, int set) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[set][q] = *(const bf16x8*)(base + q * PL_SZ + sw_off(wm + lr, 2 * g + lh));
+        b[set][q] = *(const bf16x8*)(base + q * PL_SZ + AH_SZ + sw_off(wn + lr, 2 * g + lh));
+      }
+    };
+    read_frag(0, 0);
+#pragma unroll
+    for (int g = 0; g < CH / 16; ++g) {
+      const int cs = g & 1;
+      if (g + 1 < CH / 16) read_frag(g + 1, cs ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][0], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- main loop
+  dma_step(ch0, VfIntC<0>{}, 0, ch0 < ch1);
+  static_assert(NTAPS % 2 == 0, "the two LDS stages alternate with the tap parity");
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const bool more = ch + 1 < ch1;
+    asm volatile("" : "+s"(rowA), "+s"(colA), "+s"(w0), "+s"(rowW), "+s"(colW));
+    vf_static_for<NTAPS>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      constexpr int buf = t & 1;
+      // this wave's DMAs of the stage about to be read have landed; after the barrier everybody's have, and everybody is
+      // done reading the other buffer, which the next stage's DMAs overwrite
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 1)) {
+        if constexpr (t + 1 < NTAPS)
+          dma_step(ch, VfIntC<t + 1>{}, buf ^ 1, true);
+        else
+          dma_step(ch + 1, VfIntC<0>{}, buf ^ 1, more);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 4)) compute_step(buf);
+    });
+  }
+  // the last stage's prefetch (dead: out-of-range zeros) must have landed before LDS is reused, and nobody may still be
+  // reading fragments when the epilogue's partial sums go there
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  pg_epilogue<1, 1, WAVES_M, BN>(p, acc, (float*)smem, m0, n0, wm, wn, lane, tid, wave / WAVES_N, bx, ks, ooy0, oox0, ph, pw, true);
+}
+
+// ================================================================================================ host
+static inline bool pg_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// shared with vf_conv.hip: the split-K combine (plain and with BatchNorm statistics)
+int vf_internal_slab_reduce(vf_ctx* ctx, const float* slab, float* dst, const float* bias, int64_t total, int N, int ksplit, int act,
+                            float slope, const float* dmask, int dact, float dslope, const VfBnSt* st, int st_groups);
+bool vf_internal_slab_st_ok(int64_t total, int N, int groups, int rows_cap, int* blocks_per_group);
+
+// what the shapes must satisfy for the planes GEMM (callers fall back to vf_conv.hip's kernels otherwise)
+static bool pg_shape_ok(int B, int Hl, int Wl, int C, int N) {
+  return C % 32 == 0 && N >= 32 && N % 4 == 0 && (int64_t)B * Hl * Wl > 64 && vf_is_pow2(Hl) && vf_is_pow2(Wl);
+}
+
+static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
+  const int zpar = g.parity ? 4 : 1;
+  static const int env_ch = getenv("VF_PG_CH") ? atoi(getenv("VF_PG_CH")) : 0;
+  const int ch = (g.C % 64 == 0 && env_ch != 32) ? 64 : 32;      // channels per K step: whole 128-byte lines where possible
+  g.nchunks = g.C / ch;
+  // tile: 128x64 when that still fills the chip twice over, else 64x64; split-K over channel chunks for the small grids
+  struct Tile { int bm, bn; };
+  static const int env_tile = getenv("VF_PG_TILE") ? atoi(getenv("VF_PG_TILE")) : 0;
+  static const int env_dma0 = getenv("VF_PG_DMA") ? atoi(getenv("VF_PG_DMA")) : 1;
+  const Tile cand[2] = {{128, 64}, {64, 64}};
+  int pick = 1;
+  if (env_tile == 128) pick = 0;
+  else if (env_tile == 0 && vf_cdiv(g.M, 128) * vf_cdiv(g.N, 64) * zpar >= 1024) pick = 0;
+  // the LDS-DMA kernel: 64-channel stages, whole tiles (its row decode has no ragged edge), 128x64 tiles of 8 waves by default
+  bool use_dma = env_dma0 && ch == 64 && g.N % 64 == 0;
+  if (use_dma) {
+    if (env_tile == 0) pick = (g.M % 128 == 0) ? 0 : 1;
+    if (g.M % cand[pick].bm != 0) use_dma = false;
+  }
+  const Tile t = cand[pick];
+  const int gm = (int)vf_cdiv(g.M, t.bm), gn = (int)vf_cdiv(g.N, t.bn);
+  const int64_t blocks = (int64_t)gm * gn * zpar;
+  int ksplit = 1;
+  static const int env_split = getenv("VF_PG_SPLIT_BLOCKS") ? atoi(getenv("VF_PG_SPLIT_BLOCKS")) : 512;
+  if (blocks < env_split * 3 / 4 && g.nchunks >= 2) {
+    ksplit = (int)std::min<int64_t>(g.nchunks, vf_cdiv(env_split, blocks));
+    const size_t slab_bytes = (size_t)g.out_elems * sizeof(float);
+    while (ksplit > 1 && (size_t)ksplit * slab_bytes > vf_ws_avail(ctx)) --ksplit;
+    while (ksplit > 1 && g.nchunks % ksplit != 0) --ksplit;      // equal K ranges: every tile runs the same number of steps
+  }
+  g.ksplit = ksplit;
+  g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
+  g.gm = gm; g.gn = gn; g.gz = zpar * ksplit;
+  static const int env_dbg = getenv("VF_PG_DBG") ? atoi(getenv("VF_PG_DBG")) : 0;
+  g.dbg = env_dbg;
+  // ---- BatchNorm statistics attachment (vf_bn_fuse_next_*): same contract as vf_conv.hip's launch_igemm
+  g.st.mode = 0;
+  bool slab_st = false;
+  int st_groups = 1;
+  if (ctx->bnf.mode) {
+    const int groups = ctx->bnf_groups;
+    VfBnSt st = ctx->bnf;
+    bool fused = false;
+    int bpg = 0;
+    if (ksplit == 1) {
+      if (g.M % groups == 0 && (g.M / groups) % t.bm == 0 && (int64_t)(gm / groups) * zpar <= ctx->bnf_rows_cap) {
+        st.tiles_per_group = gm / groups;
+        st.zpar = zpar;
+        st.rows_per_group = (gm / groups) * zpar;
+        g.st = st;
+        fused = true;
+      }
+    } else if (vf_internal_slab_st_ok(g.out_elems, g.N, groups, ctx->bnf_rows_cap, &bpg)) {
+      st.tiles_per_group = bpg;
+      st.zpar = 1;
+      st.rows_per_group = bpg;
+      g.st = st;
+      slab_st = true;
+      st_groups = groups;
+      fused = true;
+    }
+    if (fused) {
+      ctx->bnf_result_rows = st.rows_per_group;
+      if (st.mode == 2) {
+        g.dmask = ctx->bnf_yact;
+        g.dact = ctx->bnf_act;
+        g.dslope = ctx->bnf_slope;
+      }
+    }
+    ctx->bnf.mode = 0;
+  }
+  static const int env_dma = getenv("VF_PG_DMA") ? atoi(getenv("VF_PG_DMA")) : 1;
+  if (use_dma) {
+    const unsigned nt = (unsigned)(gm * gn * zpar * ksplit);
+    char dname[64];
+    snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
+    const double dfl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
+    if (t.bm == 128) {
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16>), dim3(nt), dim3(512), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4>), dim3(nt), dim3(512), g);
+    } else {
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16>), dim3(nt), dim3(256), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4>), dim3(nt), dim3(256), g);
+    }
+    VF_LAUNCH_CHECK();
+    if (ksplit > 1) {
+      VfProf prof(ctx, slab_st ? "slab_reduce_pconv_bnstats" : "slab_reduce_pconv", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+      return vf_internal_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, g.dmask, g.dact, g.dslope,
+                                     slab_st ? &g.st : nullptr, st_groups);
+    }
+    return 0;
+  }
+  static const int env_pair = getenv("VF_PG_PAIR") ? atoi(getenv("VF_PG_PAIR")) : 0;
+  const bool pair = env_pair && ch == 64 && t.bm == 64;
+  const unsigned ntiles = (unsigned)(gm * gn * zpar * ksplit);
+  dim3 grid(pair ? (ntiles + 1) / 2 : ntiles), block(256);
+  char name[64];
+  snprintf(name, sizeof(name), "pconv_%dx%dx%d_%s%s", t.bm, t.bn, ch, ntaps == 16 ? "t16" : "t4", pair ? "_pair" : "");
+  const double fl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
+#define PG_LAUNCH(BM_, BN_, WM_, WN_)                                                                                      \
+  do {                                                                                                                     \
+    if (pair) {                                                                                                            \
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, name, fl, 0.0, (k_pconv<BM_, BN_, WM_, WN_, 16, 64, true>), grid, dim3(512), g); \
+      else VF_LAUNCH_TIMED(ctx, name, fl, 0.0, (k_pconv<BM_, BN_, WM_, WN_, 4, 64, true>), grid, dim3(512), g);              \
+    } else if (ch == 64) {                                                                                                 \
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, name, fl, 0.0, (k_pconv<BM_, BN_, WM_, WN_, 16, 64, false>), grid, block, g);    \
+      else VF_LAUNCH_TIMED(ctx, name, fl, 0.0, (k_pconv<BM_, BN_, WM_, WN_, 4, 64, false>), grid, block, g);                 \
+    } else {                                                                                                               \
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, name, fl, 0.0, (k_pconv<BM_, BN_, WM_, WN_, 16, 32, false>), grid, block, g);    \
+      else VF_LAUNCH_TIMED(ctx, name, fl, 0.0, (k_pconv<BM_, BN_, WM_, WN_, 4, 32, false>), grid, block, g);                 \
+    }                                                                                                                      \
+  } while (0)
+  if (t.bm == 128) PG_LAUNCH(128, 64, 64, 32);
+  else PG_LAUNCH(64, 64, 32, 32);
+#undef PG_LAUNCH
+  VF_LAUNCH_CHECK();
+  if (ksplit > 1) {
+    VfProf prof(ctx, slab_st ? "slab_reduce_pconv_bnstats" : "slab_reduce_pconv", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+    return vf_internal_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, g.dmask, g.dact, g.dslope,
+                                   slab_st ? &g.st : nullptr, st_groups);
+  }
+  return 0;
+}
+
+static int pg_fill_common(PGemm& g, const void* a, int64_t a_elems, const void* w, int64_t w_elems, const float* bias, float* y) {
+  memset(&g, 0, sizeof(g));
+  g.A = a; g.W = w; g.bias = bias; g.Y = y;
+  VF_REQUIRE(a_elems * 6 < ((int64_t)1 << 31) && w_elems * 6 < ((int64_t)1 << 31), "planes exceed the 2 GiB buffer-descriptor range");
+  g.a_ps = (unsigned)(a_elems * 2);
+  g.w_ps = (unsigned)(w_elems * 2);
+  g.a_bytes = 3 * g.a_ps;
+  g.w_bytes = 3 * g.w_ps;
+  return 0;
+}
+
+// conv-like pass: Y[b,oy,ox,n] = sum_{kh,kw,c} A[b, 2oy-1+kh, 2ox-1+kw, c] * Wp[n][kh][kw][c]      (4x4, stride 2, pad 1)
+static int pconv_like_fwd(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* Y, int B, int Hi, int Wi, int C,
+                          int N, int act, float slope) {
+  const int Ho = Hi / 2, Wo = Wi / 2;
+  PGemm g;
+  if (int rc = pg_fill_common(g, ap, (int64_t)B * Hi * Wi * C, wp, (int64_t)N * 16 * C, bias, Y)) return rc;
+  g.lgMh = vf_ilog2(Ho); g.lgMw = vf_ilog2(Wo);
+  g.M = B * Ho * Wo;
+  g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
+  g.sy = 2; g.oy0 = -1; g.sx = 2; g.ox0 = -1;
+  g.lgTW = 2;
+  g.kh0 = 0; g.khs = 1; g.kw0 = 0; g.kws = 1;
+  g.outH = Ho; g.outW = Wo; g.osy = 1; g.osx = 1;
+  g.out_elems = (int64_t)g.M * N;
+  g.act = act; g.slope = slope;
+  return launch_pconv(ctx, g, 16, "fwd");
+}
+// transposed pass: Y[b,oh,ow,n] = sum_{kh,kw,c : oh = 2i-1+kh, ow = 2j-1+kw} A[b,i,j,c] * Wp[n][kh][kw][c]; per output parity
+// (ph, pw) a 2x2-tap GEMM over the low-res grid: window rows i = my + ph - 1 + th, filter row kh = 3 - ph - 2*th
+static int pconv_like_tr(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* Y, int B, int Hi, int Wi, int C, int N,
+                         int act, float slope, const float* dmask = nullptr, int dact = 0, float dslope = 0.f) {
+  PGemm g;
+  if (int rc = pg_fill_common(g, ap, (int64_t)B * Hi * Wi * C, wp, (int64_t)N * 16 * C, bias, Y)) return rc;
+  g.lgMh = vf_ilog2(Hi); g.lgMw = vf_ilog2(Wi);
+  g.M = B * Hi * Wi;
+  g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
+  g.sy = 1; g.oy0 = -1; g.sx = 1; g.ox0 = -1;      // (+ph, +pw in the kernel)
+  g.lgTW = 1;
+  g.khs = -2; g.kws = -2;                          // kh0 = 3 - ph, kw0 = 3 - pw in the kernel
+  g.parity = 1;
+  g.outH = 2 * Hi; g.outW = 2 * Wi; g.osy = 2; g.osx = 2;
+  g.out_elems = (int64_t)B * g.outH * g.outW * N;
+  g.act = act; g.slope = slope;
+  g.dmask = dmask; g.dact = dact; g.dslope = dslope;
+  return launch_pconv(ctx, g, 4, "tr");
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+VF_API int vf_planes_split(vf_ctx* ctx, const float* x, void* planes, int64_t n) {
+  VF_REQUIRE(n % 4 == 0 && pg_aligned16(x) && ((uintptr_t)planes & 7) == 0, "vf_planes_split: n %% 4 == 0 and aligned buffers");
+  const int64_t n4 = n / 4;
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(vf_cdiv(n4, 256 * 2), 4096));
+  VfProf prof(ctx, "planes_split", 0.0, 10.0 * (double)n);
+  hipLaunchKernelGGL(k_planes_split, dim3(nb), dim3(256), 0, ctx->stream, x, (__bf16*)planes, n4, n);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+VF_API int vf_weight_planes(vf_ctx* ctx, const float* w, void* planes_native, void* planes_transposed, int d0, int d1) {
+  VF_REQUIRE(w && planes_native && d0 > 0 && d1 > 0, "vf_weight_planes: bad arguments");
+  VfProf prof(ctx, "weight_planes", 0.0, (planes_transposed ? 16.0 : 10.0) * (double)d0 * 16 * d1);
+  hipLaunchKernelGGL(k_weight_planes, dim3((unsigned)vf_cdiv(d0, 32), 16, (unsigned)vf_cdiv(d1, 32)), dim3(256), 0, ctx->stream, w,
+                     (__bf16*)planes_native, (__bf16*)planes_transposed, d0, d1, (int64_t)d0 * 16 * d1);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+VF_API int vf_weight_planes_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks) {
+  VF_REQUIRE(desc_dev != nullptr && n > 0 && blocks > 0, "vf_weight_planes_multi: empty table");
+  VfProf prof(ctx, "weight_planes_multi", 0.0, 0.0);
+  hipLaunchKernelGGL(k_weight_planes_multi, dim3(blocks), dim3(256), 0, ctx->stream, (const VfWpDesc*)desc_dev, n);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+VF_API int vf_pconv_supported(int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int transposed) {
+  if (k != 4 || stride != 2 || pad != 1) return 0;
+  // conv-like passes gather on the H x W grid with channels Cin and produce Cout; transposed ones walk the low-res grid
+  return pg_shape_ok(B, transposed ? H : H / 2, transposed ? W : W / 2, Cin, Cout) && H >= 2 && W >= 2 ? 1 : 0;
+}
+/* conv forward / full-conv data-gradient: gather planes `ap` [B][H][W][Cin], weight planes `wp` [Cout][16][Cin] */
+VF_API int vf_pconv_gather(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                           int Cout, int act, float slope) {
+  VF_REQUIRE(vf_pconv_supported(B, H, W, Cin, Cout, 4, 2, 1, 0), "vf_pconv_gather: unsupported shape B=%d %dx%d %d->%d", B, H, W, Cin, Cout);
+  return pconv_like_fwd(ctx, ap, wp, bias, y, B, H, W, Cin, Cout, act, slope);
+}
+/* conv data-gradient / full-conv forward: low-res planes `ap` [B][H][W][Cin] -> y [B][2H][2W][Cout], weight planes [Cout][16][Cin] */
+VF_API int vf_pconv_scatter(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
+                            int Cout, int act, float slope, const float* dmask, int dact, float dslope) {
+  VF_REQUIRE(vf_pconv_supported(B, H, W, Cin, Cout, 4, 2, 1, 1), "vf_pconv_scatter: unsupported shape B=%d %dx%d %d->%d", B, H, W, Cin, Cout);
+  VF_REQUIRE(!(dmask && bias), "vf_pconv_scatter: the activation-backward epilogue is for data-gradient passes (no bias)");
+  return pconv_like_tr(ctx, ap, wp, bias, y, B, H, W, Cin, Cout, act, slope, dmask, dact, dslope);
+}

@@ -136,22 +136,80 @@ class SpatialConvolution(Module):
             return ((H - 1) * self.dH - 2 * self.padH + self.kH, (W - 1) * self.dW - 2 * self.padW + self.kW)
         return ((H + 2 * self.padH - self.kH) // self.dH + 1, (W + 2 * self.padW - self.kW) // self.dW + 1)
 
-    def updateOutput(self, input, act="none", slope=0.0):
+    # -- operands pre-split into bf16 planes (backend.pconv_*, csrc/vf_pgemm.hip): used in the default product mode wherever
+    #    the shape allows; `in_planes` / `g_planes` are the planes of the activation operand when its producer (a BatchNorm)
+    #    already wrote them, else the tensor is split here (one pass) — weights come from weight_planes()
+    def _pconv_ok(self, Bn, Hgrid, Wgrid, Cgather, Cout, transposed):
+        """The planes kernels pay where the GEMM has many rows per weight element: the weight planes cost a pass over the
+        weights per parameter update (16 bytes per element moved), which a pass with few rows (small batches on the deep,
+        wide layers: train_wholeim_input.lua at batchSize 4) never earns back.  Threshold: 1024 GEMM rows."""
+        B = get_backend()
+        rows = Bn * Hgrid * Wgrid // (1 if transposed else 4)
+        return (not _NO_PCONV and getattr(B, "mfma_mode", None) == "f32_3xbf16" and hasattr(B, "pconv_supported")
+                and self.kH == 4 and self.dH == 2 and self.padH == 1 and rows >= _PCONV_MIN_ROWS
+                and B.pconv_supported(Bn, Hgrid, Wgrid, Cgather, Cout, 4, 2, 1, transposed))
+
+    def pconv_layer(self):
+        """could any pass of this layer use the planes kernels (4x4 stride 2, wide enough)?"""
+        return (self.kH == 4 and self.dH == 2 and self.padH == 1 and min(self.nInputPlane, self.nOutputPlane) >= 32
+                and self.nInputPlane % 4 == 0 and self.nOutputPlane % 4 == 0)
+
+    def weight_planes(self, transposed, refresh=False):
+        """(native, transposed) bf16 planes of the weight; Sequential.refresh_weight_planes() keeps them current in one
+        launch per net — a module used on its own refreshes them on every call"""
+        B = get_backend()
+        if getattr(self, "_wp", None) is None or self._wp_src != self.weight.data_ptr() or not getattr(self, "_wp_live", False):
+            # first use (or the weight moved, e.g. getParameters): split now; from here on the net's one-launch refresh
+            # (Sequential.refresh_weight_planes) keeps this layer's planes current
+            self._wp = B.weight_planes(self.weight, *(self._wp if getattr(self, "_wp", None) is not None and self._wp[0].shape[1] == self.weight.numel() else (None, None)))
+            self._wp_src = self.weight.data_ptr()
+            self._wp_live = True
+        elif refresh:
+            B.weight_planes(self.weight, *self._wp)
+        return self._wp[1 if transposed else 0]
+
+    def _planes_buf(self, name, numel):
+        t = getattr(self, name, None)
+        if t is None or t.shape[1] != numel:
+            t = torch.empty((3, numel), dtype=torch.bfloat16, device=self.weight.device)
+            setattr(self, name, t)
+        return t
+
+    def updateOutput(self, input, act="none", slope=0.0, in_planes=None, managed=False):
         input = to_nhwc(input)
         Bn, Cin, H, W = input.shape
         assert Cin == self.nInputPlane, "expected %d input planes, got %d" % (self.nInputPlane, Cin)
         Ho, Wo = self.out_hw(H, W)
         y = self._buf("output", Bn, self.nOutputPlane, Ho, Wo)
-        fn = get_backend().deconv2d_fwd if self._is_full else get_backend().conv2d_fwd
+        B = get_backend()
+        if act in ("none", "lrelu", "relu") and self._pconv_ok(Bn, H, W, Cin, self.nOutputPlane, self._is_full):
+            xp = in_planes if in_planes is not None else B.planes_split(input, self._planes_buf("_xp", input.numel()))
+            wp = self.weight_planes(self._is_full, refresh=not managed)
+            fn = B.pconv_scatter if self._is_full else B.pconv_gather
+            fn(xp, wp, self.bias, y, Bn, H, W, Cin, self.nOutputPlane, act, slope)
+            return y
+        fn = B.deconv2d_fwd if self._is_full else B.conv2d_fwd
         fn(input, self.weight, self.bias, y, self.kH, self.dH, self.padH, act, slope)
         return y
 
-    def updateGradInput(self, input, gradOutput, in_act=None, buf="gradInput"):
+    def updateGradInput(self, input, gradOutput, in_act=None, buf="gradInput", g_planes=None, managed=False):
         """in_act = (act, slope): `input` is the in-place activated output of the previous module; its
         updateGradInput (gx .* act'(input)) is applied in this pass's epilogue instead of in a pass of its own.
         buf: the attribute that holds the result (a pass over part of the batch keeps its own buffer)."""
         gx = self._buf(buf, *input.shape)
         B = get_backend()
+        go = to_nhwc(gradOutput)
+        Bn, Co, Ho, Wo = go.shape
+        if self._pconv_ok(Bn, Ho, Wo, Co, self.nInputPlane, not self._is_full) and (in_act is None or not self._is_full):
+            gp = g_planes if g_planes is not None else B.planes_split(go, self._planes_buf("_gp" + buf, go.numel()))
+            wp = self.weight_planes(not self._is_full, refresh=not managed)
+            if self._is_full:      # full-conv data-gradient: an ordinary strided conv of gradOutput
+                B.pconv_gather(gp, wp, None, gx, Bn, Ho, Wo, Co, self.nInputPlane)
+            elif in_act is not None:
+                B.pconv_scatter(gp, wp, None, gx, Bn, Ho, Wo, Co, self.nInputPlane, dmask=input, dact=in_act[0], dslope=in_act[1])
+            else:
+                B.pconv_scatter(gp, wp, None, gx, Bn, Ho, Wo, Co, self.nInputPlane)
+            return gx
         if in_act is not None:
             B.conv2d_bwd_data_act(to_nhwc(gradOutput), self.weight, gx, input, in_act[0], in_act[1], self.kH, self.dH, self.padH)
             return gx
@@ -233,17 +291,26 @@ class SpatialBatchNormalization(Module):
             return self._gmean, self._gstd, self._gsums
         return self.save_mean, self.save_std, self._sums
 
-    def updateOutput(self, input, act="none", slope=0.0, pre_rows=0):
+    def updateOutput(self, input, act="none", slope=0.0, pre_rows=0, want_planes=False):
+        """want_planes (with pre_rows): also write the three bf16 planes of the output (self.output_planes) for a planes-fed
+        convolution behind this module"""
         B = get_backend()
         input = to_nhwc(input)
         Bn, Cc, H, W = input.shape
         assert Cc == self.nOutputPlane
         y = self._buf("output", Bn, Cc, H, W)
+        self.output_planes = None
         if pre_rows > 0:
             assert self.fusable() and Bn % self.groups == 0
             sm, ss, su = self._stat_bufs()
+            yp = None
+            if want_planes:
+                yp = getattr(self, "_yp", None)
+                if yp is None or yp.shape[1] != y.numel():
+                    yp = self._yp = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=y.device)
             B.bn_train_fwd_pre(self._part, pre_rows, input, y, self.weight, self.bias, self.running_mean, self.running_var, sm, ss,
-                               su, self.groups, self.momentum, self.eps, act, slope)
+                               su, self.groups, self.momentum, self.eps, act, slope, yp)
+            self.output_planes = yp
             return y
         if self.train and self.groups > 1:
             assert self.sync_world == 1 and Bn % self.groups == 0
@@ -290,7 +357,7 @@ class SpatialBatchNormalization(Module):
         return self._gsave
 
     def _bwd(self, input, gradOutput, want_gx, want_gp, act="none", slope=0.0, y_act=None, group=None, buf="gradInput",
-             pre_rows=0):
+             pre_rows=0, want_planes=False):
         """group = g: `input` / `gradOutput` / `y_act` hold group g's samples only (a pass over one of the concatenated
         batches); group = None with groups > 1: all groups, one after the other.
         pre_rows > 0: gradOutput arrives ALREADY MASKED by the activation's derivative and its sums sit in the partial
@@ -304,11 +371,22 @@ class SpatialBatchNormalization(Module):
         if want_gp:
             pbeta = 0.0 if self._fresh else 1.0
             self._fresh = False
+        self.grad_planes = None
         if pre_rows > 0:
-            assert group is None and self.fusable()
-            sm, ss, su = self._stat_bufs()
+            assert self.fusable()
+            if group is not None:       # a pass over ONE of the concatenated batches: that group's saved statistics
+                (sm, ss, su), G = self._group_state()[group], 1
+            else:
+                (sm, ss, su), G = self._stat_bufs(), self.groups
+            gp = None
+            if want_planes and gx is not None:
+                gp = getattr(self, "_gp_" + buf, None)
+                if gp is None or gp.shape[1] != gx.numel():
+                    gp = torch.empty((3, gx.numel()), dtype=torch.bfloat16, device=gx.device)
+                    setattr(self, "_gp_" + buf, gp)
             B.bn_bwd_pre(self._part, pre_rows, input, gradOutput, gx, self.gradWeight if want_gp else None,
-                         self.gradBias if want_gp else None, self.weight, sm, ss, su, self.groups, pbeta)
+                         self.gradBias if want_gp else None, self.weight, sm, ss, su, G, pbeta, gp)
+            self.grad_planes = gp
             return gx
         if self.groups > 1:
             assert self.sync_world == 1
@@ -570,6 +648,8 @@ _NO_DEFER_BIAS = bool(__import__("os").environ.get("VF_NO_DEFER_BIAS"))      # A
 _NO_WG_GROUP = bool(__import__("os").environ.get("VF_NO_WG_GROUP"))
 _NO_BN_GROUPS = bool(__import__("os").environ.get("VF_NO_BN_GROUPS"))
 _NO_BN_FUSE = bool(__import__("os").environ.get("VF_NO_BN_FUSE"))       # BatchNorm statistics from the neighbouring GEMMs
+_NO_PCONV = bool(__import__("os").environ.get("VF_NO_PCONV"))           # convolutions from pre-split bf16 planes
+_PCONV_MIN_ROWS = int(__import__("os").environ.get("VF_PCONV_MIN_ROWS", "1024"))
 
 
 class Sequential(Module):
@@ -590,6 +670,8 @@ class Sequential(Module):
         self.side = None      # optional side backend (backend.fork()): weight gradients overlap the data-grad chain
         self._act_done_at = -1
         self._bn_pre_at = None
+        self._wp_managed = False  # True: the owner (a trainer) calls refresh_weight_planes() after every parameter update
+        self._wp_plan = None
 
     def add(self, m):
         self.modules.append(m)
@@ -645,6 +727,11 @@ class Sequential(Module):
         B = get_backend()
         fuse_bn = self.fuse and hasattr(B, "bn_fuse_next_fwd")
         pre_rows = 0
+        cur_pl = None             # bf16 planes of `cur`, when its producer wrote them
+        managed = self._wp_managed
+        if not managed:
+            self.refresh_weight_planes()
+            managed = True
         for idx, (m, a) in enumerate(plan):
             if before is not None and idx == before[0]:
                 before[1]()
@@ -654,17 +741,31 @@ class Sequential(Module):
                 # the BatchNorm behind this convolution gets its statistics from the convolution's own epilogue
                 Ho, Wo = m.out_hw(cur.shape[2], cur.shape[3])
                 B.bn_fuse_next_fwd(nxt.running_mean, nxt.part_buffer(cur.shape[0] * Ho * Wo), nxt.groups)
-                cur = m.updateOutput(cur)
+                cur = m.updateOutput(cur, in_planes=cur_pl, managed=managed)
+                cur_pl = None
                 pre_rows = B.bn_fuse_result()
                 continue
             if isinstance(m, SpatialBatchNormalization):
                 rows, pre_rows = pre_rows, 0
-                cur = m.updateOutput(cur, *((a.act, a.slope) if a is not None else ("none", 0.0)), pre_rows=rows)
+                want_pl = (self.fuse and rows > 0 and isinstance(nxt, SpatialConvolution) and nxt.pconv_layer()
+                           and (a is None or a.act in ("lrelu", "relu")) and not _NO_PCONV)
+                cur = m.updateOutput(cur, *((a.act, a.slope) if a is not None else ("none", 0.0)), pre_rows=rows, want_planes=want_pl)
+                cur_pl = m.output_planes
+                if a is not None:
+                    a.output = cur
+                    if Sequential.act_hook is not None and a.act in ("lrelu", "relu"):
+                        Sequential.act_hook(a, cur)
+                        cur_pl = None        # (a test hook may have edited the tensor)
+                continue
+            if isinstance(m, SpatialConvolution):
+                cur = m.updateOutput(cur, *((a.act, a.slope) if a is not None else ("none", 0.0)), in_planes=cur_pl, managed=managed)
+                cur_pl = None
                 if a is not None:
                     a.output = cur
                     if Sequential.act_hook is not None and a.act in ("lrelu", "relu"):
                         Sequential.act_hook(a, cur)
                 continue
+            cur_pl = None
             if a is None:
                 cur = m.updateOutput(cur)
                 if Sequential.act_hook is not None and isinstance(m, _Act) and m.act in ("lrelu", "relu"):
@@ -696,6 +797,11 @@ class Sequential(Module):
         hi = len(plan) if hi is None else hi
         act_done = self._act_done_at == hi if hi < len(plan) else False
         bn_pre, pre = 0, [0]      # partial rows the data-gradient pass above left for the BatchNorm about to be walked
+        g_pl = None               # bf16 planes of `g`, when its producer (a BatchNorm backward) wrote them
+        managed = self._wp_managed
+        if not managed:
+            self.refresh_weight_planes()
+            managed = True
         if hi < len(plan) and self._bn_pre_at is not None and self._bn_pre_at[0] == hi:
             bn_pre = self._bn_pre_at[1]      # a walk cut between a convolution and the BatchNorm below it resumes here
         self._bn_pre_at = None
@@ -716,16 +822,23 @@ class Sequential(Module):
                 if isinstance(m, ParallelTable):
                     assert group is None, "group passes are built for plain chains"
                     g = m.walk(x, g, want_gx, want_gp)
+                    g_pl = None
                     act_done = False
                     continue
                 if isinstance(m, SpatialBatchNormalization):
                     gsel = None if group is None else group[0]
                     rows, bn_pre = bn_pre, 0
+                    # the convolution below consumes this gradient in its data-gradient pass: write its planes here
+                    below = plan[idx - 1][0] if idx > 0 else None
+                    want_pl = (self.fuse and rows > 0 and want_gx and isinstance(below, SpatialConvolution) and below.pconv_layer()
+                               and (idx - 1 > 0 or need_input_grad) and not _NO_PCONV)
                     if a is None:
-                        g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf, pre_rows=rows)
+                        g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf, pre_rows=rows, want_planes=want_pl)
                     else:
                         a.gradInput = g
-                        g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, mout, group=gsel, buf=gbuf, pre_rows=rows)
+                        g = m._bwd(x, g, want_gx, want_gp, a.act, a.slope, mout, group=gsel, buf=gbuf, pre_rows=rows,
+                                   want_planes=want_pl)
+                    g_pl = m.grad_planes
                 else:
                     if a is not None:
                         if not act_done:
@@ -749,25 +862,31 @@ class Sequential(Module):
                     # the module below is a BatchNorm (+ activation): this module's data-gradient pass also sums what that
                     # BatchNorm's backward needs, and stores its output masked by the activation's derivative
                     fuse_below = None
-                    if (self.fuse and want_gx and idx > 1 and group is None and isinstance(m, SpatialConvolution)
-                            and hasattr(B, "bn_fuse_next_bwd")):
+                    if (self.fuse and want_gx and idx > 1 and isinstance(m, SpatialConvolution) and hasattr(B, "bn_fuse_next_bwd")):
                         pm, pa = plan[idx - 1]
                         if (isinstance(pm, SpatialBatchNormalization) and pm.fusable() and (pa is None or pa.act in ("lrelu", "relu"))
-                                and pm.nOutputPlane == m.nInputPlane):
+                                and pm.nOutputPlane == m.nInputPlane and (group is None or pm.groups == group[1])):
                             fuse_below = (pm, pa)
                     if fuse_below is not None:
-                        def upd(m=m, x=x, g=g, fb=fuse_below, idx=idx):
+                        def upd(m=m, x=x, g=g, fb=fuse_below, idx=idx, gpl=g_pl):
                             pm, pa = fb
                             xbn = plan[idx - 2][0].output            # the BatchNorm's input: the convolution below it
-                            sm, _, _ = pm._stat_bufs()
-                            B.bn_fuse_next_bwd(xbn, pm.output if pa is not None else None, pa.act if pa is not None else "none",
-                                               pa.slope if pa is not None else 0.0, sm, pm.part_buffer(xbn.shape[0] * xbn.shape[2] * xbn.shape[3]),
-                                               pm.groups)
-                            out = m.updateGradInput(x, g, None, gbuf)
+                            yact = pm.output if pa is not None else None
+                            if group is not None:                    # one of the concatenated batches: its rows, its statistics
+                                gi, G = group
+                                hb = xbn.shape[0] // G
+                                xbn = xbn[gi * hb:(gi + 1) * hb]
+                                yact = None if yact is None else yact[gi * hb:(gi + 1) * hb]
+                                sm, ng = pm._group_state()[gi][0], 1
+                            else:
+                                sm, ng = pm._stat_bufs()[0], pm.groups
+                            B.bn_fuse_next_bwd(xbn, yact, pa.act if pa is not None else "none", pa.slope if pa is not None else 0.0,
+                                               sm, pm.part_buffer(xbn.shape[0] * xbn.shape[2] * xbn.shape[3]), ng)
+                            out = m.updateGradInput(x, g, None, gbuf, g_planes=gpl, managed=managed)
                             pre[0] = B.bn_fuse_result()
                             return out
                     elif isinstance(m, SpatialConvolution):
-                        upd = lambda: m.updateGradInput(x, g, in_act, gbuf)
+                        upd = lambda: m.updateGradInput(x, g, in_act, gbuf, g_planes=g_pl, managed=managed)
                     elif group is not None and isinstance(m, _Act):
                         upd = lambda: m.updateGradInput(x, g, mout)
                     else:
@@ -783,6 +902,7 @@ class Sequential(Module):
                         if want_gp:
                             self._acc(m, x, g, deferred)
                     g = gin
+                    g_pl = None
                     act_done = in_act is not None
                     bn_pre, pre[0] = pre[0], 0
                     continue
@@ -813,6 +933,27 @@ class Sequential(Module):
             m.accGradParameters(x, g, 1, deferred)
         else:
             m.accGradParameters(x, g, 1)
+
+    def refresh_weight_planes(self):
+        """The bf16 planes (native + transposed) of every convolution weight the planes kernels can use, in ONE launch.
+        A trainer calls this after each optim.adam (set_weight_planes_managed); on its own a Sequential refreshes at the
+        start of every forward and backward call, so edits of the weights by any means are always seen."""
+        B = get_backend()
+        if _NO_PCONV or getattr(B, "mfma_mode", None) != "f32_3xbf16" or not hasattr(B, "weight_planes_multi"):
+            return
+        # the layers that have taken the planes path at least once (SpatialConvolution.weight_planes marks them)
+        mods = [m for m in self.leaves() if isinstance(m, SpatialConvolution) and getattr(m, "_wp_live", False)
+                and m._wp_src == m.weight.data_ptr()]
+        if not mods:
+            return
+        key = tuple(m.weight.data_ptr() for m in mods)
+        if self._wp_plan is None or self._wp_plan[3] != key:
+            self._wp_plan = B.weight_planes_multi([(m.weight, m._wp[0], m._wp[1]) for m in mods])
+        B.weight_planes_run(self._wp_plan)
+
+    def set_weight_planes_managed(self, on=True):
+        self._wp_managed = bool(on)
+        return self
 
     def bucket_split(self, frac=0.9):
         """(plan index k, flat offset): the shortest tail plan[k:] of the backward order's head that owns at least

@@ -170,6 +170,10 @@ class _TrainerBase:
                 for m in net.leaves():
                     if isinstance(m, nn.SpatialBatchNormalization):
                         m.sync_world, m.sync_group = world, group
+        # weight planes of the planes-fed convolutions (nn.Sequential.refresh_weight_planes): refreshed by the closures,
+        # once per net and parameter update, instead of on every forward / backward call
+        self.netG.set_weight_planes_managed(True)
+        self.netD.set_weight_planes_managed(True)
         self.errD = self.errG = self.errG_l2 = self.errG_gdl = None
         self._graph = None
         self._graphs = None
@@ -306,6 +310,9 @@ class _TrainerBase:
             self.side_a = get_backend().fork(workspace_bytes=1 << 20)
         self._g_big = ([(o, o + n) for _, o, n in big], min(idxs))
         self.adam_overlap = True
+        # the split update finishes on a side stream in mid-forward: let netG refresh its own weight planes at the start of
+        # each call instead (the two side-stream tensors are the bottleneck weights, which no planes kernel reads)
+        self.netG.set_weight_planes_managed(False)
         return self
 
     def _pending_then_forward(self, fwd):
@@ -323,6 +330,7 @@ class _TrainerBase:
         if self._pending_g:
             optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
             self._pending_g = False
+            self.netG.refresh_weight_planes()
 
     def _apply_pending_g_and_sweep(self):
         if self._pending_g:
@@ -563,6 +571,9 @@ class CenterTrainer(_TrainerBase):
         if not self._pending_g:
             self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
+        self.netD.refresh_weight_planes()          # netD: updated by the previous iteration's optim.adam(fDx) (and used by fGx since)
+        if not self._pending_g:
+            self.netG.refresh_weight_planes()      # netG: updated by the previous iteration's optim.adam(fGx)
         # netG's forward does not depend on netD's real pass: issue it on a side stream (same arithmetic)
         fake = None
         if early_g:
@@ -608,6 +619,7 @@ class CenterTrainer(_TrainerBase):
         self.netD.zeroConvBiases()
         self.netG.zeroConvBiases()
         self.netG.zeroGradParameters()
+        self.netD.refresh_weight_planes()            # optim.adam(fDx) has just moved netD's weights
         label = self.real_label                      # fake labels are real for the generator cost
         output = self._netD_stale_output()           # reused from fDx (train.lua:363): stale w.r.t. D's Adam step
         self.errG = self.criterion.forward(output, label)
@@ -701,6 +713,9 @@ class VidTrainer(_TrainerBase):
         if not self._pending_g:
             self.netG.zeroConvBiases()
         self.netD.zeroGradParameters()
+        self.netD.refresh_weight_planes()          # netD: updated by the previous iteration's optim.adam(fDx) (and used by fGx since)
+        if not self._pending_g:
+            self.netG.refresh_weight_planes()      # netG: updated by the previous iteration's optim.adam(fGx)
         self._fill_from_initializer()
         fake = None
         if early_g:                            # netG forward beside netD's real pass (independent work)
@@ -751,6 +766,7 @@ class VidTrainer(_TrainerBase):
         self.netD.zeroConvBiases()
         self.netG.zeroConvBiases()
         self.netG.zeroGradParameters()
+        self.netD.refresh_weight_planes()            # optim.adam(fDx) has just moved netD's weights
         label = self.real_label
         output = self._netD_stale_output()
         self.errG = self.criterion.forward(output, label)
