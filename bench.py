@@ -245,7 +245,7 @@ def main():
         # is one kernel source; which of its symbols a layer lands on is a tiling decision), then that template's
         # largest symbol — a single symbol, so that avg_launch_us can be checked against rocprofv3's per-symbol csv
         def family(n):
-            for f in ("igemm", "wgrad", "slab_reduce", "bn", "bias_grad"):
+            for f in ("pconv", "igemm", "wgrad", "slab_reduce", "bn", "bias_grad"):
                 if n.startswith(f):
                     return f
             return n

@@ -112,6 +112,9 @@ int vf_deconv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* 
  *                      planes of the full-conv weight [Cout_full][16][Cin_full], bias, act); output is 2H x 2W
  * Both honour a pending vf_bn_fuse_next_* attachment like the entry points above. */
 int vf_planes_split(vf_ctx* ctx, const float* x, void* planes, int64_t n);
+/* vf_conv2d_fwd that also leaves the planes of y (in its epilogue for the 3-channel image-side layers, train.lua:89,183) */
+int vf_conv2d_fwd_planes(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, void* y_planes, int B,
+                         int H, int W, int Cin, int Cout, int k, int stride, int pad, int act, float slope);
 int vf_weight_planes(vf_ctx* ctx, const float* w, void* planes_native, void* planes_transposed, int d0, int d1);
 /* the same for n weights in one launch: desc_dev = device array of n records {const float* w; void* native; void* transposed;
  * int d0, d1, gx = ceil(d0/32), gz = ceil(d1/32), blk_off (first block of the record: running sum of gx*16*gz), pad;} (48 bytes
@@ -178,6 +181,14 @@ int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, const floa
  * The _pre calls are vf_bn_train_fwd_groups / vf_bn_bwd_groups without their statistics pass (g_masked: no activation);
  * y_planes / gx_planes (may be NULL): the three bf16 planes of the output, [3][groups * npix_per_group * C], written beside
  * it for a vf_pconv_* consumer. */
+int vf_bn_train_fwd_planes(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
+                           int64_t npix_per_group, int C, int groups, float momentum, float eps, int act, float slope,
+                           void* y_planes);      /* vf_bn_train_fwd_groups + the planes of y */
+int vf_bn_bwd_planes(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                     float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
+                     int64_t npix_per_group, int C, int groups, int act, float slope, float pbeta,
+                     void* gx_planes);           /* vf_bn_bwd_groups + the planes of gx */
 int vf_bn_fuse_next_fwd(vf_ctx* ctx, const float* shift, double* part, int part_rows_cap, int groups);
 int vf_bn_fuse_next_bwd(vf_ctx* ctx, const float* x, const float* y_act, int act, float slope, const float* save_mean,
                         double* part, int part_rows_cap, int groups);

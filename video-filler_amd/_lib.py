@@ -38,6 +38,7 @@ SIGNATURES = {
     "vf_deconv2d_bwd_data": (i32, [vp, vp, vp, vp] + [i32] * 8),
     "vf_deconv2d_bwd_weight": (i32, [vp, vp, vp, vp, vp] + [i32] * 8 + [f32]),
     "vf_planes_split": (i32, [vp, vp, vp, i64]),
+    "vf_conv2d_fwd_planes": (i32, [vp, vp, vp, vp, vp, vp] + [i32] * 8 + [i32, f32]),
     "vf_weight_planes": (i32, [vp, vp, vp, vp, i32, i32]),
     "vf_weight_planes_multi": (i32, [vp, vp, i32, i32]),
     "vf_pconv_supported": (i32, [i32] * 9),
@@ -53,6 +54,8 @@ SIGNATURES = {
     "vf_bn_bwd": (i32, [vp] * 11 + [i64, i32, i32, f32, f32]),
     "vf_bn_train_fwd_groups": (i32, [vp] * 10 + [i64, i32, i32, f32, f32, i32, f32]),
     "vf_bn_bwd_groups": (i32, [vp] * 11 + [i64, i32, i32, i32, f32, f32]),
+    "vf_bn_train_fwd_planes": (i32, [vp] * 10 + [i64, i32, i32, f32, f32, i32, f32, vp]),
+    "vf_bn_bwd_planes": (i32, [vp] * 11 + [i64, i32, i32, i32, f32, f32, vp]),
     "vf_bn_fuse_next_fwd": (i32, [vp, vp, vp, i32, i32]),
     "vf_bn_fuse_next_bwd": (i32, [vp, vp, vp, i32, f32, vp, vp, i32, i32]),
     "vf_bn_fuse_result": (i32, [vp, C.POINTER(i32)]),

@@ -145,6 +145,11 @@ class HipBackend:
         self._c("vf_conv2d_fwd", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W, Cin, w.shape[0], k, stride, pad,
                 ACT[act], slope)
 
+    def conv2d_fwd_planes(self, x, w, bias, y, y_planes, k, stride, pad, act="none", slope=0.0):
+        B, Cin, H, W = x.shape
+        self._c("vf_conv2d_fwd_planes", _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(y_planes), B, H, W, Cin, w.shape[0], k, stride,
+                pad, ACT[act], slope)
+
     def conv2d_bwd_data(self, gy, w, gx, k, stride, pad):
         B, Cin, H, W = gx.shape
         self._c("vf_conv2d_bwd_data", _ptr(gy), _ptr(w), _ptr(gx), B, H, W, Cin, w.shape[0], k, stride, pad)
@@ -283,17 +288,26 @@ class HipBackend:
                 _ptr(save_invstd), _ptr(sums), B * H * W, Cc, momentum, eps, ACT[act], slope)
 
     def bn_train_fwd_groups(self, x, y, gamma, beta, rm, rv, save_mean, save_invstd, sums, groups, momentum, eps,
-                            act="none", slope=0.0):
+                            act="none", slope=0.0, y_planes=None):
         """x = `groups` concatenated batches; save_mean / save_invstd [groups][C], sums [groups][2C] (vf_hip.h)."""
         B, Cc, H, W = x.shape
         assert B % groups == 0 and save_mean.numel() == groups * Cc and sums.numel() == groups * 2 * Cc
+        if y_planes is not None:
+            self._c("vf_bn_train_fwd_planes", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(save_mean),
+                    _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, momentum, eps, ACT[act], slope, _ptr(y_planes))
+            return
         self._c("vf_bn_train_fwd_groups", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(save_mean),
                 _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, momentum, eps, ACT[act], slope)
 
     def bn_bwd_groups(self, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, groups, act="none",
-                      slope=0.0, pbeta=1.0):
+                      slope=0.0, pbeta=1.0, gx_planes=None):
         B, Cc, H, W = x.shape
         assert B % groups == 0 and save_mean.numel() == groups * Cc and sums.numel() == groups * 2 * Cc
+        if gx_planes is not None:
+            self._c("vf_bn_bwd_planes", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
+                    _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, ACT[act], slope, pbeta,
+                    _ptr(gx_planes))
+            return
         self._c("vf_bn_bwd_groups", _ptr(x), _ptr(y_act), _ptr(gy), _ptr(gx), _ptr(ggamma), _ptr(gbeta), _ptr(gamma),
                 _ptr(save_mean), _ptr(save_invstd), _ptr(sums), (B // groups) * H * W, Cc, groups, ACT[act], slope, pbeta)
 

@@ -573,7 +573,8 @@ static int bn_apply_groups(vf_ctx* ctx, const float* x, float* y, const float* g
 
 static int bn_train_fwd_groups(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
-                               int64_t npix, int C, int groups, float momentum, float eps, int act, float slope) {
+                               int64_t npix, int C, int groups, float momentum, float eps, int act, float slope,
+                               void* y_planes = nullptr) {
   VF_REQUIRE(C % 4 == 0, "BatchNorm channel count must be a multiple of 4 (got %d)", C);
   VF_REQUIRE(groups >= 1 && groups <= 64, "BatchNorm batch groups: %d", groups);
   const BnGeom g = bn_geom(npix, C, bn_stat_blocks(npix, C, 32768));
@@ -589,7 +590,7 @@ static int bn_train_fwd_groups(vf_ctx* ctx, const float* x, float* y, const floa
                        (float*)nullptr, 0.f, groups);
     VF_LAUNCH_CHECK();
   }
-  return bn_apply_groups(ctx, x, y, gamma, beta, save_mean, save_invstd, npix, C, groups, act, slope);
+  return bn_apply_groups(ctx, x, y, gamma, beta, save_mean, save_invstd, npix, C, groups, act, slope, y_planes);
 }
 
 VF_API int vf_bn_train_fwd(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
@@ -674,6 +675,22 @@ VF_API int vf_bn_bwd_groups(vf_ctx* ctx, const float* x, const float* y_act, con
   if (int rc = bn_bwd_stats_groups(ctx, x, y_act, gy, save_mean, sums, npix_per_group, C, groups, act, slope)) return rc;
   return bn_bwd_apply_groups(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix_per_group,
                              npix_per_group, C, groups, act, slope, pbeta);
+}
+
+// the grouped forms that also write the bf16 planes of their output (for a vf_pconv_* consumer)
+VF_API int vf_bn_train_fwd_planes(vf_ctx* ctx, const float* x, float* y, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, double* sums,
+                                  int64_t npix_per_group, int C, int groups, float momentum, float eps, int act, float slope,
+                                  void* y_planes) {
+  return bn_train_fwd_groups(ctx, x, y, gamma, beta, running_mean, running_var, save_mean, save_invstd, sums, npix_per_group, C,
+                             groups, momentum, eps, act, slope, y_planes);
+}
+VF_API int vf_bn_bwd_planes(vf_ctx* ctx, const float* x, const float* y_act, const float* gy, float* gx, float* ggamma,
+                            float* gbeta, const float* gamma, const float* save_mean, const float* save_invstd, double* sums,
+                            int64_t npix_per_group, int C, int groups, int act, float slope, float pbeta, void* gx_planes) {
+  if (int rc = bn_bwd_stats_groups(ctx, x, y_act, gy, save_mean, sums, npix_per_group, C, groups, act, slope)) return rc;
+  return bn_bwd_apply_groups(ctx, x, y_act, gy, gx, ggamma, gbeta, gamma, save_mean, save_invstd, sums, npix_per_group,
+                             npix_per_group, C, groups, act, slope, pbeta, gx_planes);
 }
 
 // ---- statistics already summed per tile by the GEMM that produced the tensor (vf_bn_fuse_next_fwd / _bwd, VfBnSt):

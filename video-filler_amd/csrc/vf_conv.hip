@@ -1966,10 +1966,19 @@ static bool main_net_shape(int H, int W, int k, int stride, int pad) {
   return k == 4 && ((stride == 2 && pad == 1) || (stride == 1 && pad == 0 && H == 4 && W == 4)) && vf_is_pow2(H) && vf_is_pow2(W);
 }
 
+int vf_internal_conv_thin_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, void* y_planes, int B, int H,
+                              int W, int Cin, int Cout, int act, float slope);      // vf_conv_thin.hip
 VF_API int vf_conv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
                          int Cin, int Cout, int k, int stride, int pad, int act, float slope) {
   if (!main_net_shape(H, W, k, stride, pad)) return vf_internal_gconv_fwd(ctx, x, w, bias, y, B, H, W, Cin, Cout, k, stride, pad, act, slope);
   if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
+  if (stride == 2 && Cin == 3 && !ctx->bnf.mode) {      // the image-side layers: direct convolution (vf_conv_thin.hip)
+    static const int no_thin = getenv("VF_NO_THIN") ? 1 : 0;
+    if (!no_thin) {
+      const int rc = vf_internal_conv_thin_fwd(ctx, x, w, bias, y, nullptr, B, H, W, Cin, Cout, act, slope);
+      if (rc >= 0) return rc;
+    }
+  }
   return conv_like_fwd(ctx, x, w, bias, y, B, H, W, Cin, Cout, stride, pad, act, slope);
 }
 

@@ -1,0 +1,161 @@
+// vf_conv_thin.hip — the image-side convolutions: 3 input channels (netG's first conv train.lua:89, netD's first conv :183).
+//
+// K = 16 taps x 3 channels = 48: an MFMA tile would be mostly padding, and the implicit-GEMM kernels' scalar-gather path
+// (vf_conv.hip, V = 0) spends its time on per-element address arithmetic — 52 us for 0.4 GFLOP whose cost is really the
+// 67 MB output write.  This is a direct convolution instead: a block owns 8 x 8 output pixels of one image and 64 output
+// channels; the 18 x 18 pixel input patch is staged once in LDS (one float4 per pixel, zero-filled at the image border), every thread keeps the
+// 2 x 48 weights of its two output channels in registers and walks 8 pixels, reading the patch as wave-uniform LDS
+// broadcasts; a pixel's 64 channels leave as one 256-byte row (bias + LeakyReLU/ReLU fused), optionally with the three
+// bf16 planes of the output beside it for the planes-fed convolution that consumes it (vf_pgemm.hip).
+// fp32 FMA chains in (kh, kw, c) order: the parity bars of the implicit-GEMM path (tests/test_gpu_conv_sweep.py).
+#include <algorithm>
+#include <cstdlib>
+
+#include "vf_common.h"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TP = 8;                    // output pixels per tile side
+constexpr int PW = 2 * TP + 2;           // patch side (stride 2, pad 1, 4 taps)
+
+template <int CIN>
+__global__ __launch_bounds__(256) void k_conv_thin_in(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      unsigned short* __restrict__ planes, int64_t pstride, int H, int W, int Cout,
+                                                      int tiles_x, int tiles_y, float neg) {
+  static_assert(CIN <= 4, "pixels are padded to one float4 in LDS");
+  constexpr int K = 16 * CIN, ROW4 = PW;                 // patch rows of PW float4 pixels (channels CIN..3 unused)
+  constexpr int PP = (PW * ROW4 + 255) / 256;            // patch pixels per thread
+  __shared__ f32x4 patch[PW * ROW4];
+  __shared__ float wl[64 * (K + 1)];
+  const int tid = threadIdx.x;
+  // a block walks one ROW of tiles (tiles_x of them): the weights reach its registers once, and the next tile's patch is
+  // on its way while the current one is computed (with one tile per block the kernel was all prologue: 30 of 55 us)
+  const int ty = blockIdx.x % tiles_y, b = blockIdx.x / tiles_y;
+  const int n0 = blockIdx.y * 64;
+  const int iy0 = 2 * TP * ty - 1;
+  const float* xb = x + (int64_t)b * H * W * CIN;
+  f32x4 pre[PP];
+  auto fetch = [&](int tx) {       // this thread's pixels of tile tx's patch -> registers (zeros outside the image)
+    const int ix0 = 2 * TP * tx - 1;
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+      const int i = tid + 256 * j;
+      const int r = i / ROW4, c = i - r * ROW4;
+      const int iy = iy0 + r, ix = ix0 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < PW * ROW4 && tx < tiles_x && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        const float* px = xb + ((int64_t)iy * W + ix) * CIN;
+#pragma unroll
+        for (int e = 0; e < CIN; ++e) v[e] = px[e];
+      }
+      pre[j] = v;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+      const int i = tid + 256 * j;
+      if (i < PW * ROW4) patch[i] = pre[j];
+    }
+  };
+  fetch(0);
+  // ---- this thread's two output channels: 2 x K weights in registers, by way of LDS (the 64 x K block of the weight matrix is
+  // contiguous in memory: coalesced loads; a thread fetching its own two rows straight from memory touched 32 lines per load)
+  for (int i = tid; i < 64 * K; i += 256) wl[(i / K) * (K + 1) + (i % K)] = w[(int64_t)n0 * K + i];
+  stash();
+  const int n2 = tid & 31, pg = tid >> 5;
+  const int n = n0 + 2 * n2;
+  __syncthreads();
+  float w0[K], w1[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    w0[k] = wl[(2 * n2) * (K + 1) + k];
+    w1[k] = wl[(2 * n2 + 1) * (K + 1) + k];
+  }
+  const float b0 = bias ? bias[n] : 0.f, b1 = bias ? bias[n + 1] : 0.f;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int oy = TP * ty + pg;
+  for (int tx = 0; tx < tiles_x; ++tx) {
+    fetch(tx + 1);
+#pragma unroll 2
+    for (int px = 0; px < TP; ++px) {
+      float a0 = b0, a1 = b1;
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh) {
+        const f32x4* pr = patch + (2 * pg + kh) * ROW4 + 2 * px;      // 4 taps, one float4 each (wave-uniform per half: broadcast)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          const f32x4 xv = pr[kw];
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) {
+            a0 = fmaf(xv[c], w0[(kh * 4 + kw) * CIN + c], a0);
+            a1 = fmaf(xv[c], w1[(kh * 4 + kw) * CIN + c], a1);
+          }
+        }
+      }
+      a0 = a0 * (a0 > 0.f ? 1.f : neg);
+      a1 = a1 * (a1 > 0.f ? 1.f : neg);
+      const int ox = TP * tx + px;
+      const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * Cout + n;
+      f32x2 v = {a0, a1};
+      *(f32x2*)(y + o) = v;
+      if (planes) {
+        float r0 = a0, r1 = a1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1);
+          *(unsigned*)(planes + q * pstride + o) = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+          if (q < 2) {
+            r0 -= __uint_as_float(u0 & 0xffff0000u);
+            r1 -= __uint_as_float(u1 & 0xffff0000u);
+          }
+        }
+      }
+    }
+    __syncthreads();        // everyone has read this tile's patch
+    stash();
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// conv forward with 3 input channels, 4x4 stride 2 pad 1; act in {none, LeakyReLU, ReLU}.  Returns -1 if the shape is not this
+// kernel's (the caller keeps the implicit-GEMM path), 0 when launched, > 0 on a launch error.
+int vf_internal_conv_thin_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, void* y_planes, int B, int H,
+                              int W, int Cin, int Cout, int act, float slope) {
+  if (ctx->mfma_bf16 == 1) return -1;       // (the bf16-operand mode rounds its operands: that is the GEMM kernels' business)
+  if (Cin != 3 || Cout % 64 != 0 || H % (2 * TP) != 0 || W % (2 * TP) != 0) return -1;
+  if (!(act == VF_ACT_NONE || act == VF_ACT_LRELU || act == VF_ACT_RELU)) return -1;
+  if ((((uintptr_t)y) & 7) != 0) return -1;
+  const float neg = act == VF_ACT_LRELU ? slope : (act == VF_ACT_RELU ? 0.f : 1.f);
+  const int tiles_x = W / (2 * TP), tiles_y = H / (2 * TP);
+  const int64_t out = (int64_t)B * (H / 2) * (W / 2) * Cout;
+  VfProf prof(ctx, y_planes ? "conv_thin_in_planes" : "conv_thin_in", 2.0 * (double)out * 16 * Cin, 0.0);
+  hipLaunchKernelGGL((k_conv_thin_in<3>), dim3((unsigned)(B * tiles_y), (unsigned)(Cout / 64)), dim3(256), 0, ctx->stream, x, w,
+                     bias, y, (unsigned short*)y_planes, out, H, W, Cout, tiles_x, tiles_y, neg);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int vf_conv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                             int Cout, int k, int stride, int pad, int act, float slope);
+extern "C" int vf_planes_split(vf_ctx* ctx, const float* x, void* planes, int64_t n);
+
+// vf_conv2d_fwd that also leaves the three bf16 planes of y (for a planes-fed consumer): in the epilogue where the kernel
+// can (the thin-input layers above), else by a pass over y.
+VF_API int vf_conv2d_fwd_planes(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, void* y_planes, int B,
+                                int H, int W, int Cin, int Cout, int k, int stride, int pad, int act, float slope) {
+  VF_REQUIRE(y_planes != nullptr, "vf_conv2d_fwd_planes: y_planes is NULL (use vf_conv2d_fwd)");
+  if (k == 4 && stride == 2 && pad == 1) {
+    const int rc = vf_internal_conv_thin_fwd(ctx, x, w, bias, y, y_planes, B, H, W, Cin, Cout, act, slope);
+    if (rc >= 0) return rc;
+  }
+  if (int rc = vf_conv2d_fwd(ctx, x, w, bias, y, B, H, W, Cin, Cout, k, stride, pad, act, slope)) return rc;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  return vf_planes_split(ctx, y, y_planes, (int64_t)B * Ho * Wo * Cout);
+}

@@ -175,13 +175,22 @@ class SpatialConvolution(Module):
             setattr(self, name, t)
         return t
 
-    def updateOutput(self, input, act="none", slope=0.0, in_planes=None, managed=False):
+    def updateOutput(self, input, act="none", slope=0.0, in_planes=None, managed=False, want_planes=False):
+        """want_planes: also leave the bf16 planes of the output in self.output_planes (for a planes-fed consumer) where this
+        pass can write them itself (the 3-channel image-side layers); None otherwise — the consumer then splits."""
         input = to_nhwc(input)
         Bn, Cin, H, W = input.shape
         assert Cin == self.nInputPlane, "expected %d input planes, got %d" % (self.nInputPlane, Cin)
         Ho, Wo = self.out_hw(H, W)
         y = self._buf("output", Bn, self.nOutputPlane, Ho, Wo)
         B = get_backend()
+        self.output_planes = None
+        if (want_planes and not self._is_full and Cin == 3 and act in ("none", "lrelu", "relu") and hasattr(B, "conv2d_fwd_planes")
+                and self.kH == 4 and self.dH == 2 and self.padH == 1 and self.nOutputPlane % 64 == 0 and H % 16 == 0 and W % 16 == 0):
+            yp = self._planes_buf("_yp", y.numel())
+            B.conv2d_fwd_planes(input, self.weight, self.bias, y, yp, self.kH, self.dH, self.padH, act, slope)
+            self.output_planes = yp
+            return y
         if act in ("none", "lrelu", "relu") and self._pconv_ok(Bn, H, W, Cin, self.nOutputPlane, self._is_full):
             xp = in_planes if in_planes is not None else B.planes_split(input, self._planes_buf("_xp", input.numel()))
             wp = self.weight_planes(self._is_full, refresh=not managed)
@@ -312,6 +321,16 @@ class SpatialBatchNormalization(Module):
                                su, self.groups, self.momentum, self.eps, act, slope, yp)
             self.output_planes = yp
             return y
+        if want_planes and self.train and self.sync_world == 1 and hasattr(B, "bn_train_fwd_groups") and Bn % self.groups == 0:
+            # the separate statistics pass (no convolution in front could sum them), planes of the output all the same
+            sm, ss, su = self._stat_bufs()
+            yp = getattr(self, "_yp", None)
+            if yp is None or yp.shape[1] != y.numel():
+                yp = self._yp = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=y.device)
+            B.bn_train_fwd_groups(input, y, self.weight, self.bias, self.running_mean, self.running_var, sm, ss, su, self.groups,
+                                  self.momentum, self.eps, act, slope, y_planes=yp)
+            self.output_planes = yp
+            return y
         if self.train and self.groups > 1:
             assert self.sync_world == 1 and Bn % self.groups == 0
             h = Bn // self.groups
@@ -386,6 +405,20 @@ class SpatialBatchNormalization(Module):
                     setattr(self, "_gp_" + buf, gp)
             B.bn_bwd_pre(self._part, pre_rows, input, gradOutput, gx, self.gradWeight if want_gp else None,
                          self.gradBias if want_gp else None, self.weight, sm, ss, su, G, pbeta, gp)
+            self.grad_planes = gp
+            return gx
+        if want_planes and gx is not None and self.sync_world == 1 and hasattr(B, "bn_bwd_groups"):
+            # separate statistics pass, gradient planes all the same (the layers right under a bottleneck / under netD's head)
+            if group is not None:
+                (sm, ss, su), G = self._group_state()[group], 1
+            else:
+                (sm, ss, su), G = self._stat_bufs(), self.groups
+            gp = getattr(self, "_gp_" + buf, None)
+            if gp is None or gp.shape[1] != gx.numel():
+                gp = torch.empty((3, gx.numel()), dtype=torch.bfloat16, device=gx.device)
+                setattr(self, "_gp_" + buf, gp)
+            B.bn_bwd_groups(input, y_act, gradOutput, gx, self.gradWeight if want_gp else None, self.gradBias if want_gp else None,
+                            self.weight, sm, ss, su, G, act, slope, pbeta, gx_planes=gp)
             self.grad_planes = gp
             return gx
         if self.groups > 1:
@@ -747,8 +780,9 @@ class Sequential(Module):
                 continue
             if isinstance(m, SpatialBatchNormalization):
                 rows, pre_rows = pre_rows, 0
-                want_pl = (self.fuse and rows > 0 and isinstance(nxt, SpatialConvolution) and nxt.pconv_layer()
-                           and (a is None or a.act in ("lrelu", "relu")) and not _NO_PCONV)
+                want_pl = (self.fuse and m.train and isinstance(nxt, SpatialConvolution) and nxt.pconv_layer()
+                           and (a is None or a.act in ("lrelu", "relu")) and not _NO_PCONV
+                           and nxt._pconv_ok(cur.shape[0], cur.shape[2], cur.shape[3], nxt.nInputPlane, nxt.nOutputPlane, nxt._is_full))
                 cur = m.updateOutput(cur, *((a.act, a.slope) if a is not None else ("none", 0.0)), pre_rows=rows, want_planes=want_pl)
                 cur_pl = m.output_planes
                 if a is not None:
@@ -758,12 +792,17 @@ class Sequential(Module):
                         cur_pl = None        # (a test hook may have edited the tensor)
                 continue
             if isinstance(m, SpatialConvolution):
-                cur = m.updateOutput(cur, *((a.act, a.slope) if a is not None else ("none", 0.0)), in_planes=cur_pl, managed=managed)
-                cur_pl = None
+                Ho, Wo = m.out_hw(cur.shape[2], cur.shape[3])
+                want_pl = (self.fuse and isinstance(nxt, SpatialConvolution) and not _NO_PCONV and nxt.pconv_layer()
+                           and nxt._pconv_ok(cur.shape[0], Ho, Wo, nxt.nInputPlane, nxt.nOutputPlane, nxt._is_full))
+                cur = m.updateOutput(cur, *((a.act, a.slope) if a is not None else ("none", 0.0)), in_planes=cur_pl, managed=managed,
+                                     want_planes=want_pl)
+                cur_pl = m.output_planes
                 if a is not None:
                     a.output = cur
                     if Sequential.act_hook is not None and a.act in ("lrelu", "relu"):
                         Sequential.act_hook(a, cur)
+                        cur_pl = None
                 continue
             cur_pl = None
             if a is None:
@@ -830,8 +869,10 @@ class Sequential(Module):
                     rows, bn_pre = bn_pre, 0
                     # the convolution below consumes this gradient in its data-gradient pass: write its planes here
                     below = plan[idx - 1][0] if idx > 0 else None
-                    want_pl = (self.fuse and rows > 0 and want_gx and isinstance(below, SpatialConvolution) and below.pconv_layer()
-                               and (idx - 1 > 0 or need_input_grad) and not _NO_PCONV)
+                    want_pl = (self.fuse and want_gx and isinstance(below, SpatialConvolution) and below.pconv_layer()
+                               and (idx - 1 > 0 or need_input_grad) and not _NO_PCONV
+                               and below._pconv_ok(x.shape[0], x.shape[2], x.shape[3], below.nOutputPlane, below.nInputPlane,
+                                                   not below._is_full))
                     if a is None:
                         g = m._bwd(x, g, want_gx, want_gp, group=gsel, buf=gbuf, pre_rows=rows, want_planes=want_pl)
                     else:
