@@ -102,15 +102,19 @@ def main():
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
+        if args.backend != "nccl":          # rehearsal of the control flow (several ranks on one GPU): torch.distributed
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from video_filler_amd.backend import get_backend
+    from video_filler_amd.backend import exchange_comm_id, get_backend
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
 
     B = get_backend()
+    store = None
+    if (world > 1 or args.force_dist) and args.backend == "nccl":
+        # the exchange is the C-ABI's (vf_comm_*: RCCL inside libvf_hip.so); the only host-side rendezvous is moving
+        # rank 0's 128-byte id, through a TCP store at MASTER_ADDR:MASTER_PORT — no torch.distributed process group
+        cid, store = exchange_comm_id(B, world, rank)
+        B.init_comm(world, rank, cid)
     global PEAK_F32_MFMA_TFLOPS
     B.set_mfma_mode(args.mfma)
     if args.mfma == "bf16":
@@ -176,8 +180,12 @@ def main():
             run()
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if B.comm is not None:
+                B.comm_barrier()        # every rank's streams have drained and every rank is here (host-blocking)
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
@@ -188,7 +196,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        B.all_reduce(t, op="max")           # vf_comm_allreduce_inline (or torch.distributed in the gloo rehearsal)
         dt = float(t.item())
     # per-step distribution (median and p10/p90 over >= 100 iterations): a separate pass after the timed
     # region, one event pair per step on the launch stream, nothing synchronises inside it
@@ -390,9 +398,23 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if world > 1 or args.force_dist:
-        if world > 1:
-            dist.barrier()          # ranks > 0 wait here while rank 0 runs its instrumented pass and the CPU baseline
-        dist.destroy_process_group()
+        # ranks > 0 wait here while rank 0 runs its instrumented pass and the CPU baseline: on the host (a store key), not
+        # inside a collective whose kernel would spin on their GPUs for minutes
+        if store is not None:
+            if rank == 0:
+                store.set("vf_bench_done", "1")
+                t_end = time.time() + 120
+                while world > 1 and store.add("vf_bench_left", 0) < world - 1 and time.time() < t_end:
+                    time.sleep(0.05)        # the store lives in this process: stay until everyone has read the key
+            elif world > 1:
+                import datetime
+                store.wait(["vf_bench_done"], datetime.timedelta(seconds=1800))
+                store.add("vf_bench_left", 1)
+            B.destroy_comm()
+        else:
+            if world > 1:
+                dist.barrier()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -313,6 +313,37 @@ int vf_wgrad_group_abort(vf_ctx* ctx);
 int vf_bias_grad_plan(int64_t P, int C, int* cq, int* rows_per_block, int* gx, int* gy);
 int vf_bias_grad_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks1, int blocks2);
 
+/* ---- data-parallel exchange over RCCL (one process per GPU) --------------------------------------------------------
+ * The reference trains on one device (train.lua:42 `gpu = 1`); BASELINE's N > 1 configuration is data parallelism over
+ * the same closures: the flat gradient vectors of train.lua:240-241 are averaged over ranks before each optim.adam,
+ * optionally BatchNorm's sums are added over ranks (statistics of the global batch).  These entries are that exchange, so
+ * a Lua / FFI host needs nothing besides this library.  RCCL is bound at run time (dlopen "librccl.so", or $VF_RCCL_LIB)
+ * at the first call; the rest of the library does not depend on it.
+ *
+ * vf_comm_unique_id: rank 0 fills 128 opaque bytes; the host hands them to every rank (file, socket, MPI ...).
+ * vf_comm_init: collective over all ranks, on the CURRENT device (hipSetDevice first).
+ * vf_comm_allreduce_async: in place, on the communicator's own stream, ordered after the work already given to ctx's
+ *   stream; ctx's stream carries on (backward kernels overlap the bucket's flight).  dtype 0 = f32, 1 = f64;
+ *   op 0 = sum, 1 = average, 2 = max, 3 = min.  *ticket (0..63, reused round-robin) names it for vf_comm_wait, which makes
+ *   ctx's stream wait on the DEVICE for that collective and all earlier ones (the host does not block).
+ * vf_comm_allreduce_avg_async: the gradient bucket case (f32, average).
+ * vf_comm_allreduce_inline: the collective on ctx's stream itself (SyncBN sums; capturable into a hipGraph with the
+ *   kernels around it).  vf_comm_broadcast: root's buffer to all ranks, on ctx's stream (initial parameters).
+ * vf_comm_barrier: host-blocking; both streams of every rank have drained. */
+typedef struct vf_comm vf_comm;
+#define VF_COMM_ID_BYTES 128
+int vf_comm_unique_id(void* id128);
+int vf_comm_init(vf_comm** out, const void* id128, int world, int rank);
+int vf_comm_world(const vf_comm* c);
+int vf_comm_rank(const vf_comm* c);
+int vf_comm_allreduce_async(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op, int* ticket);
+int vf_comm_allreduce_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t n, int* ticket);
+int vf_comm_wait(vf_comm* c, vf_ctx* ctx, int ticket);
+int vf_comm_allreduce_inline(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op);
+int vf_comm_broadcast(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int root);
+int vf_comm_barrier(vf_comm* c, vf_ctx* ctx);
+int vf_comm_destroy(vf_comm* c);
+
 /* ---- per-kernel timers (the reference has three torch.Timers, train.lua:241-243; these are finer) ----
  * Between vf_prof_begin and vf_prof_end every kernel launch of the library is bracketed by HIP events on the
  * context's stream.  vf_prof_end synchronises and aggregates per kernel name; vf_prof_get reads entry i:

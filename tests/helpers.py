@@ -134,3 +134,10 @@ class KinkSync:
         finally:
             hnn.Sequential.act_hook = None
         # every recorded pass must have been consumed
+
+
+def attach_world1_comm(hipb):
+    """a one-rank RCCL communicator on the session's HIP backend (vf_comm_init), created once"""
+    if hipb.comm is None:
+        hipb.init_comm(1, 0, hipb.comm_unique_id())
+    return hipb

@@ -1,0 +1,123 @@
+"""vf_comm_* — the data-parallel exchange of the C-ABI (include/vf_hip.h, csrc/vf_comm.hip) — on the one GPU a test box has:
+a communicator of ONE rank (RCCL refuses two ranks on one device).  What can be checked here: the library binds RCCL at run
+time, every entry does what it says when averaging over one rank is the identity, the stream ordering of the asynchronous
+form (a producer kernel before, a consumer kernel after), and that the inline form is recorded by a graph capture together
+with the kernels around it (SyncBN's sums).  The arithmetic of N > 1 ranks is covered on the CPU over gloo
+(tests/test_host_logic.py: world 2 and 4, synchronised and local BatchNorm)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import attach_world1_comm, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_communicator_entries(hipb):
+    B = attach_world1_comm(hipb)
+    lib, comm, ctx = B.lib, B.comm, B.ctx
+    assert lib.vf_comm_world(comm) == 1 and lib.vf_comm_rank(comm) == 0
+    n = 1 << 22
+    x = torch.randn(n, device=B.device)
+    want = x.clone()
+    t = C.c_int32(-1)
+    # asynchronous average, ordered after a producer on the context's stream and before a consumer
+    B.scale_shift(x, 2.0, 1.0)
+    assert lib.vf_comm_allreduce_avg_async(comm, ctx, C.c_void_p(x.data_ptr()), n, C.byref(t)) == 0
+    assert 0 <= t.value < 64
+    assert lib.vf_comm_wait(comm, ctx, t.value) == 0
+    B.scale_shift(x, 0.5, -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(x, (want * 2.0 + 1.0) * 0.5 - 0.5)
+    # f64 sums inline (SyncBN), max / min, broadcast, barrier
+    s = torch.arange(64, dtype=torch.float64, device=B.device)
+    for op in ("sum", "max", "min"):
+        B.all_reduce(s, op=op)
+    B.comm_broadcast(s, 0)
+    B.comm_barrier()
+    assert torch.equal(s.cpu(), torch.arange(64, dtype=torch.float64))
+    # many collectives in flight: tickets wrap round a ring of 64
+    seen = set()
+    for _ in range(70):
+        assert lib.vf_comm_allreduce_async(comm, ctx, C.c_void_p(x.data_ptr()), 1024, 0, 0, C.byref(t)) == 0
+        seen.add(t.value)
+    assert lib.vf_comm_wait(comm, ctx, t.value) == 0
+    torch.cuda.synchronize()
+    assert len(seen) == 64
+    # argument errors come back as codes with a message, not as crashes
+    assert lib.vf_comm_allreduce_async(comm, ctx, C.c_void_p(x.data_ptr()), 16, 7, 0, C.byref(t)) != 0
+    assert b"dtype" in lib.vf_last_error()
+    assert lib.vf_comm_wait(comm, ctx, 64) != 0
+    assert lib.vf_comm_broadcast(comm, ctx, C.c_void_p(x.data_ptr()), 16, 0, 3) != 0
+
+
+def test_gradient_bucket_overlaps_the_kernels_issued_after_it(hipb):
+    """vf_comm_allreduce_avg_async returns with the collective on the communicator's stream: kernels given to the context's
+    stream afterwards run without waiting for it, and vf_comm_wait is the only join."""
+    B = attach_world1_comm(hipb)
+    big = torch.ones(64 << 20, device=B.device)                 # 256 MB bucket: netG's tail bucket
+    other = torch.zeros(1 << 20, device=B.device)
+    h = B.all_reduce_avg(big, 1, async_op=True)
+    B.scale_shift(other, 1.0, 3.0)                              # independent work behind the launch
+    h.wait()
+    B.scale_shift(big, 2.0, 0.0)                                # consumer: after the collective
+    torch.cuda.synchronize()
+    assert float(other[0]) == 3.0 and float(big[0]) == 2.0 and float(big[-1]) == 2.0
+
+
+@pytest.mark.parametrize("kind", ["center", "vid"])
+def test_syncbn_collectives_are_captured_with_the_phases(kind, oracle, hipb):
+    """SyncBN puts one collective per BatchNorm layer and pass INSIDE the phases (a layer's statistics are needed before the
+    layer can be applied: the dependency is per layer, only the two moments travel together).  They are issued on the
+    context's stream (vf_comm_allreduce_inline), so capture_phased records them in the same four graphs.  One rank: the
+    sums come back unchanged, so the replayed trajectory must agree with a trainer that never leaves the device-local path
+    (different kernels for the statistics: fp32 agreement, not bitwise), and replaying must equal running eagerly (bitwise)."""
+    from video_filler_amd import nn
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+    attach_world1_comm(hipb)
+    if kind == "center":
+        opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4)
+        batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)
+        mk = lambda **kw: CenterTrainer(opt, seed=3, **kw)
+    else:
+        opt = dict(nBottleneck=128, predLen=2)
+        batch = tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(4, np.random.default_rng(5), 6))
+        mk = lambda **kw: VidTrainer(opt, seed=3, **kw)
+
+    def synced():
+        t = mk(overlap=False)                  # what the trainers do for world > 1 with sync_bn (one stream)
+        t.set_batch(*batch)
+        t.force_comm = True
+        n = 0
+        for net in (t.netG, t.netD):
+            for m in net.leaves():
+                if isinstance(m, nn.SpatialBatchNormalization):
+                    m.sync_force = True
+                    n += 1
+        assert n >= 8
+        return t
+
+    plain = mk()
+    plain.set_batch_d(False)
+    plain.set_batch(*batch)
+    eager, graph = synced(), synced()
+    plain.step()
+    eager.step_phased()
+    torch.cuda.synchronize()
+    # first iteration: same weights, same batch — the two BatchNorm paths agree to fp32 rounding
+    assert rel_err(eager.gradParametersG.cpu().numpy(), plain.gradParametersG.cpu().numpy()) < 1e-4
+    l0, l1 = plain.losses(), eager.losses()
+    for k in ("errD", "errG", "errG_l2"):
+        assert abs(l0[k] - l1[k]) <= 2e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    for _ in range(4):
+        plain.step()
+        eager.step_phased()
+    graph.capture_phased(warmup=3)
+    graph.step_phased()
+    graph.step_phased()
+    torch.cuda.synchronize()
+    assert torch.equal(graph.parametersG, eager.parametersG) and torch.equal(graph.parametersD, eager.parametersD)
+    # seven Adam steps later the trajectories are still together (Adam amplifies rounding on near-zero gradients: DESIGN.md)
+    assert rel_err(graph.parametersG.cpu().numpy(), plain.parametersG.cpu().numpy()) < 5e-2

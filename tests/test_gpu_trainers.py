@@ -333,14 +333,11 @@ def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb):
 def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hipb):
     """The data-parallel iteration (4 HIP graphs with RCCL all-reduce-average between them, G's gradient in two
     buckets, the tail one in flight during the encoder's backward) on a world of ONE rank must walk exactly the
-    trajectory of the plain loop body: averaging over one rank is the identity."""
-    import os
-    import torch.distributed as dist
+    trajectory of the plain loop body: averaging over one rank is the identity.  The exchange is the C-ABI's
+    (vf_comm_*, tests/test_gpu_comm.py): no torch.distributed process group exists in this process."""
+    from helpers import attach_world1_comm
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    attach_world1_comm(hipb)
     if kind == "center":
         opt = dict(nBottleneck=256, wtl2=0.999, overlapPred=4)
         batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)

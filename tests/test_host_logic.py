@@ -291,7 +291,7 @@ def test_checkpoint_roundtrip(tmp_path, cpu_backend):
     assert util.cudnn(a) is a          # drivers keep their util.cudnn(net) call
 
 
-# ------------------------------------------------------------------ data parallel over gloo, world_size 2
+# ------------------------------------------------------------------ data parallel over gloo, world_size 2 and 4
 def _dp_worker(rank, world, port, kind, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -301,8 +301,10 @@ def _dp_worker(rank, world, port, kind, out_dir):
     from video_filler_amd import backend as vb2
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
     vb2.set_backend(OracleBackend())
-    B = 4
-    if kind.startswith("center"):
+    local_bn = kind.endswith("_local")           # sync_bn=False: every rank normalises with its own shard's statistics
+    base = kind[:-len("_local")] if local_bn else kind
+    B = 2 * world
+    if base.startswith("center"):
         opt = dict(SMALL, wtl2=0.999, overlapPred=4, smooth=True)   # smooth nets: see tests/test_gpu_trainers.py
         full_batch = torch.from_numpy(O.synth_center_batch(B, np.random.default_rng(77)))
         mk = lambda w, r, s: CenterTrainer(opt, seed=11, world=w, rank=r, sync_bn=s)
@@ -312,25 +314,26 @@ def _dp_worker(rank, world, port, kind, out_dir):
         ctx, full, mask = [torch.from_numpy(a) for a in O.synth_vid_batch(B, np.random.default_rng(78), 6)]
         mk = lambda w, r, s: VidTrainer(opt, seed=11, world=w, rank=r, sync_bn=s)
         feed = lambda tr, lo, hi: tr.set_batch(ctx[lo:hi], full[lo:hi], mask[lo:hi])
-    tr = mk(world, rank, True)
+    tr = mk(world, rank, not local_bn)
     per = B // world
     # "vid" runs the phased step (A | all-reduce D | B | all-reduce G | C) that bench.py uses for N > 1;
     # "center" runs the plain loop body with the exchange inside the closures.  Both must equal the big batch.
     # "*_pipe" runs the pipelined step (G's exchange and Adam deferred behind the next iteration's netD real pass).
-    if kind.endswith("_pipe"):
+    if base.endswith("_pipe"):
         tr._pipelined = True
         dp_step = tr.step_pipelined
     else:
-        dp_step = tr.step_phased if kind == "vid" else tr.step
+        dp_step = tr.step_phased if base == "vid" else tr.step
     feed(tr, rank * per, (rank + 1) * per)
     dp_step()
     g1 = tr.gradParametersG.numpy().copy()      # after ONE iteration: gradients are comparable at fp32 precision
+    gD1 = tr.gradParametersD.numpy().copy()
     rm1 = [m.running_mean.numpy().copy() for m in tr.netG.leaves() if hasattr(m, "running_mean")]
     feed(tr, rank * per, (rank + 1) * per)
     dp_step()
     tr.flush()                                  # pipelined: the last iteration's Adam(G) is still pending
     res = dict(pG=tr.parametersG.numpy().copy(), pD=tr.parametersD.numpy().copy(), gG=g1, rm=rm1)
-    if rank == 0:
+    if rank == 0 and not local_bn:
         one = mk(1, 0, False)                 # the single-device big batch the shards must reproduce
         feed(one, 0, B)
         one.step()
@@ -342,6 +345,30 @@ def _dp_worker(rank, world, port, kind, out_dir):
                   gG=rel_err(res["gG"], one_g1),
                   rm=max(float(np.abs(a - b).max()) for a, b in zip(res["rm"], one_rm1)))
         np.save(os.path.join(out_dir, "ok.npy"), np.array([ok["pG"], ok["pD"], ok["gG"], ok["rm"]]))
+    if rank == 0 and local_bn:
+        # local statistics: the exchanged gradient is the MEAN over ranks of what a single-device trainer computes on each
+        # shard alone (same initial weights; netD's gradient does not depend on netG's update, netG's is taken after the
+        # averaged Adam(D) step — so replay D's update with the mean gradient before each shard's fGx)
+        gD, gG, rms = [], [], []
+        shard = []
+        for r in range(world):
+            one = mk(1, 0, False)
+            feed(one, r * per, (r + 1) * per)
+            one.fDx(one.parametersD)
+            gD.append(one.gradParametersD.numpy().copy())
+            shard.append(one)
+        gD_mean = np.mean(np.stack(gD), axis=0, dtype=np.float64).astype(np.float32)
+        from video_filler_amd import optim as vopt
+        for one in shard:
+            one.gradParametersD.copy_(torch.from_numpy(gD_mean))
+            vopt.adam_update(one.parametersD, one.gradParametersD, one.optimStateD)
+            one.fGx(one.parametersG)
+            gG.append(one.gradParametersG.numpy().copy())
+        gG_mean = np.mean(np.stack(gG), axis=0, dtype=np.float64).astype(np.float32)
+        rm_own = [m.running_mean.numpy().copy() for m in shard[0].netG.leaves() if hasattr(m, "running_mean")]
+        ok = dict(gD=rel_err(gD1, gD_mean), gG=rel_err(g1, gG_mean),
+                  rm=max(float(np.abs(a - b).max()) for a, b in zip(rm1, rm_own)))
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([0.0, ok["gD"], ok["gG"], ok["rm"]]))
     # replicas must stay bit-identical across ranks
     t = torch.from_numpy(res["pG"]).clone()
     dist.broadcast(t, 0)
@@ -353,15 +380,44 @@ def _dp_worker(rank, world, port, kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["center", "vid", "center_pipe", "vid_pipe"])
+_DP_KINDS = ["center", "vid", "center_pipe", "vid_pipe"]
+
+
+def _dp_port(i):
+    return 29500 + (os.getpid() % 2000) + 7 * i
+
+
+@pytest.mark.parametrize("kind", _DP_KINDS)
 def test_data_parallel_world2_equals_big_batch(kind, tmp_path):
-    port = 29500 + (os.getpid() % 2000) + 7 * ["center", "vid", "center_pipe", "vid_pipe"].index(kind)
-    mp.spawn(_dp_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, _dp_port(_DP_KINDS.index(kind)), kind, str(tmp_path)), nprocs=2, join=True)
     pG, pD, gG, rm = np.load(str(tmp_path / "ok.npy"))
     assert float(np.load(str(tmp_path / "same.npy"))[0]) == 1.0, "replicas diverged across ranks"
     # sharded gradients are mean-reduced in a different order than the big batch sums: fp32 tolerance
     assert gG < 5e-5 and rm < 1e-5, (gG, rm)
     assert pG < 5e-3 and pD < 5e-3, (pG, pD)     # Adam amplifies rounding on near-zero gradients
+
+
+@pytest.mark.parametrize("kind", ["center", "vid_pipe"])
+def test_data_parallel_world4_equals_big_batch(kind, tmp_path):
+    """four ranks, two samples each, SyncBN: the big batch of 8 (the 8-GPU configuration's control flow at half width)"""
+    mp.spawn(_dp_worker, args=(4, _dp_port(5 + ["center", "vid_pipe"].index(kind)), kind, str(tmp_path)), nprocs=4, join=True)
+    pG, pD, gG, rm = np.load(str(tmp_path / "ok.npy"))
+    assert float(np.load(str(tmp_path / "same.npy"))[0]) == 1.0, "replicas diverged across ranks"
+    assert gG < 5e-5 and rm < 1e-5, (gG, rm)
+    assert pG < 5e-3 and pD < 5e-3, (pG, pD)
+
+
+@pytest.mark.parametrize("kind,world", [("center_local", 2), ("vid_local", 2), ("center_local", 4)])
+def test_data_parallel_with_local_batchnorm_is_the_mean_of_the_shard_gradients(kind, world, tmp_path):
+    """sync_bn=False (bench.py's default for N > 1, a documented deviation from the big batch: DESIGN.md): BatchNorm sees the
+    rank's shard only, so the result is NOT the big batch's — it is exactly the average over ranks of the single-device
+    closures run on each shard, with the replicas' parameters still bit-identical and each rank's running statistics
+    those of its own shard."""
+    i = 8 + ["center_local", "vid_local"].index(kind) + (2 if world == 4 else 0)
+    mp.spawn(_dp_worker, args=(world, _dp_port(i), kind, str(tmp_path)), nprocs=world, join=True)
+    _, gD, gG, rm = np.load(str(tmp_path / "ok.npy"))
+    assert float(np.load(str(tmp_path / "same.npy"))[0]) == 1.0, "replicas diverged across ranks"
+    assert gD < 5e-6 and gG < 5e-5 and rm < 1e-6, (gD, gG, rm)
 
 
 def test_whole_image_batched_tiles_equal_the_tile_loop(cpu_backend):

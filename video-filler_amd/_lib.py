@@ -90,6 +90,17 @@ SIGNATURES = {
     "vf_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, vp]),
     "vf_adam_prep": (i32, [vp, f64, f64, f64, vp]),
     "vf_adam_apply": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, vp]),
+    "vf_comm_unique_id": (i32, [vp]),
+    "vf_comm_init": (i32, [C.POINTER(vp), vp, i32, i32]),
+    "vf_comm_world": (i32, [vp]),
+    "vf_comm_rank": (i32, [vp]),
+    "vf_comm_allreduce_async": (i32, [vp, vp, vp, i64, i32, i32, C.POINTER(i32)]),
+    "vf_comm_allreduce_avg_async": (i32, [vp, vp, vp, i64, C.POINTER(i32)]),
+    "vf_comm_wait": (i32, [vp, vp, i32]),
+    "vf_comm_allreduce_inline": (i32, [vp, vp, vp, i64, i32, i32]),
+    "vf_comm_broadcast": (i32, [vp, vp, vp, i64, i32, i32]),
+    "vf_comm_barrier": (i32, [vp, vp]),
+    "vf_comm_destroy": (i32, [vp]),
     "vf_prof_begin": (i32, [vp]),
     "vf_prof_end": (i32, [vp]),
     "vf_prof_count": (i32, []),

@@ -23,6 +23,40 @@ MFMA_MODES = {"f32": 0, "bf16": 1, "f32_3xbf16": 3}
 DEFAULT_MFMA_MODE = "f32_3xbf16"
 
 
+_COMM_DTYPE = {torch.float32: 0, torch.float64: 1}
+_COMM_OP = {"sum": 0, "avg": 1, "max": 2, "min": 3}
+
+
+class _CommHandle:
+    """one collective in flight on the communicator's stream (vf_comm_allreduce_async's ticket)"""
+
+    def __init__(self, backend, ticket):
+        self.backend, self.ticket = backend, ticket
+
+    def wait(self):
+        b = self.backend
+        _lib.check(b.lib.vf_comm_wait(b.comm, b.ctx, self.ticket))
+
+
+def exchange_comm_id(backend, world, rank, addr=None, port=None, timeout_s=300):
+    """rank 0's vf_comm_unique_id to every rank through a TCP key-value store at MASTER_ADDR:MASTER_PORT (what
+    torch.distributed.run exports).  The store is the only piece of torch.distributed involved: no process group."""
+    import datetime
+    from torch.distributed import TCPStore
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or os.environ["MASTER_PORT"])
+    # under torch.distributed.run the launcher's agent already serves a store on that port (TORCHELASTIC_USE_AGENT_STORE):
+    # every rank is then a client of it; otherwise rank 0 hosts the store
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = TCPStore(addr, port, world, (rank == 0) and not agent, timeout=datetime.timedelta(seconds=timeout_s))
+    if agent:
+        from torch.distributed import PrefixStore
+        store = PrefixStore("vf_comm/%s" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), store)
+    if rank == 0:
+        store.set("vf_comm_id", backend.comm_unique_id())
+    return bytes(store.get("vf_comm_id")), store
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -94,6 +128,7 @@ class HipBackend:
         side.stream = torch.cuda.Stream(device=self.device)
         _lib.check(self.lib.vf_ctx_set_stream(side.ctx, C.c_void_p(side.stream.cuda_stream)))
         side.parent = self
+        side.comm = self.comm
         side._forks = []
         side.mfma_mode = self.mfma_mode
         _lib.check(self.lib.vf_ctx_set_mfma_mode(side.ctx, MFMA_MODES[self.mfma_mode]))
@@ -120,14 +155,67 @@ class HipBackend:
     def from_host(self, t):
         return t.to(self.device)
 
-    def all_reduce(self, t, group=None):
+    # ---- the data-parallel exchange.  With a communicator attached (init_comm: vf_comm_* of the C-ABI, RCCL underneath)
+    #      nothing here touches torch.distributed; without one — tests that rehearse the control flow over gloo, or a host
+    #      that already owns a torch process group — the same calls go through torch.distributed.
+    comm = None
+
+    def init_comm(self, world, rank, id_bytes):
+        """vf_comm_init on this backend's device (collective over all ranks).  id_bytes: rank 0's `comm_unique_id()`,
+        moved to every rank by the host (`exchange_comm_id` does it through a TCP store under torchrun's MASTER_ADDR/PORT)."""
+        assert self.comm is None and getattr(self, "parent", None) is None, "one communicator per process, on the main backend"
+        assert len(id_bytes) == 128
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        _lib.check(self.lib.vf_comm_init(C.byref(h), buf, world, rank))
+        self.comm = h
+        for b in self._forks:
+            b.comm = h
+        return self
+
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        _lib.check(self.lib.vf_comm_unique_id(buf))
+        return buf.raw
+
+    def destroy_comm(self):
+        if self.comm is not None:
+            _lib.check(self.lib.vf_comm_destroy(self.comm))
+            self.comm = None
+            for b in self._forks:
+                b.comm = None
+
+    def comm_barrier(self):
+        _lib.check(self.lib.vf_comm_barrier(self.comm, self.ctx))
+
+    def comm_broadcast(self, t, root=0):
+        assert t.is_contiguous() and t.dtype in _COMM_DTYPE
+        _lib.check(self.lib.vf_comm_broadcast(self.comm, self.ctx, _ptr(t), t.numel(), _COMM_DTYPE[t.dtype], root))
+
+    def all_reduce(self, t, group=None, op="sum"):
+        """in place, on this backend's stream (SyncBN's sums: the next kernel reads them)"""
+        if self.comm is not None:
+            assert t.is_contiguous() and t.dtype in _COMM_DTYPE
+            _lib.check(self.lib.vf_comm_allreduce_inline(self.comm, self.ctx, _ptr(t), t.numel(), _COMM_DTYPE[t.dtype],
+                                                         _COMM_OP[op]))
+            return
         import torch.distributed as dist
-        dist.all_reduce(t, group=group)
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=group)
 
     def all_reduce_avg(self, t, world, group=None, async_op=False):
         """Mean over ranks of a flat gradient bucket.  RCCL averages inside the collective (no extra pass over the
-        bucket); other backends sum, then scale.  async_op: returns a handle whose wait() orders the current stream
+        bucket); other backends sum, then scale.  async_op: returns a handle whose wait() orders this backend's stream
         after the collective, so kernels launched in between overlap it."""
+        if self.comm is not None:
+            assert t.is_contiguous() and t.dtype == torch.float32
+            ticket = C.c_int32(-1)
+            _lib.check(self.lib.vf_comm_allreduce_avg_async(self.comm, self.ctx, _ptr(t), t.numel(), C.byref(ticket)))
+            h = _CommHandle(self, ticket.value)
+            if async_op:
+                return h
+            h.wait()
+            return None
         import torch.distributed as dist
         if dist.get_backend(group) == "nccl":
             h = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)

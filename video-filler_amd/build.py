@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["vf_core.hip", "vf_bn.hip", "vf_conv.hip", "vf_conv_generic.hip", "vf_pipeline.hip", "vf_pgemm.hip", "vf_conv_thin.hip"]
+SRC = ["vf_core.hip", "vf_bn.hip", "vf_conv.hip", "vf_conv_generic.hip", "vf_pipeline.hip", "vf_pgemm.hip", "vf_conv_thin.hip", "vf_comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
             print(out.decode())
     so = lib_path()
     if rebuilt or not os.path.exists(so):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs, "-ldl"])
     return so
 
 

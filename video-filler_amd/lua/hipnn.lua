@@ -67,6 +67,16 @@ int vf_adam_apply(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t
 int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
 int vf_wgrad_group_abort(vf_ctx* ctx);
+typedef struct vf_comm vf_comm;
+int vf_comm_unique_id(void* id128);
+int vf_comm_init(vf_comm** out, const void* id128, int world, int rank);
+int vf_comm_allreduce_async(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op, int* ticket);
+int vf_comm_allreduce_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t n, int* ticket);
+int vf_comm_wait(vf_comm* c, vf_ctx* ctx, int ticket);
+int vf_comm_allreduce_inline(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op);
+int vf_comm_broadcast(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int root);
+int vf_comm_barrier(vf_comm* c, vf_ctx* ctx);
+int vf_comm_destroy(vf_comm* c);
 int vf_bias_grad_plan(int64_t P, int C, int* cq, int* rows_per_block, int* gx, int* gy);
 int vf_bias_grad_multi(vf_ctx*, const void* desc_dev, int n, int blocks1, int blocks2);
 int vf_center_prepare(vf_ctx*, const float* batch_nchw, float* ctx_nhwc, float* center_nhwc, const float* fill, int B, int C, int fs, int overlapPred);
@@ -103,6 +113,47 @@ function hipnn.endBackward() check(C.vf_wgrad_group_end(hipnn.ctx)) end
 function hipnn.abortBackward() check(C.vf_wgrad_group_abort(hipnn.ctx)) end   -- after an error inside a backward walk
 
 local function fptr(t) return ffi.cast('float*', t:data()) end
+
+----------------------------------------------------------------------------------------------------------------
+-- Data parallel (one th process per GPU; the reference itself is single-device, train.lua:42).  Rank 0 writes the
+-- 128-byte id to a file every rank can read; then, in the training loop:
+--    optim.adam(function(x) local f, g = fDx(x); hipnn.allreduceAvg(gradParametersD); return f, g end, ...)
+-- i.e. the flat gradient of train.lua:240-241 is averaged over ranks between the closure and the update.
+----------------------------------------------------------------------------------------------------------------
+function hipnn.initComm(world, rank, idfile)
+   local id = ffi.new('uint8_t[128]')
+   if rank == 0 then
+      check(C.vf_comm_unique_id(id))
+      local f = assert(io.open(idfile .. '.tmp', 'wb')); f:write(ffi.string(id, 128)); f:close()
+      os.rename(idfile .. '.tmp', idfile)
+   else
+      local f = io.open(idfile, 'rb')
+      while not f do os.execute('sleep 0.1'); f = io.open(idfile, 'rb') end
+      ffi.copy(id, f:read(128), 128); f:close()
+   end
+   local out = ffi.new('vf_comm*[1]')
+   check(C.vf_comm_init(out, id, world, rank))
+   hipnn.comm, hipnn.world, hipnn.rank = out[0], world, rank
+end
+-- synchronous form: the context's stream waits for the average (the host does not)
+function hipnn.allreduceAvg(flat)
+   if not hipnn.comm then return end
+   local t = ffi.new('int[1]')
+   check(C.vf_comm_allreduce_avg_async(hipnn.comm, hipnn.ctx, fptr(flat), flat:nElement(), t))
+   check(C.vf_comm_wait(hipnn.comm, hipnn.ctx, t[0]))
+end
+-- asynchronous form: returns the ticket; kernels launched before hipnn.waitComm(ticket) overlap the exchange
+function hipnn.allreduceAvgAsync(flat)
+   local t = ffi.new('int[1]')
+   check(C.vf_comm_allreduce_avg_async(hipnn.comm, hipnn.ctx, fptr(flat), flat:nElement(), t))
+   return t[0]
+end
+function hipnn.waitComm(ticket) check(C.vf_comm_wait(hipnn.comm, hipnn.ctx, ticket)) end
+function hipnn.broadcastParameters(flat, root)
+   check(C.vf_comm_broadcast(hipnn.comm, hipnn.ctx, fptr(flat), flat:nElement(), 0, root or 0))
+end
+function hipnn.barrier() check(C.vf_comm_barrier(hipnn.comm, hipnn.ctx)) end
+function hipnn.destroyComm() if hipnn.comm then check(C.vf_comm_destroy(hipnn.comm)); hipnn.comm = nil end end
 
 ---------------------------------------------------------------------------------------------------------------
 -- nn.SpatialConvolution replacement.  Constructor signature identical to nn.SpatialConvolution so that

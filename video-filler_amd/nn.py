@@ -273,6 +273,7 @@ class SpatialBatchNormalization(Module):
         self._fresh = False
         self.sync_world = 1                       # >1: SyncBN — all-reduce the per-channel sums
         self.sync_group = None
+        self.sync_force = False                   # take the SyncBN path at world 1 too (tests: collectives inside a capture)
         # groups > 1: the batch is the concatenation of `groups` independent batches (netD's real and fake passes run
         # as one batch of 2B): statistics, running-average updates and backward sums are per group, in group order —
         # exactly what the separate passes would do — while the convolutions around this module see one large batch
@@ -282,8 +283,11 @@ class SpatialBatchNormalization(Module):
     # -- statistics summed by the convolution that produces / consumes the tensor (backend.bn_fuse_next_*): the container
     #    attaches the request to that convolution and tells this module how many partial rows it left (0: none, run the
     #    plain statistics pass)
+    def _sync(self):
+        return self.sync_world > 1 or self.sync_force
+
     def fusable(self):
-        return self.train and self.sync_world == 1 and self.nOutputPlane % 4 == 0 and not _NO_BN_FUSE
+        return self.train and not self._sync() and self.nOutputPlane % 4 == 0 and not _NO_BN_FUSE
 
     def part_buffer(self, npix):
         """[rows][2C] float64 partials: one row per 64-pixel output tile of the producing GEMM (or per block of its
@@ -321,7 +325,7 @@ class SpatialBatchNormalization(Module):
                                su, self.groups, self.momentum, self.eps, act, slope, yp)
             self.output_planes = yp
             return y
-        if want_planes and self.train and self.sync_world == 1 and hasattr(B, "bn_train_fwd_groups") and Bn % self.groups == 0:
+        if want_planes and self.train and not self._sync() and hasattr(B, "bn_train_fwd_groups") and Bn % self.groups == 0:
             # the separate statistics pass (no convolution in front could sum them), planes of the output all the same
             sm, ss, su = self._stat_bufs()
             yp = getattr(self, "_yp", None)
@@ -332,7 +336,7 @@ class SpatialBatchNormalization(Module):
             self.output_planes = yp
             return y
         if self.train and self.groups > 1:
-            assert self.sync_world == 1 and Bn % self.groups == 0
+            assert not self._sync() and Bn % self.groups == 0
             h = Bn // self.groups
             state = self._group_state()
             if hasattr(B, "bn_train_fwd_groups") and not _NO_BN_GROUPS:       # all groups: one launch per stage
@@ -349,12 +353,12 @@ class SpatialBatchNormalization(Module):
                     B.bn_finalize(su, self.running_mean, self.running_var, sm, ss, h * H * W, self.momentum, self.eps)
                     B.bn_apply(xg, yg, self.weight, self.bias, sm, ss, act, slope)
             return y
-        if self.train and self.sync_world == 1 and hasattr(B, "bn_train_fwd"):
+        if self.train and not self._sync() and hasattr(B, "bn_train_fwd"):
             B.bn_train_fwd(input, y, self.weight, self.bias, self.running_mean, self.running_var, self.save_mean,
                            self.save_std, self._sums, self.momentum, self.eps, act, slope)
         elif self.train:
             B.bn_stats(input, self.running_mean, self._sums)
-            if self.sync_world > 1:
+            if self._sync():
                 B.all_reduce(self._sums, self.sync_group)
             B.bn_finalize(self._sums, self.running_mean, self.running_var, self.save_mean, self.save_std,
                           Bn * H * W * self.sync_world, self.momentum, self.eps)
@@ -407,7 +411,7 @@ class SpatialBatchNormalization(Module):
                          self.gradBias if want_gp else None, self.weight, sm, ss, su, G, pbeta, gp)
             self.grad_planes = gp
             return gx
-        if want_planes and gx is not None and self.sync_world == 1 and hasattr(B, "bn_bwd_groups"):
+        if want_planes and gx is not None and not self._sync() and hasattr(B, "bn_bwd_groups"):
             # separate statistics pass, gradient planes all the same (the layers right under a bottleneck / under netD's head)
             if group is not None:
                 (sm, ss, su), G = self._group_state()[group], 1
@@ -422,7 +426,7 @@ class SpatialBatchNormalization(Module):
             self.grad_planes = gp
             return gx
         if self.groups > 1:
-            assert self.sync_world == 1
+            assert not self._sync()
             state = self._group_state()
             gw, gb = (self.gradWeight, self.gradBias) if want_gp else (None, None)
 
@@ -447,13 +451,13 @@ class SpatialBatchNormalization(Module):
                 one(input[sl], None if y_act is None else y_act[sl], gradOutput[sl], None if gx is None else gx[sl], st,
                     pbeta if g == 0 else 1.0)
             return gx
-        if self.sync_world == 1 and hasattr(B, "bn_bwd"):
+        if not self._sync() and hasattr(B, "bn_bwd"):
             B.bn_bwd(input, y_act, gradOutput, gx, self.gradWeight if want_gp else None, self.gradBias if want_gp else None,
                      self.weight, self.save_mean, self.save_std, self._sums, act, slope, pbeta)
             return gx
         B.bn_bwd_stats(input, y_act, gradOutput, self.save_mean, self._sums, act, slope)
         n_total = Bn * H * W * self.sync_world
-        if self.sync_world > 1:
+        if self._sync():
             # SyncBN: gamma/beta gradients come from THIS rank's sums (the flat-gradient all-reduce adds the other
             # ranks' shares later); gradInput needs the sums over the whole global batch.
             if want_gp:
