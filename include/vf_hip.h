@@ -48,6 +48,14 @@ int vf_ctx_destroy(vf_ctx* ctx);
  *      on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped terms are below 2^-24 of a product, i.e.
  *      one fp32 rounding.  Passes the fp32 parity tolerances unchanged (tests/test_gpu_bf16.py and the whole -m gpu
  *      suite); 1.1-1.4x faster than mode 0 because the bf16 pipe is 16x the f32 one.
+ *      Outside the normal range mode 3 is NOT mode 0 (tests/test_gpu_bf16.py covers normals 1e-18 .. 1e18 only):
+ *        - a +-inf operand element gives NaN in every output it reaches (the split forms inf - inf), where modes 0 / 1 give
+ *          +-inf; NaN operands give NaN in all modes;
+ *        - operand elements below ~2^-110 in magnitude lose their low planes (the residuals are bf16 subnormals, which the
+ *          matrix pipe flushes): such an element is carried with 8-16 significant bits instead of 24, and fp32 subnormal
+ *          operands are treated as zero.  Products that small are far below fp32's own rounding of any sum they join.
+ *      Training never produces either (activations and weights of the reference nets are O(1e-3 .. 1e2)); a host that can
+ *      feed infinities and needs IEEE behaviour for them selects mode 0.
  *   0: native fp32 operands, v_mfma_f32_32x32x2_f32 (an fmaf chain, bit for bit).
  *   1: operands ROUNDED to bf16 (round-to-nearest-even), one product term — opt-in, ~2^-9 relative operand rounding. */
 int vf_ctx_set_mfma_mode(vf_ctx* ctx, int mode);
@@ -67,9 +75,17 @@ int vf_zero_segments(vf_ctx* ctx, float* base, const int64_t* offs, const int64_
 int vf_nchw_to_nhwc(vf_ctx* ctx, const float* src, float* dst, int B, int C, int H, int W);
 int vf_nhwc_to_nchw(vf_ctx* ctx, const float* src, float* dst, int B, int C, int H, int W);
 
-/* ---- nn.SpatialConvolution (THNN SpatialConvolutionMM / cudnn.SpatialConvolution) ---------- */
+/* ---- nn.SpatialConvolution (THNN SpatialConvolutionMM / cudnn.SpatialConvolution) ----------
+ * Shapes.  The matrix-core kernels (vf_conv.hip, vf_pgemm.hip) serve the reference's main nets: kernel 4x4 with
+ * stride 2 pad 1 on maps whose H and W are POWERS OF TWO (pixel coordinates are split with shifts and masks), and the
+ * 4x4 stride 1 pad 0 bottleneck pair on a 4x4 / 1x1 map (train.lua:89-146,183-199).  Every other geometry — the option
+ * branches' 5x5 / 1x1 convolutions, or 4x4 stride 2 on a map that is not a power of two — is served by the general
+ * kernels of vf_conv_generic.hip through the same entry points: same results to the fp32 tolerances, native fp32
+ * arithmetic whatever the context's product mode, and several times slower (they are not on the training hot path:
+ * fineSize is 64 / 128 / 256 in every recipe of the reference).  vf_conv_is_fast reports which path a geometry takes. */
 /* updateOutput.  y[B][Ho][Wo][Cout] = act(conv(x[B][H][W][Cin], w) + bias).  bias may be NULL.
  * act/slope fuse a following in-place nn.LeakyReLU / nn.ReLU / nn.Tanh / nn.Sigmoid (train.lua:90,196). */
+int vf_conv_is_fast(int H, int W, int k, int stride, int pad);
 int vf_conv2d_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int H,
                   int W, int Cin, int Cout, int k, int stride, int pad, int act, float slope);
 /* updateGradInput.  gx[B][H][W][Cin] from gy[B][Ho][Wo][Cout]. */

@@ -23,5 +23,11 @@ def oracle():
 def hipb():
     """The HIP backend.  No skip: on a GPU box a missing GPU/library must fail loudly."""
     import video_filler_amd  # noqa: F401
+    from video_filler_amd import nn
     from video_filler_amd.backend import get_backend
+    # The trainers route a conv pass through the planes kernels (vf_pgemm.hip) only from 3 GFLOP per pass up
+    # (nn._PCONV_MIN_GFLOP: below that the path's fixed costs outweigh its faster GEMMs).  The suite's nets are small: drop the
+    # gate so that every pass with >= 1024 GEMM rows takes the planes path and its BatchNorm / weight-plane plumbing is what
+    # the parity tests exercise; test_planes_path_gate checks the shipped threshold itself.
+    nn._PCONV_MIN_GFLOP = 0.0
     return get_backend()

@@ -7,6 +7,7 @@ fp32-exact up to summation order (2e-5 of the max-norm, as for the fp32 path), a
 unrounded operands it differs by operand rounding, 2^-9 relative per operand: bounded here by 1e-2 of the max-norm.
 Bias, BatchNorm, activations, criteria and Adam are untouched fp32."""
 import numpy as np
+import torch
 import pytest
 
 from helpers import assert_close, to_dev, to_np
@@ -250,3 +251,42 @@ def test_three_plane_split_across_the_exponent_range(scale, oracle, x3_backend):
     dy = hipb.empty_act(*y.shape)
     hipb.conv2d_fwd(to_dev(x, hipb), to_dev(m.weight, hipb), to_dev(m.bias, hipb), dy, 4, 2, 1)
     assert_close(to_np(dy), y, 2e-5, "x3 fwd at scale %g" % scale)
+
+
+def test_three_plane_mode_outside_the_normal_range_is_as_documented(x3_backend):
+    """include/vf_hip.h (vf_ctx_set_mfma_mode): what the default product mode does with operands no training run produces.
+    An infinite operand element turns the outputs it reaches into NaN (the split forms inf - inf) where the native fp32
+    mode gives inf; tiny operands lose their low planes, so they are carried to bf16-level relative accuracy, and fp32
+    subnormals count as zero.  Both the igemm path (small layer) and the planes path (>= 1024 rows) are probed."""
+    hipb = x3_backend
+    rng = np.random.default_rng(6)
+    for B_, H in ((1, 8), (4, 32)):
+        x = rng.standard_normal((B_, 64, H, H)).astype(np.float32)
+        w = rng.standard_normal((64, 64, 4, 4)).astype(np.float32)
+        xi = x.copy()
+        xi[0, 5, 3, 3] = np.inf
+        y3 = hipb.empty_act(B_, 64, H // 2, H // 2)
+        hipb.conv2d_fwd(to_dev(xi, hipb), to_dev(w, hipb), None, y3, 4, 2, 1)
+        y3 = to_np(y3)
+        hipb.set_mfma_mode("f32")
+        try:
+            y0 = hipb.empty_act(B_, 64, H // 2, H // 2)
+            hipb.conv2d_fwd(to_dev(xi, hipb), to_dev(w, hipb), None, y0, 4, 2, 1)
+            y0 = to_np(y0)
+        finally:
+            hipb.set_mfma_mode("f32_3xbf16")
+        touched = ~np.isfinite(y0)
+        assert touched.any() and np.isinf(y0[touched]).all(), "native fp32: +-inf where the infinite element is read"
+        assert np.isnan(y3[touched]).all(), "three-plane mode: NaN in the same places"
+        assert np.array_equal(np.isfinite(y3), ~touched), "and nowhere else"
+        # tiny operands: bf16-level relative accuracy instead of fp32-level; subnormal operands vanish
+        tiny = (x * np.float32(1e-36)).astype(np.float32)
+        yt = hipb.empty_act(B_, 64, H // 2, H // 2)
+        hipb.conv2d_fwd(to_dev(tiny, hipb), to_dev(w, hipb), None, yt, 4, 2, 1)
+        ref = torch.nn.functional.conv2d(torch.from_numpy(tiny).double(), torch.from_numpy(w).double(), stride=2, padding=1).numpy()
+        err = np.abs(to_np(yt) - ref).max() / np.abs(ref).max()
+        assert err < 2e-2, err
+        sub = (x * np.float32(1e-40)).astype(np.float32)
+        ys = hipb.empty_act(B_, 64, H // 2, H // 2)
+        hipb.conv2d_fwd(to_dev(sub, hipb), to_dev(w, hipb), None, ys, 4, 2, 1)
+        assert np.abs(to_np(ys)).max() <= 1e-36

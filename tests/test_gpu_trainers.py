@@ -472,3 +472,19 @@ def test_an_error_inside_a_backward_walk_does_not_poison_later_walks(hipb):
     ga, gb = a.reference_flat(grads=True), b.reference_flat(grads=True)
     assert float(gb.abs().max()) > 0
     assert torch.equal(ga, gb)
+
+
+def test_planes_path_gate(hipb, monkeypatch):
+    """nn._pconv_ok with the shipped threshold (3 GFLOP per pass, 1024 rows): train.lua's layers at batchSize 64 take the planes
+    kernels, the same layers at the video recipes' batchSize 16 and the small-row deep layers do not."""
+    from video_filler_amd import nn
+    monkeypatch.setattr(nn, "_PCONV_MIN_GFLOP", 3.0)
+    c1 = nn.SpatialConvolution(64, 128, 4, 4, 2, 2, 1, 1)
+    e4 = nn.SpatialConvolution(256, 512, 4, 4, 2, 2, 1, 1)
+    d4 = nn.SpatialFullConvolution(128, 64, 4, 4, 2, 2, 1, 1)
+    assert c1._pconv_ok(64, 64, 64, 64, 128, False) and e4._pconv_ok(64, 16, 16, 256, 512, False)
+    assert d4._pconv_ok(64, 32, 32, 128, 64, True)
+    assert not c1._pconv_ok(16, 64, 64, 64, 128, False) and not d4._pconv_ok(16, 32, 32, 128, 64, True)
+    assert not e4._pconv_ok(64, 4, 4, 256, 512, False)          # 256 rows
+    monkeypatch.setattr(nn, "_PCONV_MIN_GFLOP", 0.0)
+    assert c1._pconv_ok(16, 64, 64, 64, 128, False)

@@ -1,9 +1,12 @@
 // vf_conv.hip — 4x4 convolution / transposed convolution, forward + data-grad + weight-grad, for gfx950.
 //
-// Every pass is an implicit GEMM on the f32-input matrix core (v_mfma_f32_32x32x2_f32: exact fp32,
-// bit-for-bit a k-ordered fmaf chain, so the parity mode and the fast mode are the same code).
-// Activations are NHWC, weights are the reference tensors in channels-last (see include/vf_hip.h), which
-// makes a layer's three passes need only two kernels:
+// Every pass is an implicit GEMM on the matrix cores.  Three product modes (vf_ctx_set_mfma_mode, template parameter MODE):
+//   3 (default)  fp32 operands split exactly into three bf16 planes on their way into LDS (truncation by v_perm_b32), six
+//                cross terms on v_mfma_f32_32x32x16_bf16, fp32 accumulators: fp32-grade results at 1.1-1.4x mode 0's speed;
+//   0            v_mfma_f32_32x32x2_f32 on the fp32 operands (bit for bit a k-ordered fmaf chain);
+//   1            operands rounded to bf16, one term (opt-in).
+// Activations are NHWC, weights are the reference tensors in channels-last (see include/vf_hip.h), which makes a layer's
+// three passes need only two kernels:
 //
 //   k_igemm  C[m][n] = sum_{tap,c} A(m,tap,c) * Wt(n,tap,c)
 //            - conv forward            (reference: THNN SpatialConvolutionMM_updateOutput, train.lua:89)
@@ -11,14 +14,23 @@
 //            - full-conv forward       (= conv data-grad; THNN SpatialFullConvolution_updateOutput, train.lua:134)
 //            - full-conv data-grad     (= conv forward without bias)
 //            - the 4x4 -> 1x1 bottleneck conv and 1x1 -> 4x4 full-conv (plain GEMMs, weight-bandwidth bound)
-//   k_wgrad  dW[n][tap][c] = sum_p U(p,n) * V(p,tap,c), split over pixels p
-//            - conv / full-conv accGradParameters (the two differ only in which tensor is x and which is gy)
+//   k_wgrad / k_wgrad_group  dW[n][tap][c] = sum_p U(p,n) * V(p,tap,c), split over pixels p
+//            - conv / full-conv accGradParameters (the two differ only in which tensor is x and which is gy);
+//              the group form runs the weight gradients of a whole backward walk as one launch (vf_wgrad_group_*)
 //
-// Tiles: 256 threads = 4 waves of 32x32 MFMA tiles, BK = 16, LDS double-buffered, register-staged
-// global->LDS copies.  All global loads are UNCONDITIONAL (out-of-range lanes read element 0 and are zeroed by a
-// select) so the compiler keeps every load of tile k+1 in flight across the MFMAs of tile k and waits once,
-// before the LDS write.  Grid.z carries output parity and split-K; split-K partial slabs are combined by
-// k_slab_reduce4 in a fixed order (deterministic; no float atomics).
+// Since round 2 the forward / data-grad passes of layers with >= 1024 GEMM rows and >= 32 channels are served by the
+// planes-fed kernels of vf_pgemm.hip (operands split once by their producer, LDS-DMA staging), and the 3-channel
+// image-side forward by vf_conv_thin.hip; k_igemm keeps the small-row layers (4x4 maps, bottleneck), modes 0 / 1, the
+// thin-output passes (V = 0 scalar gather + col2im) and the callers that bring no planes.
+//
+// k_igemm tiles: 256 threads = 4 waves of 32x32 MFMA tiles (64x64, 64x128 or 128x128 block tiles), BK = 16 (modes 0 / 1)
+// or 32 channels per step (mode 3), LDS double-buffered, register-staged global->LDS copies through BUFFER loads with
+// hardware range checking (an out-of-range offset returns zeros: padding taps, ragged tile edges and split-K tails need
+// neither a branch nor a select), so every load of step k+1 stays in flight across the MFMAs of step k.  Grid.z carries
+// output parity and split-K; blocks are remapped so that the tiles sharing an operand panel land on one XCD's L2.
+// Split-K partial slabs are combined by k_slab_reduce* in a fixed order (deterministic; no float atomics); that pass — or
+// the GEMM epilogue when there is no split — also leaves the per-tile BatchNorm partial sums of the output when the next
+// module is a BatchNorm (vf_bn_fuse_next_fwd / _bwd: the separate statistics pass over the tensor disappears).
 #include <algorithm>
 #include <vector>
 #include <cstdlib>
@@ -1965,6 +1977,9 @@ int vf_internal_gconv_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, f
 static bool main_net_shape(int H, int W, int k, int stride, int pad) {
   return k == 4 && ((stride == 2 && pad == 1) || (stride == 1 && pad == 0 && H == 4 && W == 4)) && vf_is_pow2(H) && vf_is_pow2(W);
 }
+
+// 1 if this geometry runs on the matrix-core kernels, 0 if vf_conv_generic.hip serves it (include/vf_hip.h, "Shapes")
+VF_API int vf_conv_is_fast(int H, int W, int k, int stride, int pad) { return main_net_shape(H, W, k, stride, pad) ? 1 : 0; }
 
 int vf_internal_conv_thin_fwd(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, void* y_planes, int B, int H,
                               int W, int Cin, int Cout, int act, float slope);      // vf_conv_thin.hip

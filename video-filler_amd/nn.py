@@ -140,13 +140,17 @@ class SpatialConvolution(Module):
     #    the shape allows; `in_planes` / `g_planes` are the planes of the activation operand when its producer (a BatchNorm)
     #    already wrote them, else the tensor is split here (one pass) — weights come from weight_planes()
     def _pconv_ok(self, Bn, Hgrid, Wgrid, Cgather, Cout, transposed):
-        """The planes kernels pay where the GEMM has many rows per weight element: the weight planes cost a pass over the
-        weights per parameter update (16 bytes per element moved), which a pass with few rows (small batches on the deep,
-        wide layers: train_wholeim_input.lua at batchSize 4) never earns back.  Threshold: 1024 GEMM rows."""
+        """Where the planes kernels pay.  Their GEMMs are 1.2-1.4x faster than the fp32-operand ones, but the path has costs
+        that do not shrink with the batch: the weight planes (a pass over the weights per parameter update, 16 bytes per
+        element moved), the planes written beside every activation / gradient that feeds one, and a few more launches per
+        layer.  Measured on the same box: with 4.3 GFLOP per pass (train.lua's nets at batchSize 64) the
+        iteration is 2.6 % faster with them, with 1.1 GFLOP per pass (the video nets at batchSize 16) 3.5 % slower, and at
+        batchSize 4 (train_wholeim_input.lua) 2 % slower.  Threshold: 3 GFLOP per pass and 1024 GEMM rows."""
         B = get_backend()
         rows = Bn * Hgrid * Wgrid // (1 if transposed else 4)
+        gflop = 2.0 * rows * 16 * Cgather * Cout * 1e-9
         return (not _NO_PCONV and getattr(B, "mfma_mode", None) == "f32_3xbf16" and hasattr(B, "pconv_supported")
-                and self.kH == 4 and self.dH == 2 and self.padH == 1 and rows >= _PCONV_MIN_ROWS
+                and self.kH == 4 and self.dH == 2 and self.padH == 1 and rows >= _PCONV_MIN_ROWS and gflop >= _PCONV_MIN_GFLOP
                 and B.pconv_supported(Bn, Hgrid, Wgrid, Cgather, Cout, 4, 2, 1, transposed))
 
     def pconv_layer(self):
@@ -687,6 +691,7 @@ _NO_BN_GROUPS = bool(__import__("os").environ.get("VF_NO_BN_GROUPS"))
 _NO_BN_FUSE = bool(__import__("os").environ.get("VF_NO_BN_FUSE"))       # BatchNorm statistics from the neighbouring GEMMs
 _NO_PCONV = bool(__import__("os").environ.get("VF_NO_PCONV"))           # convolutions from pre-split bf16 planes
 _PCONV_MIN_ROWS = int(__import__("os").environ.get("VF_PCONV_MIN_ROWS", "1024"))
+_PCONV_MIN_GFLOP = float(__import__("os").environ.get("VF_PCONV_MIN_GFLOP", "3.0"))
 
 
 class Sequential(Module):
