@@ -9,7 +9,8 @@ from video_filler_amd.backend import get_backend
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hb = get_backend()
 # (name, gathered channels, gather grid H, output channels)   conv-like: x [B][H][H][Cin] -> [B][H/2][H/2][Cout]
-LAYERS = [("E2", 64, 64, 64), ("E3", 64, 32, 128), ("E4", 128, 16, 256), ("E5", 256, 8, 512), ("C1@2B", 64, 32, 128)]
+LAYERS = [("E2", 64, 64, 64), ("E3", 64, 32, 128), ("E4", 128, 16, 256), ("E5", 256, 8, 512), ("C1@2B", 64, 32, 128),
+          ("C2@2B", 128, 16, 256), ("C3@2B", 256, 8, 512)]
 
 
 only = os.environ.get("ONLY", "")

@@ -547,13 +547,15 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k_pconv(const PGemm p) {
 // no LDS store, so it puts no vmcnt(0) in front of the fragment reads.
 __device__ __forceinline__ void pg_dma16(unsigned lds_byte, unsigned voffset, __amdgpu_buffer_rsrc_t rsrc, unsigned soffset) {
   unsigned keep;
+  soffset = (unsigned)__builtin_amdgcn_readfirstlane((int)soffset);      // (wave-uniform by construction: pin it to an SGPR)
+  lds_byte = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "s"(lds_byte), "v"(voffset), "s"(rsrc), "s"(soffset)
                : "memory");
 }
 
-template <int BM, int BN, int NTAPS>
+template <int BM, int BN, int NTAPS, bool ILV = true>
 __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const PGemm p) {
   constexpr int CH = 64, WAVES_N = BN / 32, WAVES_M = BM / 32, NW = WAVES_M * WAVES_N;
   constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;                 // 8-row groups (one DMA instruction per plane) per wave
@@ -621,34 +623,41 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
   int w0 = 2 * (kh0 * 4 + kw0) * p.C, rowW = 8 * p.khs * p.C, colW = 2 * p.kws * p.C;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;      // LDS byte address of the buffers
 
-  auto dma_step = [&](int ch, auto TAP, int buf, bool live) {
-    constexpr int s_ = decltype(TAP)::value;
+  // one stage = NP pieces (a DMA instruction each: 8 rows x 128 bytes of one plane); piece J of tap TAP's stage
+  constexpr int NP = 3 * (AG + BG);
+  unsigned szero;                                   // an SGPR zero the compiler cannot fold into the asm's soffset operand
+  asm volatile("s_mov_b32 %0, 0" : "=s"(szero));
+  auto dma_piece = [&](int ch, auto TAP, auto PIECE, int buf, bool live) {
+    constexpr int s_ = decltype(TAP)::value, J = decltype(PIECE)::value;
     constexpr int th = NTAPS == 16 ? (((s_ >> 3) & 1) + 2 * ((s_ >> 1) & 1)) : (s_ >> 1);
     constexpr int tw = NTAPS == 16 ? (((s_ >> 2) & 1) + 2 * (s_ & 1)) : (s_ & 1);
     constexpr int t = (th << lgTW) | tw;
     const unsigned cb = (unsigned)(2 * CH) * (unsigned)ch;
-    const unsigned tA = (unsigned)(th * rowA + tw * colA) + cb, tW = (unsigned)(w0 + th * rowW + tw * colW) + cb;
     const unsigned base = lds0 + 2u * (unsigned)(buf * BUF_SZ);
-#pragma unroll
-    for (int i = 0; i < AG; ++i) {
+    if constexpr (J < 3 * AG) {
+      constexpr int i = J / 3, q = J % 3;
+      const unsigned tA = (unsigned)(th * rowA + tw * colA) + cb;
       const bool ok = live && ((a_mask[i] >> t) & 1u);
-      const unsigned off = ok ? a_byte[i] + tA : VF_OOB;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + a_lds[i], off, rsA, q * p.a_ps);
+      pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + a_lds[i], ok ? a_byte[i] + tA : VF_OOB, rsA, szero + q * p.a_ps);
+    } else {
+      constexpr int i = (J - 3 * AG) / 3, q = (J - 3 * AG) % 3;
+      const unsigned tW = (unsigned)(w0 + th * rowW + tw * colW) + cb;
+      pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + b_lds[i], live ? w_byte[i] : VF_OOB, rsW, q * p.w_ps + tW);
     }
-#pragma unroll
-    for (int i = 0; i < BG; ++i) {
-      const unsigned off = live ? w_byte[i] : VF_OOB;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + b_lds[i], off, rsW, q * p.w_ps + tW);
-    }
+  };
+  auto dma_step = [&](int ch, auto TAP, int buf, bool live) {
+    vf_static_for<NP>([&](auto J) { dma_piece(ch, TAP, J, buf, live); });
   };
 
   f32x16 acc[1][1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
   const int lr = lane & 31, lh = lane >> 5;
-  auto compute_step = [&](int buf) {
+  // MFMAs of the stage in `buf`; with ILV the NP DMA pieces of the NEXT stage are issued between them (one behind every
+  // second MFMA) instead of in front of them.  Kept as a switch (VF_PG_ILV=1) for the record: it did NOT pay — the stage's
+  // DMA issue is not what the MFMAs wait for (ablation: DMA-only 23.4 us, MFMA-only 22.7 us, both 28.8 us, neither 7.7 us on
+  // the 4.3 GFLOP pass; the two halves already overlap to within 5 us)
+  auto compute_step = [&](int buf, auto&& piece) {
     const __bf16* base = smem + buf * BUF_SZ;
     bf16x8 a[2][3], b[2][3];
     auto read_frag = [&](int g, int set) {
@@ -659,19 +668,25 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
       }
     };
     read_frag(0, 0);
-#pragma unroll
-    for (int g = 0; g < CH / 16; ++g) {
-      const int cs = g & 1;
-      if (g + 1 < CH / 16) read_frag(g + 1, cs ^ 1);
+    constexpr int NMF = 6 * (CH / 16), STRIDE = NMF / NP;
+    static_assert(STRIDE >= 1, "more DMA pieces than MFMAs in a stage");
+    vf_static_for<CH / 16>([&](auto GI) {
+      constexpr int g = decltype(GI)::value, cs = g & 1;
+      if constexpr (g + 1 < CH / 16) read_frag(g + 1, cs ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][0], acc[0][0], 0, 0, 0);
+      vf_static_for<6>([&](auto MI) {
+        constexpr int mi = decltype(MI)::value, idx = 6 * g + mi;
+        constexpr int qa = mi == 0 ? 1 : mi == 1 ? 0 : mi == 2 ? 2 : mi == 3 ? 0 : mi == 4 ? 1 : 0;
+        constexpr int qb = mi == 0 ? 1 : mi == 1 ? 2 : mi == 2 ? 0 : mi == 3 ? 1 : mi == 4 ? 0 : 0;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][qa], b[cs][qb], acc[0][0], 0, 0, 0);
+        if constexpr (ILV && idx % STRIDE == STRIDE - 1 && idx / STRIDE < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece(VfIntC<idx / STRIDE>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
   };
 
   // ---- main loop
@@ -687,14 +702,21 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
       // done reading the other buffer, which the next stage's DMAs overwrite
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (!(p.dbg & 1)) {
-        if constexpr (t + 1 < NTAPS)
-          dma_step(ch, VfIntC<t + 1>{}, buf ^ 1, true);
-        else
-          dma_step(ch + 1, VfIntC<0>{}, buf ^ 1, more);
-      }
+      auto next_piece = [&](auto J) {
+        if (!(p.dbg & 1)) {
+          if constexpr (t + 1 < NTAPS)
+            dma_piece(ch, VfIntC<t + 1>{}, J, buf ^ 1, true);
+          else
+            dma_piece(ch + 1, VfIntC<0>{}, J, buf ^ 1, more);
+        }
+      };
+      if constexpr (!ILV) vf_static_for<NP>(next_piece);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(p.dbg & 4)) compute_step(buf);
+      if (!(p.dbg & 4)) {
+        compute_step(buf, next_piece);
+      } else if constexpr (ILV) {
+        vf_static_for<NP>(next_piece);
+      }
     });
   }
   // the last stage's prefetch (dead: out-of-range zeros) must have landed before LDS is reused, and nobody may still be
@@ -739,7 +761,7 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
   const int gm = (int)vf_cdiv(g.M, t.bm), gn = (int)vf_cdiv(g.N, t.bn);
   const int64_t blocks = (int64_t)gm * gn * zpar;
   int ksplit = 1;
-  static const int env_split = getenv("VF_PG_SPLIT_BLOCKS") ? atoi(getenv("VF_PG_SPLIT_BLOCKS")) : 512;
+  static const int env_split = getenv("VF_PG_SPLIT_BLOCKS") ? atoi(getenv("VF_PG_SPLIT_BLOCKS")) : 340;   // a grid of 256 tiles (one per CU) is left whole: measured 27.6 vs 39.2 us (E4 data-gradient) against splitting it in two
   if (blocks < env_split * 3 / 4 && g.nchunks >= 2) {
     ksplit = (int)std::min<int64_t>(g.nchunks, vf_cdiv(env_split, blocks));
     const size_t slab_bytes = (size_t)g.out_elems * sizeof(float);
@@ -793,13 +815,20 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     char dname[64];
     snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
     const double dfl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
+    static const int env_ilv = getenv("VF_PG_ILV") ? atoi(getenv("VF_PG_ILV")) : 0;   // measured: no gain (gathers -2..-4 %, short-K scatters -25 %)
+#define PG_DMA(BM_, NT_, TH_)                                                                                              \
+  do {                                                                                                                     \
+    if (env_ilv) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<BM_, 64, NT_, true>), dim3(nt), dim3(TH_), g);         \
+    else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<BM_, 64, NT_, false>), dim3(nt), dim3(TH_), g);                \
+  } while (0)
     if (t.bm == 128) {
-      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16>), dim3(nt), dim3(512), g);
-      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4>), dim3(nt), dim3(512), g);
+      if (ntaps == 16) PG_DMA(128, 16, 512);
+      else PG_DMA(128, 4, 512);
     } else {
-      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16>), dim3(nt), dim3(256), g);
-      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4>), dim3(nt), dim3(256), g);
+      if (ntaps == 16) PG_DMA(64, 16, 256);
+      else PG_DMA(64, 4, 256);
     }
+#undef PG_DMA
     VF_LAUNCH_CHECK();
     if (ksplit > 1) {
       VfProf prof(ctx, slab_st ? "slab_reduce_pconv_bnstats" : "slab_reduce_pconv", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
