@@ -28,5 +28,10 @@ for k in sorted(acc):
     for n in sorted(acc[k]):
         v = acc[k][n]
         print("    %-40s %16.0f  (n=%d)" % (n, sum(v) / len(v), len(v)))
+    m = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    if m.get("SQ_BUSY_CU_CYCLES"):      # MFMA_BUSY counts per SIMD (4 per CU), BUSY_CU per CU
+        print("    => matrix pipe busy %.1f %% of the CU-busy cycles" % (100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * m["SQ_BUSY_CU_CYCLES"])))
+    if m.get("TCC_HIT_sum") is not None and m.get("TCC_MISS_sum") is not None and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
+        print("    => L2 hit rate %.1f %%; HBM read (FETCH_SIZE KiB x2, gfx950) %.1f MB" % (100.0 * m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 2 * m.get("FETCH_SIZE", 0) * 1024 / 1e6))
 PY
 cat $ROOT/gpurun_out/pmc_pconv_summary.txt

@@ -482,9 +482,10 @@ def test_planes_path_gate(hipb, monkeypatch):
     c1 = nn.SpatialConvolution(64, 128, 4, 4, 2, 2, 1, 1)
     e4 = nn.SpatialConvolution(256, 512, 4, 4, 2, 2, 1, 1)
     d4 = nn.SpatialFullConvolution(128, 64, 4, 4, 2, 2, 1, 1)
-    assert c1._pconv_ok(64, 64, 64, 64, 128, False) and e4._pconv_ok(64, 16, 16, 256, 512, False)
-    assert d4._pconv_ok(64, 32, 32, 128, 64, True)
-    assert not c1._pconv_ok(16, 64, 64, 64, 128, False) and not d4._pconv_ok(16, 32, 32, 128, 64, True)
+    # (batch, gather grid H, W, gathered channels, output channels): 4.3 GFLOP per pass at batchSize 64, 1.07 at 16
+    assert c1._pconv_ok(64, 32, 32, 64, 128, False) and e4._pconv_ok(64, 8, 8, 256, 512, False)
+    assert d4._pconv_ok(64, 16, 16, 128, 64, True)
+    assert not c1._pconv_ok(16, 32, 32, 64, 128, False) and not d4._pconv_ok(16, 16, 16, 128, 64, True)
     assert not e4._pconv_ok(64, 4, 4, 256, 512, False)          # 256 rows
     monkeypatch.setattr(nn, "_PCONV_MIN_GFLOP", 0.0)
-    assert c1._pconv_ok(16, 64, 64, 64, 128, False)
+    assert c1._pconv_ok(16, 32, 32, 64, 128, False)
