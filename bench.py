@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--sync-bn", action="store_true", help="N>1: all-reduce BatchNorm sums (big-batch parity mode)")
+    ap.add_argument("--fine-size", type=int, default=128, choices=[128, 256], help="wholeim only: 256 = the labelled NON-PARITY "
+                    "extension opt.ext256 (the reference's nets fail at that size: one more stride-2 stage in netD and around "
+                    "netG's bottleneck)")
     ap.add_argument("--force-dist", action="store_true", help="N=1: run the data-parallel path (RCCL init + all-reduce) anyway")
     ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep G's gradient exchange and Adam(G) inside the iteration "
                     "(default: they run behind the next iteration's netD real pass)")
@@ -130,17 +133,19 @@ def main():
     elif args.workload == "wholeim":
         # train_wholeim_input.lua:39-43 defaults: 3x3 array of patches in (27 channels), 2x2 out (12), nef = ngf = 192,
         # ndf = 128, nBottleneck 6400; wtgdl 0.5 exercises the GDL value path; fineSize 128
+        fs = args.fine_size
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, nc_in=27, nc_out=12, nef=192, ngf=192, ndf=128,
-                   weight_nomask=1, wtgdl=0.5)
+                   weight_nomask=1, wtgdl=0.5, fineSize=fs, ext256=(fs == 256))
         tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap)
-        full = torch.rand((args.batch, 12, 128, 128), generator=gen) * 2 - 1
-        mask = torch.zeros((args.batch, 12, 128, 128), dtype=torch.uint8)
-        mask[:, :, 32:96, 32:96] = 1
-        ctx = torch.rand((args.batch, 27, 128, 128), generator=gen) * 2 - 1
-        ctx[:, :, 32:96, 32:96] = 2 * (110.0 / 255.0) - 1
+        full = torch.rand((args.batch, 12, fs, fs), generator=gen) * 2 - 1
+        mask = torch.zeros((args.batch, 12, fs, fs), dtype=torch.uint8)
+        mask[:, :, fs // 4:3 * fs // 4, fs // 4:3 * fs // 4] = 1
+        ctx = torch.rand((args.batch, 27, fs, fs), generator=gen) * 2 - 1
+        ctx[:, :, fs // 4:3 * fs // 4, fs // 4:3 * fs // 4] = 2 * (110.0 / 255.0) - 1
         tr.set_batch(ctx, full, mask)
-        wl = ("train_wholeim_input.lua 27->12 channels nef=ngf=192 ndf=128 nBottleneck=%d wtgdl=0.5 fineSize=128 "
-              "batchSize=%d/GPU" % (args.nBottleneck, args.batch))
+        wl = ("train_wholeim_input.lua 27->12 channels nef=ngf=192 ndf=128 nBottleneck=%d wtgdl=0.5 fineSize=%d%s "
+              "batchSize=%d/GPU" % (args.nBottleneck, fs, " (NON-PARITY extension ext256: the reference's nets fail at this size)"
+                                    if fs == 256 else "", args.batch))
     else:
         predLen = 16 if args.workload == "vid16" else 4
         nc = 3 * predLen
@@ -367,7 +372,9 @@ def main():
         n_img = world * args.batch * args.steps
         out = {
             "metric": ("netG+netD fwd+bwd images/sec, 128x128 center-mask" if args.workload == "center" else
-                       "netG+netD fwd+bwd clips/sec, 128x128 (%s)" % args.workload),
+                       "netG+netD fwd+bwd clips/sec, %dx%d (%s)" % (args.fine_size if args.workload == "wholeim" else 128,
+                                                                      args.fine_size if args.workload == "wholeim" else 128,
+                                                                      args.workload + (" ext256" if args.fine_size == 256 else ""))),
             "value": round(n_img / dt, 2),
             "unit": "images/s" if args.workload == "center" else "clips/s",
             "n_gpus": world,

@@ -248,6 +248,10 @@ int vf_recon_grad_mix(vf_ctx* ctx, float* df_dg, const float* x, const float* t,
                       float c0, float c1, int band, int HW, int C, int64_t n, double* loss);
 /* nn.GDLCriterion(1):forward (gdl_criterion.lua:38-45) incl. the flattened-pairing quirk. */
 int vf_gdl_fwd(vf_ctx* ctx, const float* yhat, const float* y, int B, int H, int W, int C, double* loss);
+/* updateGradInput (gdl_criterion.lua:47-53): gyhat = d loss / d yhat, same shapes.  No driver of the reference calls it
+ * (train_vid_weighted.lua:523-528 adds the forward VALUE to the loss and uses the MSE gradient); provided so that
+ * nn.GDLCriterion is a complete nn.Criterion.  Derivative convention of THNN Abs / AbsCriterion: +1 at 0. */
+int vf_gdl_bwd(vf_ctx* ctx, const float* yhat, const float* y, float* gyhat, int B, int H, int W, int C);
 /* nn.MaskedMSECriterion(w) (MaskedMSECriterion.lua:29-41); mask is uint8 0/1. */
 int vf_masked_mse_fwd(vf_ctx* ctx, const float* x, const float* xhat, const uint8_t* mask, float w, int64_t n,
                       double* loss);

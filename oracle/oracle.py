@@ -486,6 +486,14 @@ class GDLCriterion:
         B, Cc, H, W = x.shape
         return lib().vfo_gdl_fwd(_p(x), _p(t), B, Cc, H, W)
 
+    def backward(self, x, t):
+        """gdl_criterion.lua:47-53 (no driver calls it)"""
+        B, Cc, H, W = x.shape
+        g = np.empty(x.shape, np.float32)
+        rc = lib().vfo_gdl_bwd(_p(x), _p(t), _p(g), B, Cc, H, W)
+        assert rc == 0, "GDLCriterion needs square maps"
+        return g
+
 
 class MaskedMSECriterion:
     def __init__(self, mWeight=1.0):
@@ -533,7 +541,8 @@ def _full(nIn, nOut, s2=True):
     return SpatialFullConvolution(nIn, nOut, 4, 4, 2, 2, 1, 1) if s2 else SpatialFullConvolution(nIn, nOut, 4, 4)
 
 
-def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth=False, noise_nz=0, half_last=False):
+def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth=False, noise_nz=0, half_last=False,
+               extra_bottleneck_stage=False):
     """noise_nz > 0: the noiseGen generator of train.lua:109-124 (input {context, noise[B, nz, 1, 1]}).
     half_last: train_logo_withmask.lua:95-98 — the extra decoder layer is ngf -> ngf/2 (BN over ngf/2).
     train.lua:87-148 (extra_decoder_layer=False, output nc x 64 x 64) and
@@ -547,6 +556,8 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth
     netE.add(_conv(nef, nef * 2)).add(SpatialBatchNormalization(nef * 2)).add(LeakyReLU(0.2, True))
     netE.add(_conv(nef * 2, nef * 4)).add(SpatialBatchNormalization(nef * 4)).add(LeakyReLU(0.2, True))
     netE.add(_conv(nef * 4, nef * 8)).add(SpatialBatchNormalization(nef * 8)).add(LeakyReLU(0.2, True))
+    if extra_bottleneck_stage:      # the labelled 256x256 extension (not in the reference: see video-filler_amd/trainers.py)
+        netE.add(_conv(nef * 8, nef * 8)).add(SpatialBatchNormalization(nef * 8)).add(LeakyReLU(0.2, True))
     netE.add(_conv(nef * 8, nBottleneck, s2=False))
     netG = Sequential()
     nz_size = nBottleneck
@@ -559,6 +570,8 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, smooth
         netG.add(netE)
     netG.add(SpatialBatchNormalization(nz_size)).add(LeakyReLU(0.2, True))
     netG.add(_full(nz_size, ngf * 8, s2=False)).add(SpatialBatchNormalization(ngf * 8)).add(ReLU(True))
+    if extra_bottleneck_stage:
+        netG.add(_full(ngf * 8, ngf * 8)).add(SpatialBatchNormalization(ngf * 8)).add(ReLU(True))
     netG.add(_full(ngf * 8, ngf * 4)).add(SpatialBatchNormalization(ngf * 4)).add(ReLU(True))
     netG.add(_full(ngf * 4, ngf * 2)).add(SpatialBatchNormalization(ngf * 2)).add(ReLU(True))
     netG.add(_full(ngf * 2, ngf)).add(SpatialBatchNormalization(ngf)).add(ReLU(True))
@@ -576,7 +589,7 @@ def _acts(smooth):
     return (lambda negval, inplace: globals()["LeakyReLU"](1.0, inplace)), (lambda inplace: globals()["LeakyReLU"](1.0, inplace))
 
 
-def build_netD(nc, ndf, extra_first_layer, smooth=False, conditionAdv=False):
+def build_netD(nc, ndf, extra_first_layer, smooth=False, conditionAdv=False, extra_last_layer=False):
     """train.lua:157-199 (64x64 input; conditionAdv: input {context 128x128, prediction 64x64}, :158-180) and
     train_vid_weighted.lua:213-236 (128x128 input, extra floor(ndf/2)-wide first layer)."""
     LeakyReLU, ReLU = _acts(smooth)
@@ -598,6 +611,8 @@ def build_netD(nc, ndf, extra_first_layer, smooth=False, conditionAdv=False):
     netD.add(_conv(ndf, ndf * 2)).add(SpatialBatchNormalization(ndf * 2)).add(LeakyReLU(0.2, True))
     netD.add(_conv(ndf * 2, ndf * 4)).add(SpatialBatchNormalization(ndf * 4)).add(LeakyReLU(0.2, True))
     netD.add(_conv(ndf * 4, ndf * 8)).add(SpatialBatchNormalization(ndf * 8)).add(LeakyReLU(0.2, True))
+    if extra_last_layer:      # the labelled 256x256 extension (not in the reference: its netD fails at that size)
+        netD.add(_conv(ndf * 8, ndf * 8)).add(SpatialBatchNormalization(ndf * 8)).add(LeakyReLU(0.2, True))
     netD.add(_conv(ndf * 8, 1, s2=False)).add(Sigmoid())
     netD.add(View(1).setNumInputDims(3))
     return netD
@@ -775,8 +790,9 @@ class VidTrainer:
         # logoNet: train_logo_withmask.lua:95-98 — the last decoder stage is ngf -> ngf/2 -> nc; its closures are this
         # class's with predLen = 1, weight_nomask = 1 (weights of ones), wtgdl = 0
         self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, o.get("smooth", False),
-                               half_last=bool(o.get("logoNet", False)))
-        self.netD = build_netD(self.nc_out, o["ndf"], True, o.get("smooth", False))
+                               half_last=bool(o.get("logoNet", False)), extra_bottleneck_stage=bool(o.get("ext256", False)))
+        self.netD = build_netD(self.nc_out, o["ndf"], True, o.get("smooth", False),
+                               extra_last_layer=bool(o.get("ext256", False)))
         weights_init(self.netG, rng)
         weights_init(self.netD, rng)
         self.netI = None                  # withInit: the initializer net (train_vid_weighted.lua:260-264), set by the caller

@@ -448,6 +448,38 @@ VFO_API double vfo_gdl_fwd(const float* yhat, const float* y, int B, int C, int 
   return s12 / cnt + s34 / cnt;  // ParallelCriterion, weights 1, each AbsCriterion sizeAverage
 }
 
+// nn.GDLCriterion(1) updateGradInput (gdl_criterion.lua:47-53): d loss / d Yhat.  Never called by a driver of the reference
+// (train_vid_weighted.lua:523-528 uses the forward value only); restated for the nn.Criterion protocol.
+//   crit:updateGradInput = nn.AbsCriterion per output, target 0, sizeAverage: g_term = (term >= 0 ? 1 : -1) / count  (THNN
+//   AbsCriterion_updateGradInput); term12 = term1 - term2 with term2 = |Yhat_i2 - Yhat_i1| the only part that depends on Yhat:
+//   g_d2 = -g_term12 * (d2 >= 0 ? 1 : -1) (THNN Abs_updateGradInput), d2 = Yhat_i2 - Yhat_i1 in the flattened pairing;
+//   CSubTable hands +g_d2 to its first input and -g_d2 to its second; the negative SpatialZeroPaddings put zeros back
+//   where they cropped.  The same for term34 with the j crops.
+VFO_API int vfo_gdl_bwd(const float* yhat, const float* y, float* gyhat, int B, int C, int H, int W) {
+  if (H != W) return 1;
+  const size_t planes = (size_t)B * C, m = (size_t)(H - 1) * W;
+  const float norm = (float)(1.0 / ((double)planes * (double)m));
+  for (size_t p = 0; p < planes; ++p) {
+    const float* Y = y + p * H * W;
+    const float* Yh = yhat + p * H * W;
+    float* G = gyhat + p * H * W;
+    for (size_t i = 0; i < (size_t)H * W; ++i) G[i] = 0.f;
+    for (size_t k = 0; k < m; ++k) {
+      const size_t r = k / (W - 1), c = k % (W - 1);
+      const size_t i2 = r * W + c, j2 = i2 + 1, i1 = k, j1 = W + k;
+      const float d1 = Y[i2] - Y[i1], d2 = Yh[i2] - Yh[i1], d3 = Y[j2] - Y[j1], d4 = Yh[j2] - Yh[j1];
+      const float t12 = std::fabs(d1) - std::fabs(d2), t34 = std::fabs(d3) - std::fabs(d4);
+      const float g2 = -(t12 >= 0 ? norm : -norm) * (d2 >= 0 ? 1.f : -1.f);
+      const float g4 = -(t34 >= 0 ? norm : -norm) * (d4 >= 0 ? 1.f : -1.f);
+      G[i2] += g2;
+      G[i1] -= g2;
+      G[j2] += g4;
+      G[j1] -= g4;
+    }
+  }
+  return 0;
+}
+
 // nn.MaskedMSECriterion(w) (MaskedMSECriterion.lua:7-42).  wM = (1-w)*M + w ;
 // L = mean(|wM * (X - Xhat)^2|) ; dL/dX = (2/N) * wM * (X - Xhat) * sign(wM*(X-Xhat)^2 >= 0 -> +1).
 VFO_API double vfo_masked_mse_fwd(const float* x, const float* xhat, const uint8_t* mask, float w,

@@ -297,6 +297,9 @@ class OracleBackend:
     def gdl_fwd(self, yhat, y, loss):
         loss[0] = O.GDLCriterion(1).forward(_np(yhat), _np(y))
 
+    def gdl_bwd(self, yhat, y, gyhat):
+        _put(gyhat, O.GDLCriterion(1).backward(_np(yhat), _np(y)))
+
     def masked_mse_fwd(self, x, xhat, mask_u8, w, loss):
         c = O.MaskedMSECriterion(w)
         c.setMask(np.ascontiguousarray(mask_u8.contiguous().numpy()))

@@ -516,3 +516,23 @@ def test_batchnorm_statistics_from_the_neighbouring_gemms(kind, widths, Bn, H, g
     for k, tol in (("y", 2e-5), ("gx", 1e-4), ("g", 1e-4), ("rm", 2e-5), ("rv", 2e-5)):
         e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-30))
         assert e <= tol, (k, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (4, 12, 32, 32), (2, 48, 128, 128)])
+def test_gdl_backward(shape, oracle, hipb):
+    """vf_gdl_bwd (gdl_criterion.lua:47-53) against the oracle: same four pairings per element, so bit-exact up to the order of at
+    most four additions; and through nn.GDLCriterion.backward."""
+    from video_filler_amd import nn
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    t = rng.standard_normal(shape).astype(np.float32)
+    want = oracle.GDLCriterion(1).backward(x, t)
+    crit = nn.GDLCriterion(1)
+    dx, dt = to_dev(x, hipb), to_dev(t, hipb)
+    got = to_np(crit.backward(dx, dt))
+    norm = 1.0 / (shape[0] * shape[1] * (shape[2] - 1) * shape[3])
+    assert np.abs(got - want).max() <= 1e-6 * norm * 4
+    assert abs(float(crit.forward(dx, dt)) - oracle.GDLCriterion(1).forward(x, t)) < 1e-6
+    with pytest.raises(Exception):
+        hipb.gdl_bwd(hipb.empty_act(1, 3, 8, 4), hipb.empty_act(1, 3, 8, 4), hipb.empty_act(1, 3, 8, 4))

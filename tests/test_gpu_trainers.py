@@ -168,7 +168,7 @@ def test_center_trainer_option_branches(variant, smooth, oracle, hipb):
 
 @pytest.mark.parametrize("batch_d", [False, True])
 @pytest.mark.parametrize("smooth", [True, False])
-@pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim", "logoNet", "withInit"])
+@pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim", "logoNet", "withInit", "ext256"])
 def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
     from video_filler_amd.trainers import VidTrainer, build_netG
     if variant == "weighted":          # train_vid_weighted.lua defaults, predLen = 2
@@ -180,6 +180,9 @@ def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
     elif variant == "withInit":        # train_vid_weighted.lua:401-405: initializer net + fillIn before the closures
         opt = dict(nBottleneck=64, predLen=1)
         nc_in = nc_out = 3
+    elif variant == "ext256":          # the labelled 256x256 extension: one more stride-2 stage in netD and around netG's
+        opt = dict(nBottleneck=32, predLen=1, nef=16, ngf=16, ndf=16, fineSize=256, ext256=True, wtgdl=0.5)   # bottleneck
+        nc_in = nc_out = 3             # (not parity with the reference, which fails at that size: parity with the oracle's same nets)
     elif variant == "nomask0_gdl":     # weight_nomask = 0 -> masked compose; GDL value path
         opt = dict(nBottleneck=64, predLen=1, weight_nomask=0, wtgdl=0.5)
         nc_in = nc_out = 3
@@ -208,7 +211,8 @@ def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
     # bars are 5x wider for the real nets of that variant (the smooth nets hold the plain ones).
     amp = 5.0 if (variant == "withInit" and not smooth) else 1.0
     for it in range(2):
-        ctx, full, mask = oracle.synth_vid_batch(4, np.random.default_rng(20 + it), nc_in, nc_out)   # B = 4: BatchNorm over
+        ctx, full, mask = oracle.synth_vid_batch(4, np.random.default_rng(20 + it), nc_in, nc_out,    # B = 4: BatchNorm over
+                                                 fineSize=opt.get("fineSize", 128))
         # the 1x1 bottleneck needs more than 2 samples to be well conditioned
         ref.set_batch(ctx, full, mask)
         tr.set_batch(torch.from_numpy(ctx), torch.from_numpy(full), torch.from_numpy(mask))

@@ -228,20 +228,31 @@ def test_vid_trainer_closures_match_oracle(variant, batch_d, cpu_backend):
     assert rel_err(tr.netG.reference_flat(grads=True).numpy(), ref.gradParametersG) < 2e-5
 
 
-@pytest.mark.parametrize("variant", ["logoNet", "withInit"])
+@pytest.mark.parametrize("variant", ["logoNet", "withInit", "ext256"])
 def test_vid_trainer_option_branches_match_oracle(variant, cpu_backend):
     """train_logo_withmask.lua's generator (last decoder stage ngf -> ngf/2) and train_vid_weighted.lua's withInit path
-    (initializer net in training mode, inpaint_utils.fillIn, then the usual closures)."""
+    (initializer net in training mode, inpaint_utils.fillIn, then the usual closures); ext256: the labelled fineSize-256
+    extension (one more stride-2 stage in netD and on either side of netG's bottleneck — the reference's own netD fails at
+    that size, SURVEY D5, so this is parity with the oracle's same extension, not with the reference)."""
     from video_filler_amd.trainers import VidTrainer, build_netG
     from oracle import oracle as O
+    fs = 128
     if variant == "logoNet":
         opt = dict(SMALL, predLen=1, weight_nomask=1, wtgdl=0, logoNet=True)
+    elif variant == "ext256":
+        opt = dict(SMALL, predLen=1, fineSize=256, ext256=True, wtgdl=0.5)
+        fs = 256
+        with pytest.raises(AssertionError, match="ext256"):
+            VidTrainer(dict(opt, ext256=False))
     else:
         opt = dict(SMALL, predLen=1)
     ref = O.VidTrainer(opt, np.random.default_rng(2))
     tr = VidTrainer(opt)
     if variant == "logoNet":
         assert tr.netG.leaves()[-2].nInputPlane == SMALL["ngf"] // 2
+    elif variant == "ext256":
+        assert len([m for m in tr.netD.leaves() if m.type_name() == "nn.SpatialConvolution"]) == 7
+        assert len([m for m in tr.netG.leaves() if "Convolution" in m.type_name()]) == 14      # 7 + 7 (one more on each side)
     else:
         rI = O.build_netG(3, 3, 8, 8, 16, True)
         O.weights_init(rI, np.random.default_rng(8))
@@ -252,7 +263,7 @@ def test_vid_trainer_option_branches_match_oracle(variant, cpu_backend):
         ref.netI = rI
         tr.set_initializer(hI)
     _load(tr, ref)
-    ctx, full, mask = O.synth_vid_batch(3, np.random.default_rng(9), 3)
+    ctx, full, mask = O.synth_vid_batch(3, np.random.default_rng(9), 3, fineSize=fs)
     ref.set_batch(ctx, full, mask)
     tr.set_batch(torch.from_numpy(ctx), torch.from_numpy(full), torch.from_numpy(mask))
     ref.step()

@@ -254,3 +254,33 @@ def test_sequential_protocol_and_flat_parameters(oracle):
     gi = net.updateGradInput(x, gy)            # data-grad only: parameters untouched (train.lua:371)
     np.testing.assert_array_equal(gflat, g1)
     assert gi.shape == x.shape
+
+
+def test_gdl_backward_against_autograd_of_the_flattened_pairing(oracle):
+    """gdl_criterion.lua:47-53 (never called by a driver; part of the nn.Criterion protocol).  The forward restated with
+    torch ops — crops flattened and paired element by element, as CSubTable does on tensors of equal element count —
+    and differentiated by autograd; random data keeps every |.| away from its kink, where THNN's +1 and torch's 0 differ."""
+    rng = np.random.default_rng(12)
+    B, Cc, H = 3, 4, 8
+    x = rng.standard_normal((B, Cc, H, H)).astype(np.float32)
+    t = rng.standard_normal((B, Cc, H, H)).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    tt = torch.from_numpy(t).double()
+    flat = lambda a: a.reshape(B, Cc, -1)
+    i1 = lambda a: flat(a[:, :, :H - 1, :])
+    j1 = lambda a: flat(a[:, :, 1:, :])
+    i2 = lambda a: flat(a[:, :, :, :H - 1])
+    j2 = lambda a: flat(a[:, :, :, 1:])
+    t12 = (i2(tt) - i1(tt)).abs() - (i2(xt) - i1(xt)).abs()
+    t34 = (j2(tt) - j1(tt)).abs() - (j2(xt) - j1(xt)).abs()
+    loss = t12.abs().mean() + t34.abs().mean()
+    loss.backward()
+    crit = oracle.GDLCriterion(1)
+    assert abs(crit.forward(x, t) - float(loss)) < 1e-6
+    g = crit.backward(x, t)
+    np.testing.assert_allclose(g, xt.grad.numpy(), rtol=1e-5, atol=1e-9)
+    # the convention at the kinks: input == target makes every term12 / term34 exactly 0 -> AbsCriterion's +1 branch
+    g0 = crit.backward(t, t)
+    assert np.isfinite(g0).all() and np.abs(g0).max() <= 4.0 / (B * Cc * (H - 1) * H) + 1e-12
+    # (the first W-1 pairings of the i kind pair an element with itself — i2[k] and i1[k] are both X[0][k] — so their d is
+    #  exactly 0 in every input; the +g and -g they hand out land on the same element and cancel, whatever the sign choice)

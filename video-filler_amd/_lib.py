@@ -85,6 +85,7 @@ SIGNATURES = {
     "vf_mse_bwd": (i32, [vp, vp, vp, vp, i64]),
     "vf_recon_grad_mix": (i32, [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i64, vp]),
     "vf_gdl_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "vf_gdl_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32]),
     "vf_masked_mse_fwd": (i32, [vp, vp, vp, vp, f32, i64, vp]),
     "vf_masked_mse_bwd": (i32, [vp, vp, vp, vp, f32, vp, i64]),
     "vf_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, vp]),

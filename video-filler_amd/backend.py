@@ -543,6 +543,10 @@ class HipBackend:
         B, Cc, H, W = y.shape
         self._c("vf_gdl_fwd", _ptr(yhat), _ptr(y), B, H, W, Cc, _ptr(loss))
 
+    def gdl_bwd(self, yhat, y, gyhat):
+        B, Cc, H, W = y.shape
+        self._c("vf_gdl_bwd", _ptr(yhat), _ptr(y), _ptr(gyhat), B, H, W, Cc)
+
     def masked_mse_fwd(self, x, xhat, mask_u8, w, loss):
         self._c("vf_masked_mse_fwd", _ptr(x), _ptr(xhat), _ptr(mask_u8), w, x.numel(), _ptr(loss))
 

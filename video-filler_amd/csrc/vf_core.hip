@@ -449,6 +449,49 @@ VF_API int vf_gdl_fwd(vf_ctx* ctx, const float* yhat, const float* y, int B, int
   return 0;
 }
 
+// nn.GDLCriterion(1) updateGradInput (gdl_criterion.lua:47-53), NHWC, gather form: every element of gYhat collects the (up to)
+// four pairings it takes part in — as an element of the i2 crop (cols 0..W-2), of i1 (rows 0..H-2), of j2 (cols 1..W-1) and of
+// j1 (rows 1..H-1) — so nothing is accumulated across threads.  pair(k) = the gradient handed to d = X_2[k] - X_1[k]:
+//   -(sign_ge0(|Y_2[k] - Y_1[k]| - |d|) / count) * sign_ge0(d)      (THNN AbsCriterion / Abs: derivative +1 at 0)
+__global__ __launch_bounds__(256) void k_gdl_bwd(const float* __restrict__ yh, const float* __restrict__ y, float* __restrict__ g,
+                                                 int B, int H, int W, int C, float norm) {
+  const int64_t m = (int64_t)(H - 1) * W, hw = (int64_t)H * W;
+  const int64_t total = (int64_t)B * hw * C;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += stride) {
+    const int c = (int)(e % C);
+    const int64_t q = (e / C) % hw, b = e / (C * hw);
+    const int64_t base = b * hw;
+    const int64_t r = q / W, cc = q % W;
+    auto at = [&](const float* t, int64_t pos) { return t[(base + pos) * C + c]; };
+    // i-pairing k: i2 = (k / (W-1)) * W + k % (W-1), i1 = k;  j-pairing k: j2 = i2 + 1, j1 = W + k
+    auto pair_i = [&](int64_t k) {
+      const int64_t i2 = (k / (W - 1)) * W + k % (W - 1);
+      const float d = at(yh, i2) - at(yh, k), t12 = fabsf(at(y, i2) - at(y, k)) - fabsf(d);
+      return -(t12 >= 0.f ? norm : -norm) * (d >= 0.f ? 1.f : -1.f);
+    };
+    auto pair_j = [&](int64_t k) {
+      const int64_t j2 = (k / (W - 1)) * W + k % (W - 1) + 1;
+      const float d = at(yh, j2) - at(yh, W + k), t34 = fabsf(at(y, j2) - at(y, W + k)) - fabsf(d);
+      return -(t34 >= 0.f ? norm : -norm) * (d >= 0.f ? 1.f : -1.f);
+    };
+    float acc = 0.f;        // same order as the oracle's scatter visits an element is not needed: at most four terms, summed
+    if (cc < W - 1) acc += pair_i(r * (W - 1) + cc);          // in ascending pairing index per kind
+    if (q < m) acc -= pair_i(q);
+    if (cc >= 1) acc += pair_j(r * (W - 1) + cc - 1);
+    if (q >= W) acc -= pair_j(q - W);
+    g[e] = acc;
+  }
+}
+VF_API int vf_gdl_bwd(vf_ctx* ctx, const float* yhat, const float* y, float* gyhat, int B, int H, int W, int C) {
+  VF_REQUIRE(H == W, "GDLCriterion needs square maps (the reference's CSubTable pairs H x (W-1) with (H-1) x W)");
+  const int64_t cnt = (int64_t)B * C * (H - 1) * W;
+  hipLaunchKernelGGL(k_gdl_bwd, dim3(grid_for((int64_t)B * C * H * W, 4)), dim3(256), 0, ctx->stream, yhat, y, gyhat, B, H, W, C,
+                     (float)(1.0 / (double)cnt));
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void k_masked_mse(const float* __restrict__ x, const float* __restrict__ xh,
                                                     const uint8_t* __restrict__ mask, float w, float* __restrict__ gx,
                                                     int64_t n, double inv_n, double* __restrict__ loss) {

@@ -59,6 +59,7 @@ int vf_bce_bwd(vf_ctx*, const float* x, float label, float* gx, int n);
 int vf_mse_fwd(vf_ctx*, const float* x, const float* t, int64_t n, double* loss);
 int vf_mse_bwd(vf_ctx*, const float* x, const float* t, float* gx, int64_t n);
 int vf_gdl_fwd(vf_ctx*, const float* yhat, const float* y, int B, int H, int W, int C, double* loss);
+int vf_gdl_bwd(vf_ctx*, const float* yhat, const float* y, float* gyhat, int B, int H, int W, int C);
 int vf_masked_mse_fwd(vf_ctx*, const float* x, const float* xhat, const uint8_t* mask, float w, int64_t n, double* loss);
 int vf_masked_mse_bwd(vf_ctx*, const float* x, const float* xhat, const uint8_t* mask, float w, float* gx, int64_t n);
 int vf_adam_step(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int32_t* t_dev);
@@ -371,13 +372,19 @@ function MSE:updateGradInput(input, target)
    check(C.vf_mse_bwd(hipnn.ctx, fptr(input), fptr(target), fptr(self.gradInput), input:nElement()))
    return self.gradInput
 end
-local GDL = torch.class('hipnn.GDLCriterion', 'nn.Criterion')      -- forward value only, as the drivers use it
-function GDL:__init(alpha) assert((alpha or 1) == 1); self.slot = hipnn.DoubleTensor(1) end
+local GDL = torch.class('hipnn.GDLCriterion', 'nn.Criterion')      -- the drivers use the forward value only
+function GDL:__init(alpha) assert((alpha or 1) == 1); self.gradInput = hipnn.Tensor(); self.slot = hipnn.DoubleTensor(1) end
 function GDL:updateOutput(input, target)
    check(C.vf_gdl_fwd(hipnn.ctx, fptr(input), fptr(target), input:size(1), input:size(3), input:size(4), input:size(2),
                       ffi.cast('double*', self.slot:data())))
    self.output = readLoss(self.slot)
    return self.output
+end
+function GDL:updateGradInput(input, target)      -- gdl_criterion.lua:47-53
+   self.gradInput = hipnn.resizeLike(self.gradInput, input)
+   check(C.vf_gdl_bwd(hipnn.ctx, fptr(input), fptr(target), fptr(self.gradInput), input:size(1), input:size(3), input:size(4),
+                      input:size(2)))
+   return self.gradInput
 end
 local MMSE = torch.class('hipnn.MaskedMSECriterion', 'nn.Criterion')
 function MMSE:__init(mWeight) self.mWeight = mWeight or 1; self.gradInput = hipnn.Tensor(); self.slot = hipnn.DoubleTensor(1) end

@@ -1198,7 +1198,8 @@ class MSECriterion(_Criterion):
 
 
 class GDLCriterion(_Criterion):
-    """nn.GDLCriterion(alpha) — gdl_criterion.lua:6; only :forward is consumed (train_vid_weighted.lua:524)."""
+    """nn.GDLCriterion(alpha) — gdl_criterion.lua:6; the drivers consume only :forward (train_vid_weighted.lua:524);
+    :backward (gdl_criterion.lua:47-53) completes the nn.Criterion protocol."""
 
     def __init__(self, alpha=1):
         super().__init__()
@@ -1209,6 +1210,16 @@ class GDLCriterion(_Criterion):
         get_backend().gdl_fwd(to_nhwc(input), to_nhwc(target), slot)
         self.output = DeviceScalar.of(slot)
         return self.output
+
+    def backward(self, input, target):
+        B = get_backend()
+        x = to_nhwc(input)
+        if self.gradInput is None or tuple(self.gradInput.shape) != tuple(x.shape):
+            self.gradInput = B.empty_act(*x.shape)
+        B.gdl_bwd(x, to_nhwc(target), self.gradInput)
+        return self.gradInput
+
+    updateGradInput = backward
 
 
 class MaskedMSECriterion(_Criterion):

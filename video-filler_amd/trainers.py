@@ -58,10 +58,15 @@ def _acts(smooth):
 
 
 def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=True, lazy_zero=True, smooth=False, noise_nz=0,
-               half_last=False):
+               half_last=False, extra_bottleneck_stage=False):
     """train.lua:87-148 (64x64 output) / train_vid_weighted.lua:112-176 (extra ngf->ngf layer, 128x128 output).
     noise_nz > 0: the noiseGen generator (train.lua:109-124), input {context, noise [B, nz, 1, 1]};
-    half_last: train_logo_withmask.lua:95-98, the extra decoder layer is ngf -> ngf/2."""
+    half_last: train_logo_withmask.lua:95-98, the extra decoder layer is ngf -> ngf/2.
+    extra_bottleneck_stage: NOT in the reference — the labelled 256x256 extension (opt.ext256).  As written the generator
+    "works" at fineSize 256 with a 5x5 bottleneck map, i.e. a 4x4 valid conv 8x8 -> 5x5 and its full-conv twin:
+    non-power-of-two maps that only the thin-layer generic kernels serve.  The extension keeps the bottleneck at 1x1
+    instead: one more stride-2 stage nef*8 -> nef*8 (8x8 -> 4x4) in front of it and ngf*8 -> ngf*8 (4x4 -> 8x8) behind it,
+    so every layer stays on the matrix-core path — the same kind of addition netD needs at that size."""
     BN = nn.SpatialBatchNormalization
     LReLU, ReLU = _acts(smooth)
     netE = nn.Sequential(fuse, lazy_zero)
@@ -70,6 +75,8 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=T
     netE.add(_conv(nef, nef * 2)).add(BN(nef * 2)).add(LReLU(0.2, True))
     netE.add(_conv(nef * 2, nef * 4)).add(BN(nef * 4)).add(LReLU(0.2, True))
     netE.add(_conv(nef * 4, nef * 8)).add(BN(nef * 8)).add(LReLU(0.2, True))
+    if extra_bottleneck_stage:
+        netE.add(_conv(nef * 8, nef * 8)).add(BN(nef * 8)).add(LReLU(0.2, True))
     netE.add(_conv(nef * 8, nBottleneck, s2=False))
     netG = nn.Sequential(fuse, lazy_zero)
     nz_size = nBottleneck
@@ -82,6 +89,8 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=T
         netG.add(netE)
     netG.add(BN(nz_size)).add(LReLU(0.2, True))
     netG.add(_full(nz_size, ngf * 8, s2=False)).add(BN(ngf * 8)).add(ReLU(True))
+    if extra_bottleneck_stage:
+        netG.add(_full(ngf * 8, ngf * 8)).add(BN(ngf * 8)).add(ReLU(True))
     netG.add(_full(ngf * 8, ngf * 4)).add(BN(ngf * 4)).add(ReLU(True))
     netG.add(_full(ngf * 4, ngf * 2)).add(BN(ngf * 2)).add(ReLU(True))
     netG.add(_full(ngf * 2, ngf)).add(BN(ngf)).add(ReLU(True))
@@ -93,9 +102,12 @@ def build_netG(nc_in, nc_out, nef, ngf, nBottleneck, extra_decoder_layer, fuse=T
     return netG
 
 
-def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True, smooth=False, conditionAdv=False):
+def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True, smooth=False, conditionAdv=False, extra_last_layer=False):
     """train.lua:157-199 (64x64 input) / train_vid_weighted.lua:213-236 (extra floor(ndf/2) layer, 128x128 input).
-    conditionAdv (train.lua:158-180): input {context 128x128, prediction 64x64}, two 5x5 stride-2 branches joined."""
+    conditionAdv (train.lua:158-180): input {context 128x128, prediction 64x64}, two 5x5 stride-2 branches joined.
+    extra_last_layer: NOT in the reference — the labelled 256x256 extension (opt.ext256): one more stride-2 block
+    ndf*8 -> ndf*8 in front of the final 4x4 conv, without which the reference's own netD yields 5x5 scores per sample at
+    fineSize 256 and its BCECriterion fails on the label's size."""
     BN = nn.SpatialBatchNormalization
     LReLU, _ = _acts(smooth)
     netD = nn.Sequential(fuse, lazy_zero)
@@ -117,9 +129,24 @@ def build_netD(nc, ndf, extra_first_layer, fuse=True, lazy_zero=True, smooth=Fal
     netD.add(_conv(ndf, ndf * 2)).add(BN(ndf * 2)).add(LReLU(0.2, True))
     netD.add(_conv(ndf * 2, ndf * 4)).add(BN(ndf * 4)).add(LReLU(0.2, True))
     netD.add(_conv(ndf * 4, ndf * 8)).add(BN(ndf * 8)).add(LReLU(0.2, True))
+    if extra_last_layer:
+        netD.add(_conv(ndf * 8, ndf * 8)).add(BN(ndf * 8)).add(LReLU(0.2, True))
     netD.add(_conv(ndf * 8, 1, s2=False)).add(nn.Sigmoid())
     netD.add(nn.View(1).setNumInputDims(3))
     return netD
+
+
+def _ext256(o):
+    """fineSize 256 (BASELINE configs[4] as quoted): the reference's netD does not work there and its netG only
+    with a 5x5 bottleneck map — so that size runs only as the labelled extension `ext256=True`: one more stride-2 stage in
+    netD (build_netD extra_last_layer) and around netG's bottleneck (build_netG extra_bottleneck_stage)."""
+    fs = o.get("fineSize", 128)
+    if fs != 256:
+        assert not o.get("ext256"), "ext256 is the fineSize-256 extension"
+        return False
+    assert o.get("ext256"), ("fineSize 256: the reference's netD yields 5x5 scores per sample there and its criterion fails "
+                             "(SURVEY D5); this size runs only as the labelled non-parity extension opt.ext256 (one more netD block)")
+    return True
 
 
 def weights_init(net, gen):
@@ -658,8 +685,8 @@ class VidTrainer(_TrainerBase):
         # logoNet: train_logo_withmask.lua:95-98 (last decoder stage ngf -> ngf/2 -> nc); that script's closures are
         # this class's with predLen = 1, weight_nomask = 1 (weights of ones) and wtgdl = 0
         self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, fuse, lazy_zero, sm,
-                               half_last=bool(o.get("logoNet", False)))
-        self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero, sm)
+                               half_last=bool(o.get("logoNet", False)), extra_bottleneck_stage=_ext256(o))
+        self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero, sm, extra_last_layer=_ext256(o))
         self.netI = None                 # withInit: set_initializer(net) (train_vid_weighted.lua:260-264)
         self._ctx_filled = None
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
