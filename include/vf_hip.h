@@ -141,6 +141,17 @@ int vf_pconv_gather(vf_ctx* ctx, const void* ap, const void* wp, const float* bi
                     int Cout, int act, float slope);
 int vf_pconv_scatter(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
                      int Cout, int act, float slope, const float* dmask, int dact, float dslope);
+/* accGradParameters with the planes of BOTH operands at hand (x_planes: bf16 [3][B*H*W*Cin], gy_planes: bf16 [3][B*Ho*Wo*Cout],
+ * the layout vf_planes_split writes; x and gy themselves are still needed: bias gradient, shapes the planes kernel does not
+ * take).  The weight gradient runs on k_pwgrad_group — both operands DMA-staged as [pixel][channel] tiles, fragments by the
+ * transposing LDS read — when the product mode is 3, stride 2 pad 1, the low-resolution operand has a multiple of 128
+ * channels, the gathered one a multiple of 64 and the pixel count is a multiple of 32; otherwise exactly
+ * vf_conv2d_bwd_weight / vf_deconv2d_bwd_weight.  Same six-term products, another summation order over pixels. */
+int vf_conv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw,
+                                float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
+int vf_deconv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes,
+                                  float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                  float beta);
 
 /* ---- nn.SpatialBatchNormalization (THNN/THCUNN BatchNormalization; train.lua:92) ------------ */
 /* Training forward in two phases so a data-parallel caller can all-reduce `sums` in between:

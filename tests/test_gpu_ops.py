@@ -536,3 +536,29 @@ def test_gdl_backward(shape, oracle, hipb):
     assert abs(float(crit.forward(dx, dt)) - oracle.GDLCriterion(1).forward(x, t)) < 1e-6
     with pytest.raises(Exception):
         hipb.gdl_bwd(hipb.empty_act(1, 3, 8, 4), hipb.empty_act(1, 3, 8, 4), hipb.empty_act(1, 3, 8, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Bn,nB,C8", [(4, 6400, 96), (16, 4000, 64), (3, 200, 32), (1, 128, 8), (32, 1000, 16)])
+def test_bottleneck_weight_gradients_small_batch(Bn, nB, C8, hipb):
+    """vf_wgrad_small.hip: the weight gradients of the bottleneck pair (train.lua:104,134) with K = batch <= 32 — fp32 MFMAs
+    straight from the K-major operands — against fp64, overwrite and accumulate, ragged row tiles (nB % 64 != 0), odd batch."""
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(hipb.device)
+    # conv C8 -> nB, 4x4 stride 1 pad 0 on a 4x4 map
+    x = r(Bn, 4, 4, C8).permute(0, 3, 1, 2)
+    gy = r(Bn, 1, 1, nB).permute(0, 3, 1, 2)
+    want = torch.einsum("bn,bhwc->nchw", gy.double().reshape(Bn, nB).cpu(), x.permute(0, 2, 3, 1).double().cpu())
+    for beta in (0.0, 1.0):
+        gw0 = r(nB, 4, 4, C8) * 0.3
+        gw = gw0.clone().permute(0, 3, 1, 2)
+        hipb.conv2d_bwd_weight(x, gy, gw, None, 4, 1, 0, beta)
+        ref = want + beta * gw0.permute(0, 3, 1, 2).double().cpu()
+        assert float((gw.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    # full-conv nB -> C8, 1x1 -> 4x4
+    x2 = r(Bn, 1, 1, nB).permute(0, 3, 1, 2)
+    gy2 = r(Bn, 4, 4, C8).permute(0, 3, 1, 2)
+    want2 = torch.einsum("bn,bhwc->nchw", x2.double().reshape(Bn, nB).cpu(), gy2.permute(0, 2, 3, 1).double().cpu())
+    gw2 = hipb.zeros(nB, 4, 4, C8).permute(0, 3, 1, 2)
+    hipb.deconv2d_bwd_weight(x2, gy2, gw2, None, 4, 1, 0, 0.0)
+    assert float((gw2.cpu().double() - want2).abs().max() / want2.abs().max()) < 2e-6

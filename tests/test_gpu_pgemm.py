@@ -108,3 +108,51 @@ def test_unsupported_shapes_are_reported(hipb):
     x = hipb.zeros(4 * 8 * 8 * 48)
     with pytest.raises(RuntimeError):
         hipb.pconv_gather(hipb.planes_split(x), hipb.planes_split(hipb.zeros(64 * 16 * 48)), None, hipb.zeros(4 * 4 * 4 * 64), 4, 8, 8, 48, 64)
+
+
+# (Bn, Cin, H, Cout): conv Cin -> Cout on an H x H map.  The planes weight gradient needs the low-resolution operand's channels
+# (conv: Cout; full-conv: its input's) % 128 == 0, the gathered one's % 64 == 0 and a multiple of 32 pixels — the other rows
+# must come out of the fp32 kernels untouched by the planes arguments
+WCASES = [(8, 64, 32, 128), (16, 128, 16, 256), (16, 256, 8, 512), (64, 64, 32, 128), (4, 192, 32, 384), (2, 64, 8, 128),
+          (8, 64, 64, 64), (6, 32, 32, 96)]
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("Bn,Cin,H,Cout", WCASES, ids=lambda v: str(v))
+def test_weight_gradient_from_planes(Bn, Cin, H, Cout, grouped, hipb):
+    """vf_conv2d_bwd_weight_planes / vf_deconv2d_bwd_weight_planes against the fp32-operand kernels (same six-term products,
+    another summation order: 2e-6) and fp64 torch; overwrite and accumulate; alone and inside a weight-gradient group."""
+    dev = hipb.device
+    x = _act(Bn, Cin, H, 3, dev)
+    gy = _act(Bn, Cout, H // 2, 4, dev)
+    xp, gp = hipb.planes_split(x), hipb.planes_split(gy)
+    for full in (False, True):
+        # conv: x is the high-resolution input, gy the low-resolution gradient; the full-conv with the SAME pair of maps has the
+        # low-resolution tensor as its input and the high-resolution one as its gradOutput
+        lo, hi, lop, hip_ = (gy, x, gp, xp)
+        shape = (Cout, 4, 4, Cin)                       # physical [low-res channels][kh][kw][high-res channels] in both cases
+        fn = hipb.deconv2d_bwd_weight if full else hipb.conv2d_bwd_weight
+        args = (lo, hi) if full else (hi, lo)           # (input, gradOutput)
+        pargs = (lop, hip_) if full else (hip_, lop)
+        logical = (lambda t: t.permute(0, 3, 1, 2))
+        for beta in (0.0, 1.0):
+            want = logical(_rand(shape, 7, dev, 0.5))
+            got = logical(want.permute(0, 2, 3, 1).clone())
+            nb = Cin if full else Cout
+            gb_w, gb_g = _rand((nb,), 8, dev), _rand((nb,), 8, dev)
+            fn(*args, want, gb_w, 4, 2, 1, beta)
+            if grouped:
+                hipb.wgrad_group_begin()
+            fn(*args, got, gb_g, 4, 2, 1, beta, *pargs)
+            if grouped:
+                hipb.wgrad_group_end()
+            scale = float(want.abs().max())
+            assert float((got - want).abs().max()) <= 2e-6 * scale, (full, beta)
+            assert torch.equal(gb_w, gb_g)
+    if Bn * H * H * Cin <= 1 << 21:
+        xd, gd = x.double().cpu().contiguous().requires_grad_(False), gy.double().cpu().contiguous()
+        wz = torch.zeros(Cout, Cin, 4, 4, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.conv2d(xd, wz, stride=2, padding=1).backward(gd)
+        got = hipb.zeros(Cout, 4, 4, Cin).permute(0, 3, 1, 2)
+        hipb.conv2d_bwd_weight(x, gy, got, None, 4, 2, 1, 0.0, xp, gp)
+        assert float((got.cpu().double() - wz.grad).abs().max() / wz.grad.abs().max()) <= 2e-5

@@ -290,8 +290,12 @@ class HipBackend:
         dev, n, b1, b2 = plan
         self._c("vf_bias_grad_multi", _ptr(dev), n, b1, b2)
 
-    def conv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta):
+    def conv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta, x_planes=None, gy_planes=None):
         B, Cin, H, W = x.shape
+        if x_planes is not None and gy_planes is not None:
+            self._c("vf_conv2d_bwd_weight_planes", _ptr(x), _ptr(gy), _ptr(x_planes), _ptr(gy_planes), _ptr(gw), _ptr(gb), B, H, W,
+                    Cin, gw.shape[0], k, stride, pad, beta)
+            return
         self._c("vf_conv2d_bwd_weight", _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), B, H, W, Cin, gw.shape[0], k, stride,
                 pad, beta)
 
@@ -304,8 +308,12 @@ class HipBackend:
         B, Cin, H, W = gx.shape
         self._c("vf_deconv2d_bwd_data", _ptr(gy), _ptr(w), _ptr(gx), B, H, W, Cin, w.shape[1], k, stride, pad)
 
-    def deconv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta):
+    def deconv2d_bwd_weight(self, x, gy, gw, gb, k, stride, pad, beta, x_planes=None, gy_planes=None):
         B, Cin, H, W = x.shape
+        if x_planes is not None and gy_planes is not None:
+            self._c("vf_deconv2d_bwd_weight_planes", _ptr(x), _ptr(gy), _ptr(x_planes), _ptr(gy_planes), _ptr(gw), _ptr(gb), B, H,
+                    W, Cin, gw.shape[1], k, stride, pad, beta)
+            return
         self._c("vf_deconv2d_bwd_weight", _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), B, H, W, Cin, gw.shape[1], k, stride,
                 pad, beta)
 

@@ -105,6 +105,29 @@ __device__ __forceinline__ void vf_static_for(F&& f) {
   }
 }
 
+// Weight gradient from PRE-SPLIT operands (vf_pgemm.hip: k_pwgrad_group; recorded by vf_conv.hip's group recorder).
+//   dW[n][tap][c] = sum_p U[p][n] * V[(b, 2 my - 1 + kh, 2 mx - 1 + kw)][c]      p = (b, my, mx) on the low-resolution grid
+// Up / Vp: bf16 planes [3][pixels][channels] of the two operands (conv: U = gradOutput, V = input; full-conv: U = input,
+// V = gradOutput).  out: dW, or the split-K slabs (ksplit > 1: slab s at s * Nu * 16 * Cv elements).
+struct VfPWGrad {
+  const void* Up;
+  const void* Vp;
+  float* out;
+  unsigned u_ps, v_ps;          // plane strides in bytes
+  int P, lgMh, lgMw;            // low-resolution pixels = B << (lgMh + lgMw)
+  int Nu, Cv, Hv, Wv;
+  int gx, gy, gz;               // column tiles (16 * Cv / 128), row tiles (Nu / 128), split-K
+  int ksplit, nk;               // nk = P / 32 K steps
+  float beta;                   // ksplit == 1: dW = beta * dW + sum
+};
+#define VF_PWG_MAX 16
+struct VfPWGradGroup {
+  int n;
+  int blk_off[VF_PWG_MAX + 1];  // multiples of 8 (the XCD-aware tile order of a layer assumes blockIdx % 8 == local id % 8)
+  VfPWGrad d[VF_PWG_MAX];
+};
+int vf_internal_pwgrad_group(vf_ctx* ctx, const VfPWGradGroup& G, int blocks, const char* name, double flops);
+
 static inline int vf_ilog2(int v) {  // v must be a power of two
   int l = 0;
   while ((1 << l) < v) ++l;

@@ -1757,7 +1757,8 @@ static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const floa
 // ---- recorder of a weight-gradient group (see k_wgrad_group)
 struct WgRec {
   WGrad g;
-  int bm, bf;          // tile rows (128 / 64), matrix-core mode
+  int bm, bf;          // tile rows (128 / 64), matrix-core mode; bf = 4: operands are pre-split planes (pw, k_pwgrad_group)
+  VfPWGrad pw;
   int blocks;
   int64_t total;       // dW elements
   double flops;
@@ -1777,6 +1778,33 @@ static void launch_wg_group(vf_ctx* ctx, const WGradGroup& G, int blocks, const 
 static int wg_flush(vf_ctx* ctx) {
   WgRecorder* R = (WgRecorder*)ctx->wg_rec;
   if (!R || R->recs.empty()) return 0;
+  // the layers whose operands came as planes: one k_pwgrad_group launch (vf_pgemm.hip)
+  {
+    VfPWGradGroup G;
+    int blocks = 0;
+    double fl = 0;
+    G.n = 0;
+    auto fire = [&]() -> int {
+      if (G.n == 0) return 0;
+      G.blk_off[G.n] = blocks;
+      const int rc = vf_internal_pwgrad_group(ctx, G, blocks, "pwgrad_group_128x128x32", fl);
+      G.n = 0;
+      blocks = 0;
+      fl = 0;
+      return rc;
+    };
+    for (const WgRec& r : R->recs) {
+      if (r.bf != 4) continue;
+      G.blk_off[G.n] = blocks;
+      G.d[G.n] = r.pw;
+      ++G.n;
+      blocks += (r.blocks + 7) & ~7;
+      fl += r.flops;
+      if (G.n == VF_PWG_MAX)
+        if (int rc = fire()) return rc;
+    }
+    if (int rc = fire()) return rc;
+  }
   // one launch per (tile rows, mode) family, VF_WG_GROUP_MAX layers at a time
   for (int bm : {128, 64})
     for (int bf : {3, 1, 0}) {
@@ -1872,8 +1900,14 @@ VF_API int vf_wgrad_group_end(vf_ctx* ctx) {
   return wg_flush(ctx);
 }
 
+int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float* dW, int K, int Nu, int Ncols, float beta);  // vf_wgrad_small.hip
 static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, int Hl, int Wl, int Nu, int Hv, int Wv,
-                 int Cv, int stride, int pad, float beta, int ntaps = 16) {
+                 int Cv, int stride, int pad, float beta, int ntaps = 16, const void* Up = nullptr, const void* Vp = nullptr) {
+  // the bottleneck pair (1x1 map on one side, 4x4 on the other): dW = U^T V with K = batch — write-bound, its own kernel
+  if (Hl == 1 && Wl == 1 && Hv == 4 && Wv == 4 && stride == 1 && pad == 0 && ntaps == 16) {
+    const int rc = vf_internal_wgrad_smallk(ctx, U, V, dW, B, Nu, 16 * Cv, beta);
+    if (rc >= 0) return rc;
+  }
   WGrad g;
   memset(&g, 0, sizeof(g));
   g.U = U; g.V = V; g.dW = dW;
@@ -1907,7 +1941,16 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
   g.gx = gx; g.gy = gy; g.gz = ksplit;
   dim3 grid((unsigned)gx * gy * ksplit), block(256);
-  if (ctx->wg_active && vecU && vecV && (ksplit == 1 || total % 4 == 0)) {
+  // operands that arrive as planes (vf_*_bwd_weight_planes): the LDS-DMA kernel of vf_pgemm.hip, whole 128 x 128 x 32 tiles only
+  const bool use_pw = Up && Vp && ctx->mfma_bf16 == 3 && ntaps == 16 && stride == 2 && pad == 1 && Nu % 128 == 0 &&
+                      Cv % 64 == 0 && g.P % 32 == 0 && (int64_t)g.P * Nu * 6 < ((int64_t)1 << 31) &&
+                      (int64_t)B * Hv * Wv * Cv * 6 < ((int64_t)1 << 31) && total % 4 == 0;
+  const bool own_group = use_pw && !ctx->wg_active;      // a planes layer outside a group: a group of one, launched at once
+  if (own_group) {
+    if (!ctx->wg_rec) ctx->wg_rec = new WgRecorder();
+    ctx->wg_active = 1;
+  }
+  if (ctx->wg_active && (use_pw || (vecU && vecV && (ksplit == 1 || total % 4 == 0)))) {
     // recorded, not launched: the group runs at vf_wgrad_group_end.  Every recorded layer keeps its own slab region.
     WgRecorder* R = (WgRecorder*)ctx->wg_rec;
     const size_t need = ksplit > 1 ? (((size_t)ksplit * total * sizeof(float) + 255) & ~(size_t)255) : 0;
@@ -1924,7 +1967,25 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
     r.blocks = gx * gy * ksplit;
     r.total = total;
     r.flops = 2.0 * (double)g.P * Nu * (double)ntaps * Cv;
+    if (use_pw) {
+      r.bf = 4;
+      VfPWGrad& w = r.pw;
+      memset(&w, 0, sizeof(w));
+      w.Up = Up; w.Vp = Vp;
+      w.out = ksplit > 1 ? g.slab : dW;
+      w.u_ps = (unsigned)((int64_t)g.P * Nu * 2);
+      w.v_ps = (unsigned)((int64_t)B * Hv * Wv * Cv * 2);
+      w.P = g.P; w.lgMh = g.lgMh; w.lgMw = g.lgMw;
+      w.Nu = Nu; w.Cv = Cv; w.Hv = Hv; w.Wv = Wv;
+      w.gx = gx; w.gy = gy; w.gz = ksplit;
+      w.ksplit = ksplit; w.nk = g.nk;
+      w.beta = beta;
+    }
     R->recs.push_back(r);
+    if (own_group) {
+      ctx->wg_active = 0;
+      return wg_flush(ctx);
+    }
     return 0;
   }
   if (ctx->wg_active) {      // a launch outside the group must not overwrite recorded slabs: finish the group first
@@ -2024,8 +2085,21 @@ VF_API int vf_conv2d_bwd_data_act(vf_ctx* ctx, const float* gy, const float* w, 
   return conv_like_bwd(ctx, gy, w, nullptr, gx, B, Ho, Wo, Cout, Cin, stride, pad, VF_ACT_NONE, 0.f, x_act, act, slope);
 }
 
+static int conv2d_bwd_weight_impl(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes,
+                                  float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 VF_API int vf_conv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W,
                                 int Cin, int Cout, int k, int stride, int pad, float beta) {
+  return conv2d_bwd_weight_impl(ctx, x, gy, nullptr, nullptr, gw, gb, B, H, W, Cin, Cout, k, stride, pad, beta);
+}
+// the same with the bf16 planes of both operands at hand (vf_planes_split layout): the weight gradient then runs on the
+// planes-fed kernel where its shape allows (whole 128 x 128 x 32 tiles), on the fp32 operands otherwise
+VF_API int vf_conv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes,
+                                       float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                       float beta) {
+  return conv2d_bwd_weight_impl(ctx, x, gy, x_planes, gy_planes, gw, gb, B, H, W, Cin, Cout, k, stride, pad, beta);
+}
+static int conv2d_bwd_weight_impl(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes,
+                                  float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta) {
   if (!main_net_shape(H, W, k, stride, pad))
     return vf_internal_gconv_bwd_weight(ctx, x, gy, gw, gb, B, H, W, Cin, Cout, k, stride, pad, beta);
   if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
@@ -2038,7 +2112,7 @@ VF_API int vf_conv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, fl
   }
   // (tried: the bias gradient as a by-product of this kernel's own gy fragments — the waves that carried it made
   //  their blocks the slowest of every launch: +0.25 ms per step against the 0.19 ms of the separate column sums)
-  if (int rc = wgrad(ctx, gy, x, gw, B, Ho, Wo, Cout, H, W, Cin, stride, pad, beta)) return rc;
+  if (int rc = wgrad(ctx, gy, x, gw, B, Ho, Wo, Cout, H, W, Cin, stride, pad, beta, 16, gy_planes, x_planes)) return rc;
   if (gb) return bias_grad(ctx, gy, gb, (int64_t)B * Ho * Wo, Cout, beta);
   return 0;
 }
@@ -2059,13 +2133,23 @@ VF_API int vf_deconv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, fl
   return conv_like_fwd(ctx, gy, w, nullptr, gx, B, Ho, Wo, Cout, Cin, stride, pad, VF_ACT_NONE, 0.f);
 }
 
-VF_API int vf_deconv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W,
-                                  int Cin, int Cout, int k, int stride, int pad, float beta) {
+static int deconv2d_bwd_weight_impl(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes,
+                                    float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                    float beta) {
   VF_REQUIRE(k == 4 && ((stride == 2 && pad == 1) || (stride == 1 && pad == 0)), "unsupported full-conv shape");
   VF_REQUIRE(vf_is_pow2(H) && vf_is_pow2(W), "spatial sizes must be powers of two");
   const int Ho = (H - 1) * stride - 2 * pad + 4, Wo = (W - 1) * stride - 2 * pad + 4;
   // gw[ci][kh][kw][co] = sum_{b,i,j} x[b,i,j,ci] * gy[b, i*s-pad+kh, j*s-pad+kw, co]
-  if (int rc = wgrad(ctx, x, gy, gw, B, H, W, Cin, Ho, Wo, Cout, stride, pad, beta)) return rc;
+  if (int rc = wgrad(ctx, x, gy, gw, B, H, W, Cin, Ho, Wo, Cout, stride, pad, beta, 16, x_planes, gy_planes)) return rc;
   if (gb) return bias_grad(ctx, gy, gb, (int64_t)B * Ho * Wo, Cout, beta);
   return 0;
+}
+VF_API int vf_deconv2d_bwd_weight(vf_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, int B, int H, int W,
+                                  int Cin, int Cout, int k, int stride, int pad, float beta) {
+  return deconv2d_bwd_weight_impl(ctx, x, gy, nullptr, nullptr, gw, gb, B, H, W, Cin, Cout, k, stride, pad, beta);
+}
+VF_API int vf_deconv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes,
+                                         float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad,
+                                         float beta) {
+  return deconv2d_bwd_weight_impl(ctx, x, gy, x_planes, gy_planes, gw, gb, B, H, W, Cin, Cout, k, stride, pad, beta);
 }

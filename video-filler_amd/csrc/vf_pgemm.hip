@@ -24,6 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define VF_OOB 0x80000000u
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* p, unsigned bytes) {
@@ -723,6 +724,158 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
   // reading fragments when the epilogue's partial sums go there
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   pg_epilogue<1, 1, WAVES_M, BN>(p, acc, (float*)smem, m0, n0, wm, wn, lane, tid, wave / WAVES_N, bx, ks, ooy0, oox0, ph, pw, true);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients from planes
+// dW[n][tap][c] = sum_p U[p][n] * V[p @ tap][c] (VfPWGrad, vf_common.h): a 128 (n) x 128 (tap, c) tile per block, K = pixels in
+// steps of 32.  Both operands are K-MAJOR in memory ([pixel][channel]), which is the layout gfx950's transposing LDS read
+// wants: a stage is [3 planes][U 32 x 128 | V 32 x 128] bf16 = 48 KB, moved global -> LDS by DMA (one instruction = 4 pixel
+// rows x 256 bytes of one plane; wave w owns rows 4w .. 4w+3 of both tiles in all three planes), fragments come out through
+// ds_read_b64_tr_b16 (8 consecutive pixels of one channel per lane: the 32x32x16 operand map).  Rows are unpadded (the DMA
+// image is lane-linear), so the four pixel rows one transposing read touches are spread over the banks by an XOR of the
+// 64-byte block index with (row & 3), applied in the per-lane SOURCE address.  THREE stages in LDS (144 KB): the DMAs of stage
+// k+2 are issued before the MFMAs of stage k, `s_waitcnt vmcnt(6)` lets the newest stage stay in flight, one barrier per
+// step.  8 waves of a 32 x 64 accumulator tile.  Whole tiles only (Nu % 128 == 0, Cv % 64 == 0, P % 32 == 0): the host keeps
+// everything else on vf_conv.hip's k_wgrad.
+__device__ __forceinline__ bf16x8 pg_tr_frag(const __bf16* tile, int col0, int k0, int lane) {
+  // tile: [32][128] bf16, 256-byte rows, 64-byte block b of row k stored at block b ^ (k & 3).  Lane l gets column
+  // col0 + l % 32 (col0 a multiple of 32), k = k0 + 8 * (l / 32) .. + 7
+  const int grp = lane >> 4, i = lane & 15;
+  const int k = k0 + 8 * (grp >> 1) + (i >> 2);
+  const int blk = (col0 >> 5) ^ ((i >> 2) & 3);                 // (k & 3) == (i >> 2) & 3: k0 and 8 * (grp >> 1) are multiples of 4
+  const __bf16* a = tile + k * 128 + blk * 32 + 16 * (grp & 1) + 4 * (i & 3);
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * 128));      // rows k + 4: the same (k & 3)
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
+  int l = 0;
+  while (l + 1 < G.n && (int)blockIdx.x >= G.blk_off[l + 1]) ++l;
+  const VfPWGrad& p = G.d[l];
+  const int local = (int)blockIdx.x - G.blk_off[l];
+  const int ntiles = p.gx * p.gy * p.gz;
+  if (local >= ntiles) return;                       // padding blocks (uniform exit)
+  constexpr int BK = 32, TILE = BK * 128, PL_SZ = 2 * TILE, ST_SZ = 3 * PL_SZ, NST = 3;      // bf16 elements
+  __shared__ __attribute__((aligned(1024))) __bf16 smem[NST * ST_SZ];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+  const int lid = pg_xcd_remap(local, ntiles);
+  const int jx = __builtin_amdgcn_readfirstlane(lid % p.gx), rest = __builtin_amdgcn_readfirstlane(lid / p.gx);
+  const int n0 = __builtin_amdgcn_readfirstlane(rest % p.gy) * 128, j0 = jx * 128;
+  const int ks = __builtin_amdgcn_readfirstlane(rest / p.gy);
+  const int steps = (p.nk + p.ksplit - 1) / p.ksplit;
+  const int kt0 = ks * steps, kt1 = min(p.nk, kt0 + steps);
+
+  // ---- this lane's piece of every stage: pixel row k = 4 * wave + lane / 16, 16-byte chunk lane % 16 of the 256-byte row;
+  //      the chunk it FETCHES is the one whose swizzled home is that slot
+  const int krow = 4 * wave + (lane >> 4);
+  const int slot = lane & 15;
+  const int chunk = (((slot >> 2) ^ (krow & 3)) << 2) | (slot & 3);            // logical 8-channel chunk of the tile row
+  const unsigned u_off = 2u * (unsigned)(n0 + 8 * chunk);                      // + pixel * Nu * 2
+  const int col = j0 + 8 * chunk;                                              // (tap, c) column of the V tile
+  const int tap = col / p.Cv, cch = col - tap * p.Cv;
+  const int dy = (tap >> 2) - 1, dx = (tap & 3) - 1;                           // stride 2, pad 1
+  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
+  const __amdgpu_buffer_rsrc_t rsU = pg_rsrc(p.Up, 3u * p.u_ps), rsV = pg_rsrc(p.Vp, 3u * p.v_ps);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned row_lds = 2u * (unsigned)(4 * wave * 128);                    // this wave's four rows inside a tile (bytes)
+  unsigned szero;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(szero));
+
+  auto dma_stage = [&](int kt, int st, bool live) {
+    const int pix = kt * BK + krow;
+    const int mx = pix & (Mw - 1), my = (pix >> p.lgMw) & (Mh - 1), b = pix >> (p.lgMw + p.lgMh);
+    const int iy = 2 * my + dy, ix = 2 * mx + dx;
+    const bool okv = live && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
+    const unsigned uo = live ? u_off + 2u * (unsigned)(pix * p.Nu) : VF_OOB;
+    const unsigned vo = okv ? 2u * (unsigned)(((b * p.Hv + iy) * p.Wv + ix) * p.Cv + cch) : VF_OOB;
+    const unsigned base = lds0 + 2u * (unsigned)(st * ST_SZ) + row_lds;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      pg_dma16(base + 2u * (unsigned)(q * PL_SZ), uo, rsU, szero + q * p.u_ps);
+      pg_dma16(base + 2u * (unsigned)(q * PL_SZ + TILE), vo, rsV, szero + q * p.v_ps);
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  auto compute_stage = [&](int st) {
+    const __bf16* base = smem + st * ST_SZ;
+    bf16x8 a[2][3], b[2][3][2];
+    auto read_frag = [&](int g, int set) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[set][q] = pg_tr_frag(base + q * PL_SZ, wm, 16 * g, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b[set][q][nt] = pg_tr_frag(base + q * PL_SZ + TILE, wn + 32 * nt, 16 * g, lane);
+      }
+    };
+    read_frag(0, 0);
+#pragma unroll
+    for (int g = 0; g < BK / 16; ++g) {
+      const int cs = g & 1;
+      if (g + 1 < BK / 16) read_frag(g + 1, cs ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {      // smallest terms first (the order of vf_conv.hip's mode 3)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1][nt], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2][nt], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0][nt], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1][nt], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0][nt], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][0][nt], acc[nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- K loop: stages kt and kt + 1 are in flight when stage kt is waited for; every wave issues 6 DMAs per stage, live or not
+  dma_stage(kt0, 0, kt0 < kt1);
+  dma_stage(kt0 + 1, 1, kt0 + 1 < kt1);
+  int st = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    // the 6 newest DMAs of this wave (stage kt + 1) may stay outstanding; after the barrier everybody's stage kt has landed
+    // and nobody still reads the buffer stage kt + 2 goes to (it held stage kt - 1)
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int st2 = st >= 1 ? st - 1 : 2;                        // (st + 2) % 3
+    dma_stage(kt + 2, st2, kt + 2 < kt1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_stage(st);
+    st = st == 2 ? 0 : st + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead prefetches (zeros) have landed before the block ends
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int lr = lane & 31, lh = lane >> 5;
+  const int Ncols = 16 * p.Cv;
+  const int64_t total = (int64_t)p.Nu * Ncols;
+  float* out = p.out + (p.ksplit > 1 ? (int64_t)ks * total : 0);
+  const bool acc_old = p.ksplit == 1 && p.beta != 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t idx = (int64_t)n * Ncols + j0 + wn + nt * 32 + lr;
+      float v = acc[nt][r];
+      if (acc_old) v += p.beta * out[idx];
+      out[idx] = v;
+    }
+  }
+}
+
+int vf_internal_pwgrad_group(vf_ctx* ctx, const VfPWGradGroup& G, int blocks, const char* name, double flops) {
+  VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group, dim3((unsigned)blocks), dim3(512), G);
+  VF_LAUNCH_CHECK();
+  return 0;
 }
 
 // ================================================================================================ host

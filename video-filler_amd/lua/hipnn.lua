@@ -65,6 +65,8 @@ int vf_masked_mse_bwd(vf_ctx*, const float* x, const float* xhat, const uint8_t*
 int vf_adam_step(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int32_t* t_dev);
 int vf_adam_prep(vf_ctx*, double lr, double beta1, double beta2, int32_t* t_dev);
 int vf_adam_apply(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps, const int32_t* t_dev);
+int vf_conv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
+int vf_deconv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
 int vf_wgrad_group_abort(vf_ctx* ctx);

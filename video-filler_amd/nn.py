@@ -197,10 +197,12 @@ class SpatialConvolution(Module):
             return y
         if act in ("none", "lrelu", "relu") and self._pconv_ok(Bn, H, W, Cin, self.nOutputPlane, self._is_full):
             xp = in_planes if in_planes is not None else B.planes_split(input, self._planes_buf("_xp", input.numel()))
+            self._x_planes = (input.data_ptr(), tuple(input.shape), xp)      # accGradParameters reads the same operand
             wp = self.weight_planes(self._is_full, refresh=not managed)
             fn = B.pconv_scatter if self._is_full else B.pconv_gather
             fn(xp, wp, self.bias, y, Bn, H, W, Cin, self.nOutputPlane, act, slope)
             return y
+        self._x_planes = None
         fn = B.deconv2d_fwd if self._is_full else B.conv2d_fwd
         fn(input, self.weight, self.bias, y, self.kH, self.dH, self.padH, act, slope)
         return y
@@ -215,6 +217,7 @@ class SpatialConvolution(Module):
         Bn, Co, Ho, Wo = go.shape
         if self._pconv_ok(Bn, Ho, Wo, Co, self.nInputPlane, not self._is_full) and (in_act is None or not self._is_full):
             gp = g_planes if g_planes is not None else B.planes_split(go, self._planes_buf("_gp" + buf, go.numel()))
+            self._g_planes = (go.data_ptr(), tuple(go.shape), gp)
             wp = self.weight_planes(not self._is_full, refresh=not managed)
             if self._is_full:      # full-conv data-gradient: an ordinary strided conv of gradOutput
                 B.pconv_gather(gp, wp, None, gx, Bn, Ho, Wo, Co, self.nInputPlane)
@@ -223,6 +226,7 @@ class SpatialConvolution(Module):
             else:
                 B.pconv_scatter(gp, wp, None, gx, Bn, Ho, Wo, Co, self.nInputPlane)
             return gx
+        self._g_planes = None
         if in_act is not None:
             B.conv2d_bwd_data_act(to_nhwc(gradOutput), self.weight, gx, input, in_act[0], in_act[1], self.kH, self.dH, self.padH)
             return gx
@@ -230,9 +234,11 @@ class SpatialConvolution(Module):
         fn(to_nhwc(gradOutput), self.weight, gx, self.kH, self.dH, self.padH)
         return gx
 
-    def accGradParameters(self, input, gradOutput, scale=1, defer_bias=None):
+    def accGradParameters(self, input, gradOutput, scale=1, defer_bias=None, use_planes=True):
         """defer_bias: a list the container flushes at the end of its backward walk — gradBias (the column sums of
-        gradOutput) is then computed for all layers in two launches (backend.bias_grad_multi) instead of two each."""
+        gradOutput) is then computed for all layers in two launches (backend.bias_grad_multi) instead of two each.
+        use_planes=False: the caller runs this BEFORE this walk's updateGradInput (side-stream mode), so the remembered
+        planes of gradOutput would be the previous iteration's."""
         assert scale == 1, "the reference always uses scale = 1"
         beta = 0.0 if self._fresh else 1.0
         self._fresh = False
@@ -242,7 +248,16 @@ class SpatialConvolution(Module):
         if defer_bias is not None and self.nOutputPlane % 4 == 0 and go.data_ptr() % 16 == 0:
             defer_bias.append((go, self.gradBias, beta))
             gb = None
-        fn(to_nhwc(input), go, self.gradWeight, gb, self.kH, self.dH, self.padH, beta)
+        x = to_nhwc(input)
+        # the planes both GEMM passes of this layer were fed with (forward: the input's, data-gradient: gradOutput's) are the
+        # operands of the weight gradient too: when both are still at hand — same tensors, same shapes — it takes them
+        xs, gs = getattr(self, "_x_planes", None), getattr(self, "_g_planes", None)
+        self._g_planes = None          # single use: only an updateGradInput of THIS walk may hand its planes over
+        if (use_planes and _PWGRAD and not _NO_PCONV and xs is not None and gs is not None and xs[0] == x.data_ptr()
+                and xs[1] == tuple(x.shape) and gs[0] == go.data_ptr() and gs[1] == tuple(go.shape)):
+            fn(x, go, self.gradWeight, gb, self.kH, self.dH, self.padH, beta, xs[2], gs[2])
+        else:
+            fn(x, go, self.gradWeight, gb, self.kH, self.dH, self.padH, beta)
 
     def parameters(self):
         return [self.weight, self.bias], [self.gradWeight, self.gradBias]
@@ -692,6 +707,11 @@ _NO_BN_FUSE = bool(__import__("os").environ.get("VF_NO_BN_FUSE"))       # BatchN
 _NO_PCONV = bool(__import__("os").environ.get("VF_NO_PCONV"))           # convolutions from pre-split bf16 planes
 _PCONV_MIN_ROWS = int(__import__("os").environ.get("VF_PCONV_MIN_ROWS", "1024"))
 _PCONV_MIN_GFLOP = float(__import__("os").environ.get("VF_PCONV_MIN_GFLOP", "3.0"))
+# Weight gradients from the planes too (k_pwgrad_group).  OFF by default: the kernel is ~10 % faster than k_wgrad_group on the layers
+# it takes (159 against 143 TFLOP/s inside the iteration), but those layers then leave the group launch they shared with the
+# write-bound bottleneck weight gradients, whose 0.12 ms no longer hides under MFMA-bound tiles: same-box A/B of the iteration
+# 3.30 ms with, 3.23 ms without.  VF_PWGRAD=1 turns it on.
+_PWGRAD = __import__("os").environ.get("VF_PWGRAD", "0") == "1"
 
 
 class Sequential(Module):
@@ -944,7 +964,7 @@ class Sequential(Module):
                     if want_gp and self.side is not None and m.parameters():
                         # dW/db only read x and g; nothing on the main stream writes either before the join below
                         with self.side.on():
-                            self._acc(m, x, g, deferred)
+                            self._acc(m, x, g, deferred, use_planes=False)      # (runs before this walk's upd())
                         used_side = True
                         gin = upd() if want_gx else None
                     else:
@@ -978,9 +998,9 @@ class Sequential(Module):
         return g
 
     @staticmethod
-    def _acc(m, x, g, deferred):
-        if deferred is not None and isinstance(m, SpatialConvolution):
-            m.accGradParameters(x, g, 1, deferred)
+    def _acc(m, x, g, deferred, use_planes=True):
+        if isinstance(m, SpatialConvolution):
+            m.accGradParameters(x, g, 1, deferred, use_planes)
         else:
             m.accGradParameters(x, g, 1)
 
