@@ -556,7 +556,7 @@ __device__ __forceinline__ void pg_dma16(unsigned lds_byte, unsigned voffset, __
                : "memory");
 }
 
-template <int BM, int BN, int NTAPS, bool ILV = true>
+template <int BM, int BN, int NTAPS, bool ILV = false>
 __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const PGemm p) {
   constexpr int CH = 64, WAVES_N = BN / 32, WAVES_M = BM / 32, NW = WAVES_M * WAVES_N;
   constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;                 // 8-row groups (one DMA instruction per plane) per wave
@@ -655,7 +655,7 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
   const int lr = lane & 31, lh = lane >> 5;
   // MFMAs of the stage in `buf`; with ILV the NP DMA pieces of the NEXT stage are issued between them (one behind every
-  // second MFMA) instead of in front of them.  Kept as a switch (VF_PG_ILV=1) for the record: it did NOT pay — the stage's
+  // second MFMA) instead of in front of them.  Kept as a template switch for the record (no instantiation ships): it did NOT pay — the stage's
   // DMA issue is not what the MFMAs wait for (ablation: DMA-only 23.4 us, MFMA-only 22.7 us, both 28.8 us, neither 7.7 us on
   // the 4.3 GFLOP pass; the two halves already overlap to within 5 us)
   auto compute_step = [&](int buf, auto&& piece) {
@@ -968,20 +968,14 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     char dname[64];
     snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
     const double dfl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
-    static const int env_ilv = getenv("VF_PG_ILV") ? atoi(getenv("VF_PG_ILV")) : 0;   // measured: no gain (gathers -2..-4 %, short-K scatters -25 %)
-#define PG_DMA(BM_, NT_, TH_)                                                                                              \
-  do {                                                                                                                     \
-    if (env_ilv) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<BM_, 64, NT_, true>), dim3(nt), dim3(TH_), g);         \
-    else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<BM_, 64, NT_, false>), dim3(nt), dim3(TH_), g);                \
-  } while (0)
+    // (the interleaved-issue variant ILV = true is not instantiated: measured -2..-25 %, see compute_step)
     if (t.bm == 128) {
-      if (ntaps == 16) PG_DMA(128, 16, 512);
-      else PG_DMA(128, 4, 512);
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, false>), dim3(nt), dim3(512), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, false>), dim3(nt), dim3(512), g);
     } else {
-      if (ntaps == 16) PG_DMA(64, 16, 256);
-      else PG_DMA(64, 4, 256);
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, false>), dim3(nt), dim3(256), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, false>), dim3(nt), dim3(256), g);
     }
-#undef PG_DMA
     VF_LAUNCH_CHECK();
     if (ksplit > 1) {
       VfProf prof(ctx, slab_st ? "slab_reduce_pconv_bnstats" : "slab_reduce_pconv", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
