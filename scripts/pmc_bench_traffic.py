@@ -22,7 +22,7 @@ def bench_name(k):
         return "igemm_%sx%s_%s_v%s%s%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4),
                                           suf.get(m.group(5) or "0", ""), "_db" if m.group(7) == "true" else "")
     # k_pconv_dma<BM, BN, NTAPS> / k_pconv<BM, BN, WM, WN, NTAPS, CH, PAIR>
-    m = re.match(r"void k_pconv_dma<(\d+), (\d+), (\d+)>", k)
+    m = re.match(r"void k_pconv_dma<(\d+), (\d+), (\d+)(?:, \w+)?>", k)
     if m:
         return "pconv_dma_%sx%sx64_t%s" % (m.group(1), m.group(2), m.group(3))
     m = re.match(r"void k_pconv<(\d+), (\d+), \d+, \d+, (\d+), (\d+), (\w+)>", k)
