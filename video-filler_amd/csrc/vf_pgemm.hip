@@ -556,13 +556,13 @@ __device__ __forceinline__ void pg_dma16(unsigned lds_byte, unsigned voffset, __
                : "memory");
 }
 
-template <int BM, int BN, int NTAPS, bool ILV = false>
+template <int BM, int BN, int NTAPS, int NBUF = 2>
 __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const PGemm p) {
   constexpr int CH = 64, WAVES_N = BN / 32, WAVES_M = BM / 32, NW = WAVES_M * WAVES_N;
   constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;                 // 8-row groups (one DMA instruction per plane) per wave
   static_assert(AG * NW * 8 == BM && BG * NW * 8 == BN, "row groups must divide over the waves");
   constexpr int AH_SZ = BM * CH, BH_SZ = BN * CH, PL_SZ = AH_SZ + BH_SZ, BUF_SZ = 3 * PL_SZ;      // bf16 elements
-  __shared__ __attribute__((aligned(1024))) __bf16 smem[2 * BUF_SZ];
+  __shared__ __attribute__((aligned(1024))) __bf16 smem[NBUF * BUF_SZ];
   auto sw_off = [](int row, int octet) { return row * 64 + ((octet ^ ((row >> 1) & 7)) << 3); };
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -654,11 +654,10 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
   const int lr = lane & 31, lh = lane >> 5;
-  // MFMAs of the stage in `buf`; with ILV the NP DMA pieces of the NEXT stage are issued between them (one behind every
-  // second MFMA) instead of in front of them.  Kept as a template switch for the record (no instantiation ships): it did NOT pay — the stage's
-  // DMA issue is not what the MFMAs wait for (ablation: DMA-only 23.4 us, MFMA-only 22.7 us, both 28.8 us, neither 7.7 us on
-  // the 4.3 GFLOP pass; the two halves already overlap to within 5 us)
-  auto compute_step = [&](int buf, auto&& piece) {
+  // MFMAs of the stage in `buf` (fragment reads one k-group ahead).  (Tried and dropped: issuing the next stage's DMA pieces
+  // BETWEEN these MFMAs instead of in front of them: -2 % on the gathers, -25 % on the short-K transposed passes — the issue
+  // slots are not what the MFMAs wait for: DMA-only 23.4 us, MFMA-only 22.7 us, both 28.8 us, neither 7.7 us on the 4.3 GFLOP pass.)
+  auto compute_step = [&](int buf) {
     const __bf16* base = smem + buf * BUF_SZ;
     bf16x8 a[2][3], b[2][3];
     auto read_frag = [&](int g, int set) {
@@ -669,25 +668,19 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
       }
     };
     read_frag(0, 0);
-    constexpr int NMF = 6 * (CH / 16), STRIDE = NMF / NP;
-    static_assert(STRIDE >= 1, "more DMA pieces than MFMAs in a stage");
-    vf_static_for<CH / 16>([&](auto GI) {
-      constexpr int g = decltype(GI)::value, cs = g & 1;
-      if constexpr (g + 1 < CH / 16) read_frag(g + 1, cs ^ 1);
+#pragma unroll
+    for (int g = 0; g < CH / 16; ++g) {
+      const int cs = g & 1;
+      if (g + 1 < CH / 16) read_frag(g + 1, cs ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      vf_static_for<6>([&](auto MI) {
-        constexpr int mi = decltype(MI)::value, idx = 6 * g + mi;
-        constexpr int qa = mi == 0 ? 1 : mi == 1 ? 0 : mi == 2 ? 2 : mi == 3 ? 0 : mi == 4 ? 1 : 0;
-        constexpr int qb = mi == 0 ? 1 : mi == 1 ? 2 : mi == 2 ? 0 : mi == 3 ? 1 : mi == 4 ? 0 : 0;
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][qa], b[cs][qb], acc[0][0], 0, 0, 0);
-        if constexpr (ILV && idx % STRIDE == STRIDE - 1 && idx / STRIDE < NP) {
-          __builtin_amdgcn_sched_barrier(0);
-          piece(VfIntC<idx / STRIDE>{});
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][0], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-    });
+    }
   };
 
   // ---- main loop
@@ -698,25 +691,28 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
     asm volatile("" : "+s"(rowA), "+s"(colA), "+s"(w0), "+s"(rowW), "+s"(colW));
     vf_static_for<NTAPS>([&](auto T) {
       constexpr int t = decltype(T)::value;
-      constexpr int buf = t & 1;
-      // this wave's DMAs of the stage about to be read have landed; after the barrier everybody's have, and everybody is
-      // done reading the other buffer, which the next stage's DMAs overwrite
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      auto next_piece = [&](auto J) {
+      constexpr int buf = NBUF == 2 ? (t & 1) : 0, nbuf = NBUF == 2 ? (buf ^ 1) : 0;
+      auto next_stage = [&]() {
         if (!(p.dbg & 1)) {
           if constexpr (t + 1 < NTAPS)
-            dma_piece(ch, VfIntC<t + 1>{}, J, buf ^ 1, true);
+            dma_step(ch, VfIntC<t + 1>{}, nbuf, true);
           else
-            dma_piece(ch + 1, VfIntC<0>{}, J, buf ^ 1, more);
+            dma_step(ch + 1, VfIntC<0>{}, nbuf, more);
         }
       };
-      if constexpr (!ILV) vf_static_for<NP>(next_piece);
+      // this wave's DMAs of the stage about to be read have landed; after the barrier everybody's have, and (two stages)
+      // everybody is done reading the other buffer, which the next stage's DMAs overwrite
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (!(p.dbg & 4)) {
-        compute_step(buf, next_piece);
-      } else if constexpr (ILV) {
-        vf_static_for<NP>(next_piece);
+      if constexpr (NBUF == 2) next_stage();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 4)) compute_step(buf);
+      if constexpr (NBUF == 1) {
+        // ONE stage (72 KB: two blocks per CU): the next stage can only go in once everybody has read this one — a block
+        // does not overlap its own loads and MFMAs, its CU-mate does.  For the transposed passes whose tiles have four K
+        // steps, where a lone block per CU spent more time starting up and draining than computing.
+        asm volatile("s_barrier" ::: "memory");
+        next_stage();
       }
     });
   }
@@ -968,13 +964,28 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     char dname[64];
     snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
     const double dfl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
-    // (the interleaved-issue variant ILV = true is not instantiated: measured -2..-25 %, see compute_step)
+    // a grid of at least two tiles per CU runs the single-stage variant, two blocks per CU (measured, scripts/bench_pconv.py:
+    // E2 transposed pass 79 -> 67 us, E2 gather 68 -> 62, E3 transposed 31.2 -> 28.8, netD's first layer at 2B 58 -> 53;
+    // with one tile per CU the second stage is what is needed instead: E3 gather 29.7 vs 39.8 single-stage)
+    static const int env_nbuf = getenv("VF_PG_NBUF") ? atoi(getenv("VF_PG_NBUF")) : 0;
+    const bool one_stage = env_nbuf ? env_nbuf == 1 : (t.bm == 128 && nt >= 512);
+    if (one_stage) snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s_1stage", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
     if (t.bm == 128) {
-      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, false>), dim3(nt), dim3(512), g);
-      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, false>), dim3(nt), dim3(512), g);
+      if (ntaps == 16) {
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, 1>), dim3(nt), dim3(512), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, 2>), dim3(nt), dim3(512), g);
+      } else {
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, 1>), dim3(nt), dim3(512), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, 2>), dim3(nt), dim3(512), g);
+      }
     } else {
-      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, false>), dim3(nt), dim3(256), g);
-      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, false>), dim3(nt), dim3(256), g);
+      if (ntaps == 16) {
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, 1>), dim3(nt), dim3(256), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, 2>), dim3(nt), dim3(256), g);
+      } else {
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, 1>), dim3(nt), dim3(256), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, 2>), dim3(nt), dim3(256), g);
+      }
     }
     VF_LAUNCH_CHECK();
     if (ksplit > 1) {
