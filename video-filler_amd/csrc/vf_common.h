@@ -110,8 +110,12 @@ __device__ __forceinline__ void vf_static_for(F&& f) {
 // Up / Vp: bf16 planes [3][pixels][channels] of the two operands (conv: U = gradOutput, V = input; full-conv: U = input,
 // V = gradOutput).  out: dW, or the split-K slabs (ksplit > 1: slab s at s * Nu * 16 * Cv elements).
 struct VfPWGrad {
-  const void* Up;
+  const void* Up;               // NULL: the fp32-fed form below
   const void* Vp;
+  // fp32-fed form (the two bottleneck layers riding in the same launch: their planes do not exist, K = batch): plain matrices
+  // Uf [P][Nu], Vf [P][16 * Cv]; the block splits them on their way into LDS
+  const float* Uf;
+  const float* Vf;
   float* out;
   unsigned u_ps, v_ps;          // plane strides in bytes
   int P, lgMh, lgMw;            // low-resolution pixels = B << (lgMh + lgMw)

@@ -1759,6 +1759,8 @@ struct WgRec {
   WGrad g;
   int bm, bf;          // tile rows (128 / 64), matrix-core mode; bf = 4: operands are pre-split planes (pw, k_pwgrad_group)
   VfPWGrad pw;
+  bool plain_ok;       // a bottleneck layer (fp32 operands, K = batch) that can ride in a k_pwgrad_group launch: pw is its
+                       // fp32-fed descriptor, used when the group has planes layers (else it stays with k_wgrad_group)
   int blocks;
   int64_t total;       // dW elements
   double flops;
@@ -1778,8 +1780,18 @@ static void launch_wg_group(vf_ctx* ctx, const WGradGroup& G, int blocks, const 
 static int wg_flush(vf_ctx* ctx) {
   WgRecorder* R = (WgRecorder*)ctx->wg_rec;
   if (!R || R->recs.empty()) return 0;
-  // the layers whose operands came as planes: one k_pwgrad_group launch (vf_pgemm.hip)
+  // the layers whose operands came as planes: one k_pwgrad_group launch (vf_pgemm.hip).  The bottleneck layers of the same
+  // walk go with them in their fp32-fed form: write-bound tiles (131 MB of dW from K = batch) that hide under the MFMA-bound
+  // ones of the same launch, as they did in k_wgrad_group
   {
+    bool any_planes = false;
+    for (const WgRec& r : R->recs) any_planes |= (r.bf == 4);
+    if (any_planes)
+      for (WgRec& r : R->recs)
+        if (r.bf == 3 && r.plain_ok) {
+          r.bf = 4;
+          r.blocks = r.pw.gx * r.pw.gy;
+        }
     VfPWGradGroup G;
     int blocks = 0;
     double fl = 0;
@@ -1967,6 +1979,19 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
     r.blocks = gx * gy * ksplit;
     r.total = total;
     r.flops = 2.0 * (double)g.P * Nu * (double)ntaps * Cv;
+    r.plain_ok = false;
+    if (!use_pw && ctx->mfma_bf16 == 3 && BM == 128 && ksplit == 1 && Hl == 1 && Wl == 1 && Hv == 4 && Wv == 4 && stride == 1 &&
+        pad == 0 && ntaps == 16 && Nu % 4 == 0 && (16 * Cv) % 128 == 0 && vecU && vecV) {
+      r.plain_ok = true;
+      VfPWGrad& w = r.pw;
+      memset(&w, 0, sizeof(w));
+      w.Uf = U; w.Vf = V;                  // U [B][Nu], V [B][4][4][Cv] = [B][16 * Cv]
+      w.out = dW;
+      w.P = g.P; w.Nu = Nu; w.Cv = Cv; w.Hv = Hv; w.Wv = Wv;
+      w.gx = (16 * Cv) / 128; w.gy = (int)vf_cdiv(Nu, 128); w.gz = 1;
+      w.ksplit = 1; w.nk = (int)vf_cdiv(g.P, 32);
+      w.beta = beta;
+    }
     if (use_pw) {
       r.bf = 4;
       VfPWGrad& w = r.pw;

@@ -729,9 +729,14 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
 // rows x 256 bytes of one plane; wave w owns rows 4w .. 4w+3 of both tiles in all three planes), fragments come out through
 // ds_read_b64_tr_b16 (8 consecutive pixels of one channel per lane: the 32x32x16 operand map).  Rows are unpadded (the DMA
 // image is lane-linear), so the four pixel rows one transposing read touches are spread over the banks by an XOR of the
-// 64-byte block index with (row & 3), applied in the per-lane SOURCE address.  THREE stages in LDS (144 KB): the DMAs of stage
-// k+2 are issued before the MFMAs of stage k, `s_waitcnt vmcnt(6)` lets the newest stage stay in flight, one barrier per
-// step.  8 waves of a 32 x 64 accumulator tile.  Whole tiles only (Nu % 128 == 0, Cv % 64 == 0, P % 32 == 0): the host keeps
+// 64-byte block index with (row & 3), applied in the per-lane SOURCE address.  8 waves of a 32 x 64 accumulator tile.
+// NST = 1 (default): ONE stage in LDS (48 KB, three blocks per CU): issue the stage's DMAs, wait, barrier, MFMAs, barrier — a
+// block does not overlap its own loads and MFMAs, its CU-mates do; these grids are heavily split (tiles of 8-16 K steps, ten
+// rounds of blocks), and what bounds them is the start-up and drain of each tile, which co-resident blocks cover.
+// NST = 3: three stages (144 KB, one block per CU), DMAs of stage k+2 issued before the MFMAs of stage k, `s_waitcnt vmcnt(6)`
+// lets the newest stage stay in flight, one barrier per step: 20 % slower here (VF_PWG_STAGES=3).
+// Layers WITHOUT planes (Up == NULL: the bottleneck pair, plain [K][Nu] x [K][16 Cv] fp32 matrices) are staged by the block
+// itself — float4 loads, exact three-way split, 8-byte LDS writes into the same swizzled image — so that they share the launch.  Whole tiles only (Nu % 128 == 0, Cv % 64 == 0, P % 32 == 0): the host keeps
 // everything else on vf_conv.hip's k_wgrad.
 __device__ __forceinline__ bf16x8 pg_tr_frag(const __bf16* tile, int col0, int k0, int lane) {
   // tile: [32][128] bf16, 256-byte rows, 64-byte block b of row k stored at block b ^ (k & 3).  Lane l gets column
@@ -746,6 +751,7 @@ __device__ __forceinline__ bf16x8 pg_tr_frag(const __bf16* tile, int col0, int k
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+template <int NST>
 __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
   int l = 0;
   while (l + 1 < G.n && (int)blockIdx.x >= G.blk_off[l + 1]) ++l;
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
   const int local = (int)blockIdx.x - G.blk_off[l];
   const int ntiles = p.gx * p.gy * p.gz;
   if (local >= ntiles) return;                       // padding blocks (uniform exit)
-  constexpr int BK = 32, TILE = BK * 128, PL_SZ = 2 * TILE, ST_SZ = 3 * PL_SZ, NST = 3;      // bf16 elements
+  constexpr int BK = 32, TILE = BK * 128, PL_SZ = 2 * TILE, ST_SZ = 3 * PL_SZ;      // bf16 elements
   __shared__ __attribute__((aligned(1024))) __bf16 smem[NST * ST_SZ];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -797,6 +803,33 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
     }
   };
 
+  // fp32-fed layers: 32 rows x 128 columns of each operand per stage, 2 float4 per thread and operand; every float4 becomes
+  // three 8-byte plane pieces written to the same swizzled K-major image the DMA form builds
+  const bool fed32 = p.Up == nullptr;
+  const int Ncols = 16 * p.Cv;
+  auto stage_fp32 = [&](int kt) {
+    const int c4 = (tid & 31) * 4;                     // 4 consecutive columns of the 128-wide tiles
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = (tid >> 5) + 16 * j;               // row of the stage
+      const int pix = kt * BK + k;
+      f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < p.P) {
+        if (n0 + c4 < p.Nu) u = *(const f32x4*)(p.Uf + (int64_t)pix * p.Nu + n0 + c4);      // (Nu % 4 == 0: a float4 is in or out)
+        v = *(const f32x4*)(p.Vf + (int64_t)pix * Ncols + j0 + c4);
+      }
+      u32x2 up[3], vp[3];
+      pg_split4(u, up);
+      pg_split4(v, vp);
+      const int off = k * 128 + (((c4 >> 5) ^ (k & 3)) << 5) + (c4 & 31);      // bf16 elements inside a tile
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        *(u32x2*)(smem + q * PL_SZ + off) = up[q];
+        *(u32x2*)(smem + q * PL_SZ + TILE + off) = vp[q];
+      }
+    }
+  };
+
   f32x16 acc[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -832,32 +865,50 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
     }
   };
 
-  // ---- K loop: stages kt and kt + 1 are in flight when stage kt is waited for; every wave issues 6 DMAs per stage, live or not
-  dma_stage(kt0, 0, kt0 < kt1);
-  dma_stage(kt0 + 1, 1, kt0 + 1 < kt1);
-  int st = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    // the 6 newest DMAs of this wave (stage kt + 1) may stay outstanding; after the barrier everybody's stage kt has landed
-    // and nobody still reads the buffer stage kt + 2 goes to (it held stage kt - 1)
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const int st2 = st >= 1 ? st - 1 : 2;                        // (st + 2) % 3
-    dma_stage(kt + 2, st2, kt + 2 < kt1);
-    __builtin_amdgcn_sched_barrier(0);
-    compute_stage(st);
-    st = st == 2 ? 0 : st + 1;
+  if (fed32) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      stage_fp32(kt);
+      __syncthreads();
+      compute_stage(0);
+      __syncthreads();
+    }
+  } else if constexpr (NST == 3) {
+    // ---- K loop: stages kt and kt + 1 are in flight when stage kt is waited for; every wave issues 6 DMAs per stage, live or not
+    dma_stage(kt0, 0, kt0 < kt1);
+    dma_stage(kt0 + 1, 1, kt0 + 1 < kt1);
+    int st = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      // the 6 newest DMAs of this wave (stage kt + 1) may stay outstanding; after the barrier everybody's stage kt has landed
+      // and nobody still reads the buffer stage kt + 2 goes to (it held stage kt - 1)
+      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const int st2 = st >= 1 ? st - 1 : 2;                        // (st + 2) % 3
+      dma_stage(kt + 2, st2, kt + 2 < kt1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_stage(st);
+      st = st == 2 ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead prefetches (zeros) have landed before the block ends
+  } else {
+    // ---- ONE stage (48 KB: three blocks per CU): a block does not overlap its own DMAs and MFMAs, its CU-mates do
+    for (int kt = kt0; kt < kt1; ++kt) {
+      dma_stage(kt, 0, true);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      compute_stage(0);
+      asm volatile("s_barrier" ::: "memory");
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead prefetches (zeros) have landed before the block ends
 
   // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int lr = lane & 31, lh = lane >> 5;
-  const int Ncols = 16 * p.Cv;
   const int64_t total = (int64_t)p.Nu * Ncols;
   float* out = p.out + (p.ksplit > 1 ? (int64_t)ks * total : 0);
   const bool acc_old = p.ksplit == 1 && p.beta != 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = n0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (n >= p.Nu) continue;                          // (only the fp32-fed layers have a ragged last row tile)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int64_t idx = (int64_t)n * Ncols + j0 + wn + nt * 32 + lr;
@@ -869,7 +920,9 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
 }
 
 int vf_internal_pwgrad_group(vf_ctx* ctx, const VfPWGradGroup& G, int blocks, const char* name, double flops) {
-  VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group, dim3((unsigned)blocks), dim3(512), G);
+  static const int env_nst = getenv("VF_PWG_STAGES") ? atoi(getenv("VF_PWG_STAGES")) : 1;   // 1: 48 KB, three blocks per CU (measured 34.7 vs 42.9 us per 4.3 GFLOP layer)
+  if (env_nst == 1) VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group<1>, dim3((unsigned)blocks), dim3(512), G);
+  else VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group<3>, dim3((unsigned)blocks), dim3(512), G);
   VF_LAUNCH_CHECK();
   return 0;
 }

@@ -707,11 +707,11 @@ _NO_BN_FUSE = bool(__import__("os").environ.get("VF_NO_BN_FUSE"))       # BatchN
 _NO_PCONV = bool(__import__("os").environ.get("VF_NO_PCONV"))           # convolutions from pre-split bf16 planes
 _PCONV_MIN_ROWS = int(__import__("os").environ.get("VF_PCONV_MIN_ROWS", "1024"))
 _PCONV_MIN_GFLOP = float(__import__("os").environ.get("VF_PCONV_MIN_GFLOP", "3.0"))
-# Weight gradients from the planes too (k_pwgrad_group).  OFF by default: the kernel is ~10 % faster than k_wgrad_group on the layers
-# it takes (159 against 143 TFLOP/s inside the iteration), but those layers then leave the group launch they shared with the
-# write-bound bottleneck weight gradients, whose 0.12 ms no longer hides under MFMA-bound tiles: same-box A/B of the iteration
-# 3.30 ms with, 3.23 ms without.  VF_PWGRAD=1 turns it on.
-_PWGRAD = __import__("os").environ.get("VF_PWGRAD", "0") == "1"
+# Weight gradients from the planes too (k_pwgrad_group, single-stage form: 18-23 % faster than k_wgrad_group on its layers).  The
+# bottleneck weight gradients of the same walk ride in the same launch in their fp32-fed form (vf_conv.hip's recorder), as
+# they did in k_wgrad_group: write-bound tiles under MFMA-bound ones.  Same-box A/B of the iteration: +0.5 .. +1.2 %
+# (DESIGN.md 4.7f).  VF_PWGRAD=0 keeps every weight gradient on the fp32-operand kernels.
+_PWGRAD = __import__("os").environ.get("VF_PWGRAD", "1") == "1"
 
 
 class Sequential(Module):
