@@ -22,9 +22,11 @@ def bench_name(k):
         return "igemm_%sx%s_%s_v%s%s%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4),
                                           suf.get(m.group(5) or "0", ""), "_db" if m.group(7) == "true" else "")
     # k_pconv_dma<BM, BN, NTAPS> / k_pconv<BM, BN, WM, WN, NTAPS, CH, PAIR>
-    m = re.match(r"void k_pconv_dma<(\d+), (\d+), (\d+)(?:, \w+)?>", k)
+    if re.match(r"void k_pwgrad_group<", k):
+        return "pwgrad_group_128x128x32"
+    m = re.match(r"void k_pconv_dma<(\d+), (\d+), (\d+)(?:, (\w+))?>", k)      # 4th argument: LDS stages (1: the two-blocks-per-CU form)
     if m:
-        return "pconv_dma_%sx%sx64_t%s" % (m.group(1), m.group(2), m.group(3))
+        return "pconv_dma_%sx%sx64_t%s%s" % (m.group(1), m.group(2), m.group(3), "_1stage" if m.group(4) == "1" else "")
     m = re.match(r"void k_pconv<(\d+), (\d+), \d+, \d+, (\d+), (\d+), (\w+)>", k)
     if m:
         return "pconv_%sx%sx%s_t%s%s" % (m.group(1), m.group(2), m.group(4), m.group(3), "_pair" if m.group(5) == "true" else "")
