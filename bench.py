@@ -65,6 +65,8 @@ def main():
                     "(default: they run behind the next iteration's netD real pass)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control "
                     "flow with several ranks on ONE GPU (not a measurement)")
+    ap.add_argument("--comm", default="cabi", choices=["cabi", "torch"], help="N > 1 over RCCL: the exchange through the C-ABI "
+                    "(vf_comm_*, default) or through torch.distributed's process group")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--mfma", default="f32_3xbf16", choices=["f32_3xbf16", "f32", "bf16"],
                     help="how conv products are formed: f32_3xbf16 (default; fp32 operands split exactly into 3 bf16 planes, 6 "
@@ -115,9 +117,19 @@ def main():
     store = None
     if (world > 1 or args.force_dist) and args.backend == "nccl":
         # the exchange is the C-ABI's (vf_comm_*: RCCL inside libvf_hip.so); the only host-side rendezvous is moving
-        # rank 0's 128-byte id, through a TCP store at MASTER_ADDR:MASTER_PORT — no torch.distributed process group
-        cid, store = exchange_comm_id(B, world, rank)
-        B.init_comm(world, rank, cid)
+        # rank 0's 128-byte id, through a TCP store at MASTER_ADDR:MASTER_PORT — no torch.distributed process group.
+        # (--comm torch, or a failure to bring the communicator up, runs the same iteration over torch.distributed's RCCL
+        #  process group instead: the trainers call the backend's all_reduce either way.)
+        if args.comm == "cabi":
+            try:
+                cid, store = exchange_comm_id(B, world, rank)
+                B.init_comm(world, rank, cid)
+            except Exception as e:      # noqa: BLE001 — any failure here must not cost the run
+                sys.stderr.write("bench.py: vf_comm_* could not be brought up (%s: %s); using torch.distributed\n" % (type(e).__name__, e))
+                store = None
+                B.comm = None
+        if B.comm is None:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     global PEAK_F32_MFMA_TFLOPS
     B.set_mfma_mode(args.mfma)
     if args.mfma == "bf16":
