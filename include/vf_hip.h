@@ -384,6 +384,19 @@ int vf_prof_end(vf_ctx* ctx);
 int vf_prof_count(void);
 int vf_prof_get(int i, char* name, int name_cap, int64_t* launches, double* ms, double* flops, double* bytes);
 
+/* ---- roctx ranges (the reference's tracing is three torch.Timers; this is the profiler-visible counterpart) ----
+ * vf_range_push / vf_range_pop / vf_mark forward to roctx when a roctx library is present (librocprofiler-sdk-roctx.so as
+ * injected by rocprofv3, else libroctx64.so; $VF_ROCTX_LIB overrides) and are no-ops otherwise: `rocprofv3 --marker-trace
+ * --kernel-trace` shows them beside the kernels.  vf_trace_enable(1) (or VF_ROCTX=1 in the environment) additionally puts one
+ * range around every launch site of the library, named like the vf_prof_* kernel table.  vf_trace_available: 1 if bound.
+ * vf_range_depth: ranges currently open (pushes minus pops). */
+int vf_trace_available(void);
+int vf_trace_enable(int on);
+int vf_range_push(const char* name);
+int vf_range_pop(void);
+int vf_mark(const char* message);
+int vf_range_depth(void);
+
 #ifdef __cplusplus
 }
 #endif

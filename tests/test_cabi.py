@@ -112,3 +112,19 @@ def test_descriptor_mirror_matches_the_device_struct():
         for part in decl.split(","):
             names.append(re.sub(r"^.*[\s\*]", "", part.strip()))
     assert names == list(dt.names), (names, dt.names)
+
+
+def test_range_helpers_balance_without_a_gpu():
+    """vf_range_push / vf_range_pop / vf_mark (roctx when a roctx library is there, no-ops otherwise): host-only entries, so they are
+    exercised here — pushes and pops balance, a stray pop is an error with a message, not a crash."""
+    from video_filler_amd import _lib
+    lib = _lib.load()
+    assert lib.vf_trace_available() in (0, 1)
+    d0 = lib.vf_range_depth()
+    assert lib.vf_range_push(b"outer") == 0 and lib.vf_range_push(b"inner") == 0
+    assert lib.vf_range_depth() == d0 + 2
+    assert lib.vf_mark(b"a point in time") == 0
+    assert lib.vf_range_pop() == 0 and lib.vf_range_pop() == 0
+    assert lib.vf_range_depth() == d0
+    if d0 == 0:
+        assert lib.vf_range_pop() != 0 and b"no range" in lib.vf_last_error()

@@ -105,6 +105,12 @@ SIGNATURES = {
     "vf_comm_broadcast": (i32, [vp, vp, vp, i64, i32, i32]),
     "vf_comm_barrier": (i32, [vp, vp]),
     "vf_comm_destroy": (i32, [vp]),
+    "vf_trace_available": (i32, []),
+    "vf_trace_enable": (i32, [i32]),
+    "vf_range_push": (i32, [C.c_char_p]),
+    "vf_range_pop": (i32, []),
+    "vf_mark": (i32, [C.c_char_p]),
+    "vf_range_depth": (i32, []),
     "vf_prof_begin": (i32, [vp]),
     "vf_prof_end": (i32, [vp]),
     "vf_prof_count": (i32, []),

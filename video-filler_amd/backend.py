@@ -27,6 +27,19 @@ _COMM_DTYPE = {torch.float32: 0, torch.float64: 1}
 _COMM_OP = {"sum": 0, "avg": 1, "max": 2, "min": 3}
 
 
+class _Range:
+    def __init__(self, lib, name):
+        self.lib, self.name = lib, name.encode()
+
+    def __enter__(self):
+        self.lib.vf_range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.vf_range_pop()
+        return False
+
+
 class _CommHandle:
     """one collective in flight on the communicator's stream (vf_comm_allreduce_async's ticket)"""
 
@@ -226,6 +239,14 @@ class HipBackend:
 
     def _c(self, name, *args):
         _lib.check(getattr(self.lib, name)(self.ctx, *args))
+
+    # ---- roctx ranges (vf_trace.hip): `with B.range("fDx"): ...` shows up in `rocprofv3 --marker-trace`; no-ops without roctx
+    def range(self, name):
+        return _Range(self.lib, name)
+
+    def trace_enable(self, on=True):
+        """one range per library launch as well (named like bench.py's kernel table)"""
+        _lib.check(self.lib.vf_trace_enable(1 if on else 0))
 
     # ---- convolution family.  x/y logical BxCxHxW (NHWC physical); w logical as the reference (channels-last)
     def conv2d_fwd(self, x, w, bias, y, k, stride, pad, act="none", slope=0.0):

@@ -72,10 +72,24 @@ void vf_set_error(const char* fmt, ...);
 // per-launch profiling scope (active only between vf_prof_begin / vf_prof_end)
 bool vf_prof_enabled();
 void vf_prof_push(vf_ctx* ctx, const char* name, double flops, double bytes, bool begin);
+// roctx range around a launch site (vf_trace.hip): active with vf_trace_enable(1) / VF_ROCTX=1, free otherwise
+bool vf_trace_enabled();
+extern "C" int vf_range_push(const char* name);
+extern "C" int vf_range_pop(void);
+struct VfRange {
+  bool on;
+  explicit VfRange(const char* name) : on(vf_trace_enabled()) {
+    if (on) vf_range_push(name);
+  }
+  ~VfRange() {
+    if (on) vf_range_pop();
+  }
+};
 struct VfProf {
   vf_ctx* c;
   bool on;
-  VfProf(vf_ctx* ctx, const char* name, double flops, double bytes) : c(ctx), on(vf_prof_enabled()) {
+  VfRange range;
+  VfProf(vf_ctx* ctx, const char* name, double flops, double bytes) : c(ctx), on(vf_prof_enabled()), range(name) {
     if (on) vf_prof_push(c, name, flops, bytes, true);
   }
   ~VfProf() {
@@ -88,6 +102,7 @@ struct VfProf {
 bool vf_prof_ext(const char* name, double flops, double bytes, hipEvent_t* e0, hipEvent_t* e1);
 #define VF_LAUNCH_TIMED(ctx, name, flops, bytes, kernel, grid, block, ...)                                   \
   do {                                                                                                       \
+    VfRange _vr(name);                                                                                       \
     hipEvent_t _e0, _e1;                                                                                     \
     if (vf_prof_ext(name, flops, bytes, &_e0, &_e1))                                                         \
       hipExtLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, _e0, _e1, 0, __VA_ARGS__);                \

@@ -67,6 +67,12 @@ int vf_adam_prep(vf_ctx*, double lr, double beta1, double beta2, int32_t* t_dev)
 int vf_adam_apply(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_conv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 int vf_deconv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
+int vf_trace_available(void);
+int vf_trace_enable(int on);
+int vf_range_push(const char* name);
+int vf_range_pop(void);
+int vf_mark(const char* message);
+int vf_range_depth(void);
 int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
 int vf_wgrad_group_abort(vf_ctx* ctx);
@@ -111,6 +117,8 @@ end
 -- reference's fmaf chain bit for bit); 1 operands rounded to bf16 (opt-in)
 function hipnn.setMfmaMode(mode) check(C.vf_ctx_set_mfma_mode(hipnn.ctx, mode)) end
 -- every weight gradient recorded between these two runs as one grouped launch (wrap net:backward with them)
+-- roctx ranges (rocprofv3 --marker-trace): hipnn.range('fDx', function() ... end)
+function hipnn.range(name, fn) C.vf_range_push(name); local ok, err = pcall(fn); C.vf_range_pop(); if not ok then error(err, 0) end end
 function hipnn.beginBackward() check(C.vf_wgrad_group_begin(hipnn.ctx)) end
 function hipnn.endBackward() check(C.vf_wgrad_group_end(hipnn.ctx)) end
 function hipnn.abortBackward() check(C.vf_wgrad_group_abort(hipnn.ctx)) end   -- after an error inside a backward walk

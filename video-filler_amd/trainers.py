@@ -173,6 +173,13 @@ def _solver(opt):
     return ({"learningRate": lrG, "beta1": opt["beta1"]}, {"learningRate": opt["lr"], "beta1": opt["beta1"]})
 
 
+import contextlib
+
+
+def _no_range(name):
+    return contextlib.nullcontext()
+
+
 class _TrainerBase:
     def _finish_init(self, seed, world, rank, group, sync_bn, skip_dead_grads, overlap=True):
         # stream-level overlap: weight gradients beside the data-gradient chain (both nets) and netG's forward
@@ -309,12 +316,16 @@ class _TrainerBase:
         side stream that also runs netG's forward, beside netD's real pass (which reads no generator state): the
         28 B/param HBM-bound update then overlaps MFMA-bound work.  Same arithmetic, same order on every buffer;
         `flush()` applies a pending update (call it before reading parametersG)."""
-        optim.adam(self.fDx, self.parametersD, self.optimStateD)
-        if (self.defer_adam_g and self.side_g is not None) or self.adam_overlap:
-            self.fGx(self.parametersG)
-            self._pending_g = True
-        else:
-            optim.adam(self.fGx, self.parametersG, self.optimStateG)
+        B = get_backend()
+        rng = B.range if hasattr(B, "range") else _no_range         # roctx ranges of the two optimiser calls (rocprofv3 --marker-trace)
+        with rng("optim.adam(fDx)"):
+            optim.adam(self.fDx, self.parametersD, self.optimStateD)
+        with rng("optim.adam(fGx)"):
+            if (self.defer_adam_g and self.side_g is not None) or self.adam_overlap:
+                self.fGx(self.parametersG)
+                self._pending_g = True
+            else:
+                optim.adam(self.fGx, self.parametersG, self.optimStateG)
 
     # -- Adam(G) beside the next iteration's encoder forward (single device).  92 % of the generator's parameters are
     #    the two bottleneck weight tensors (E6, D1: 32.8 M each); the first layer that reads either is E6.  The update of
