@@ -384,6 +384,36 @@ int vf_prof_end(vf_ctx* ctx);
 int vf_prof_count(void);
 int vf_prof_get(int i, char* name, int name_cap, int64_t* launches, double* ms, double* flops, double* bytes);
 
+/* ---- nn.Sequential as one object (net_{create, forward, backward, update_grad_input, parameters}) ---------
+ * For a host that does not want to mirror the module protocol itself: hand over the layer list the reference builds with
+ * netG:add(...) / netD:add(...) (train.lua:87-199) and drive the net with one call per Torch7 method.  Pure host code over
+ * the entry points above (same kernels; an activation behind a convolution / BatchNorm is applied in its producer's epilogue
+ * and undone in its backward; all weight gradients of a backward call in one grouped launch).  It does not carry the
+ * cross-layer shortcuts of video-filler_amd/nn.py (BatchNorm statistics out of the GEMMs, planes): the simple surface.
+ * Activations NHWC, weights channels-last; the flat parameter buffer holds {weight, bias} ({gamma, beta}) module by module,
+ * segments padded to 64 floats (vf_net_param_offset).  Shapes are fixed at creation. */
+enum { VF_L_CONV = 1, VF_L_FULLCONV = 2, VF_L_BN = 3, VF_L_ACT = 4, VF_L_VIEW = 5 };
+typedef struct vf_layer_desc {
+  int kind;             /* VF_L_* */
+  int nin, nout;        /* conv / full-conv planes; BatchNorm: nout = channels */
+  int k, stride, pad;   /* conv / full-conv */
+  int act;              /* VF_L_ACT: VF_ACT_LRELU / RELU / TANH / SIGMOID */
+  float slope;          /* LeakyReLU negval */
+  float eps, momentum;  /* BatchNorm (0 -> 1e-5 / 0.1) */
+} vf_layer_desc;
+typedef struct vf_net vf_net;
+int vf_net_create(vf_ctx* ctx, vf_net** out, const vf_layer_desc* layers, int nlayers, int B, int C, int H, int W);
+int vf_net_destroy(vf_net* net);
+int vf_net_parameters(vf_net* net, float** params, float** grads, int64_t* count);   /* net:getParameters() */
+int64_t vf_net_param_offset(const vf_net* net, int layer, int which, int64_t* length); /* which: 0 weight/gamma, 1 bias/beta; -1 if none */
+int vf_net_bn_running(vf_net* net, int layer, float** running_mean, float** running_var);
+int vf_net_training(vf_net* net, int train);                                          /* net:training() / net:evaluate() */
+int vf_net_zero_grad(vf_net* net);                                                    /* net:zeroGradParameters() */
+int vf_net_forward(vf_net* net, const float* x, const float** y);                     /* net:forward(input) */
+int vf_net_backward(vf_net* net, const float* x, const float* gy, const float** gx);  /* net:backward(input, gradOutput) */
+int vf_net_update_grad_input(vf_net* net, const float* x, const float* gy, const float** gx); /* train.lua:366 */
+int vf_net_layer_output(vf_net* net, int layer, const float** y);                     /* net.modules[i].output */
+
 /* ---- roctx ranges (the reference's tracing is three torch.Timers; this is the profiler-visible counterpart) ----
  * vf_range_push / vf_range_pop / vf_mark forward to roctx when a roctx library is present (librocprofiler-sdk-roctx.so as
  * injected by rocprofv3, else libroctx64.so; $VF_ROCTX_LIB overrides) and are no-ops otherwise: `rocprofv3 --marker-trace

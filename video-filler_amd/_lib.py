@@ -105,6 +105,17 @@ SIGNATURES = {
     "vf_comm_broadcast": (i32, [vp, vp, vp, i64, i32, i32]),
     "vf_comm_barrier": (i32, [vp, vp]),
     "vf_comm_destroy": (i32, [vp]),
+    "vf_net_create": (i32, [vp, C.POINTER(vp), vp, i32, i32, i32, i32, i32]),
+    "vf_net_destroy": (i32, [vp]),
+    "vf_net_parameters": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]),
+    "vf_net_param_offset": (i64, [vp, i32, i32, C.POINTER(i64)]),
+    "vf_net_bn_running": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp)]),
+    "vf_net_training": (i32, [vp, i32]),
+    "vf_net_zero_grad": (i32, [vp]),
+    "vf_net_forward": (i32, [vp, vp, C.POINTER(vp)]),
+    "vf_net_backward": (i32, [vp, vp, vp, C.POINTER(vp)]),
+    "vf_net_update_grad_input": (i32, [vp, vp, vp, C.POINTER(vp)]),
+    "vf_net_layer_output": (i32, [vp, i32, C.POINTER(vp)]),
     "vf_trace_available": (i32, []),
     "vf_trace_enable": (i32, [i32]),
     "vf_range_push": (i32, [C.c_char_p]),

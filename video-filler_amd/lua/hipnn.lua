@@ -67,6 +67,19 @@ int vf_adam_prep(vf_ctx*, double lr, double beta1, double beta2, int32_t* t_dev)
 int vf_adam_apply(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_conv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 int vf_deconv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
+typedef struct vf_layer_desc { int kind; int nin, nout; int k, stride, pad; int act; float slope; float eps, momentum; } vf_layer_desc;
+typedef struct vf_net vf_net;
+int vf_net_create(vf_ctx* ctx, vf_net** out, const vf_layer_desc* layers, int nlayers, int B, int C, int H, int W);
+int vf_net_destroy(vf_net* net);
+int vf_net_parameters(vf_net* net, float** params, float** grads, int64_t* count);
+int64_t vf_net_param_offset(const vf_net* net, int layer, int which, int64_t* length);
+int vf_net_bn_running(vf_net* net, int layer, float** running_mean, float** running_var);
+int vf_net_training(vf_net* net, int train);
+int vf_net_zero_grad(vf_net* net);
+int vf_net_forward(vf_net* net, const float* x, const float** y);
+int vf_net_backward(vf_net* net, const float* x, const float* gy, const float** gx);
+int vf_net_update_grad_input(vf_net* net, const float* x, const float* gy, const float** gx);
+int vf_net_layer_output(vf_net* net, int layer, const float** y);
 int vf_trace_available(void);
 int vf_trace_enable(int on);
 int vf_range_push(const char* name);
@@ -117,6 +130,40 @@ end
 -- reference's fmaf chain bit for bit); 1 operands rounded to bf16 (opt-in)
 function hipnn.setMfmaMode(mode) check(C.vf_ctx_set_mfma_mode(hipnn.ctx, mode)) end
 -- every weight gradient recorded between these two runs as one grouped launch (wrap net:backward with them)
+----------------------------------------------------------------------------------------------------------------
+-- hipnn.Net: a whole nn.Sequential as ONE library object (vf_net_*).  The simple route for a driver: build the layer list from
+-- the Torch7 net (kinds / planes / kernel geometry as util.cudnn reads them, util.lua:117-119), copy weight / bias into the
+-- flat buffer at vf_net_param_offset, then net:forward / :backward / :updateGradInput are one C call each.
+----------------------------------------------------------------------------------------------------------------
+local KIND = { ['nn.SpatialConvolution'] = 1, ['nn.SpatialFullConvolution'] = 2, ['nn.SpatialBatchNormalization'] = 3,
+               ['nn.LeakyReLU'] = 4, ['nn.ReLU'] = 4, ['nn.Tanh'] = 4, ['nn.Sigmoid'] = 4, ['nn.View'] = 5 }
+local ACTCODE = { ['nn.LeakyReLU'] = 1, ['nn.ReLU'] = 2, ['nn.Tanh'] = 3, ['nn.Sigmoid'] = 4 }
+function hipnn.Net(seq, B, Cc, H, W)
+   local n = #seq.modules
+   local d = ffi.new('vf_layer_desc[?]', n)
+   for i, m in ipairs(seq.modules) do
+      local t = torch.type(m)
+      local e = d[i - 1]
+      e.kind = assert(KIND[t], 'hipnn.Net: unsupported module ' .. t)
+      if e.kind <= 2 then e.nin, e.nout, e.k, e.stride, e.pad = m.nInputPlane, m.nOutputPlane, m.kW, m.dW, m.padW
+      elseif e.kind == 3 then e.nout, e.eps, e.momentum = m.running_mean:size(1), m.eps, m.momentum
+      elseif e.kind == 4 then e.act, e.slope = ACTCODE[t], m.negval or 0 end
+   end
+   local out = ffi.new('vf_net*[1]')
+   check(C.vf_net_create(hipnn.ctx, out, d, n, B, Cc, H, W))
+   local net = { h = ffi.gc(out[0], C.vf_net_destroy) }
+   function net:forward(x) local y = ffi.new('const float*[1]'); check(C.vf_net_forward(self.h, fptr(x), y)); return y[0] end
+   function net:backward(x, gy) local g = ffi.new('const float*[1]'); check(C.vf_net_backward(self.h, fptr(x), fptr(gy), g)); return g[0] end
+   function net:updateGradInput(x, gy) local g = ffi.new('const float*[1]'); check(C.vf_net_update_grad_input(self.h, fptr(x), fptr(gy), g)); return g[0] end
+   function net:zeroGradParameters() check(C.vf_net_zero_grad(self.h)) end
+   function net:training() check(C.vf_net_training(self.h, 1)) end
+   function net:evaluate() check(C.vf_net_training(self.h, 0)) end
+   function net:getParameters()
+      local p, g, c = ffi.new('float*[1]'), ffi.new('float*[1]'), ffi.new('int64_t[1]')
+      check(C.vf_net_parameters(self.h, p, g, c)); return p[0], g[0], tonumber(c[0])
+   end
+   return net
+end
 -- roctx ranges (rocprofv3 --marker-trace): hipnn.range('fDx', function() ... end)
 function hipnn.range(name, fn) C.vf_range_push(name); local ok, err = pcall(fn); C.vf_range_pop(); if not ok then error(err, 0) end end
 function hipnn.beginBackward() check(C.vf_wgrad_group_begin(hipnn.ctx)) end
