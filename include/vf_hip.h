@@ -246,6 +246,11 @@ int vf_masked_compose(vf_ctx* ctx, float* out, const float* real, const float* f
 /* nn.BCECriterion (eps 1e-12, sizeAverage; train.lua:204).  target = constant label (label:fill). */
 int vf_bce_fwd(vf_ctx* ctx, const float* x, float label, int n, double* loss);
 int vf_bce_bwd(vf_ctx* ctx, const float* x, float label, float* gx, int n);
+/* criterion:forward and criterion:backward of the same scores in ONE launch, for one group of n scores or for two consecutive
+ * groups with their own labels (netD's real and fake halves, train.lua:331-349): loss0 / loss1 get the group means, gx the
+ * gradient of all groups * n scores.  Element for element vf_bce_fwd + vf_bce_bwd. */
+int vf_bce_fwd_bwd(vf_ctx* ctx, const float* x, float label0, float label1, int n_per_group, int groups, double* loss0,
+                   double* loss1, float* gx);
 /* nn.MSECriterion (train.lua:207).  loss = mean((x-t)^2); gx = (2/n)(x-t). */
 int vf_mse_fwd(vf_ctx* ctx, const float* x, const float* t, int64_t n, double* loss);
 int vf_mse_bwd(vf_ctx* ctx, const float* x, const float* t, float* gx, int64_t n);

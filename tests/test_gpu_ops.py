@@ -562,3 +562,24 @@ def test_bottleneck_weight_gradients_small_batch(Bn, nB, C8, hipb):
     gw2 = hipb.zeros(nB, 4, 4, C8).permute(0, 3, 1, 2)
     hipb.deconv2d_bwd_weight(x2, gy2, gw2, None, 4, 1, 0, 0.0)
     assert float((gw2.cpu().double() - want2).abs().max() / want2.abs().max()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_bce_forward_and_backward_in_one_launch(hipb):
+    """vf_bce_fwd_bwd against vf_bce_fwd + vf_bce_bwd: one group, and two groups with their own labels (netD's real and fake
+    halves) — element for element the same arithmetic, so bitwise."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2 * 37, generator=g).to(hipb.device)
+    x[0], x[1] = 0.0, 1.0                                     # the eps = 1e-12 edges (train.lua:204)
+    loss = hipb.zeros(4, dtype=torch.float64)
+    gx_ref, gx = hipb.zeros(2 * 37), hipb.zeros(2 * 37)
+    hipb.bce_fwd(x[:37], 1.0, loss[0:1])
+    hipb.bce_fwd(x[37:], 0.0, loss[1:2])
+    hipb.bce_bwd(x[:37], 1.0, gx_ref[:37])
+    hipb.bce_bwd(x[37:], 0.0, gx_ref[37:])
+    hipb.bce_fwd_bwd(x, 1.0, 0.0, 37, 2, loss[2:3], loss[3:4], gx)
+    assert torch.equal(gx, gx_ref) and torch.equal(loss[:2], loss[2:])
+    hipb.bce_fwd_bwd(x[37:], 0.0, 0.0, 37, 1, loss[2:3], None, gx[:37])
+    assert torch.equal(gx[:37], gx_ref[37:]) and float(loss[2]) == float(loss[1])
+    with pytest.raises(Exception):
+        hipb.bce_fwd_bwd(x, 1.0, 0.0, 37, 3, loss[2:3], loss[3:4], gx)

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vf_noise_fill": (i32, [vp, vp, i64, u64, vp, u64, i32]),
     "vf_bce_fwd": (i32, [vp, vp, f32, i32, vp]),
     "vf_bce_bwd": (i32, [vp, vp, f32, vp, i32]),
+    "vf_bce_fwd_bwd": (i32, [vp, vp, f32, f32, i32, i32, vp, vp, vp]),
     "vf_mse_fwd": (i32, [vp, vp, vp, i64, vp]),
     "vf_mse_bwd": (i32, [vp, vp, vp, vp, i64]),
     "vf_recon_grad_mix": (i32, [vp, vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i64, vp]),

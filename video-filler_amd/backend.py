@@ -551,6 +551,9 @@ class HipBackend:
         dst.copy_(src)  # cudaMemcpyAsync D2D on the current stream — plumbing
 
     # ---- criteria (loss: 1-element float64 device tensor)
+    def bce_fwd_bwd(self, x, label0, label1, n_per_group, groups, loss0, loss1, gx):
+        self._c("vf_bce_fwd_bwd", _ptr(x), float(label0), float(label1), n_per_group, groups, _ptr(loss0), _ptr(loss1), _ptr(gx))
+
     def bce_fwd(self, x, label, loss):
         self._c("vf_bce_fwd", _ptr(x), float(label), x.numel(), _ptr(loss))
 

@@ -339,6 +339,39 @@ __global__ void k_bce_bwd(const float* __restrict__ x, float label, float* __res
   const double EPS = 1e-12, xv = x[i], t = label;
   gx[i] = (float)(-(1.0 / (double)n) * (t - xv) / ((1. - xv + EPS) * (xv + EPS)));
 }
+// forward value AND gradient of one or two groups of n scores each in ONE launch (block g = group g: the closures always ask for
+// both, back to back — train.lua:331-349 for netD's real and fake halves, :364-366 for the generator's cost); the arithmetic of
+// k_bce_fwd / k_bce_bwd, element for element
+__global__ __launch_bounds__(256) void k_bce_fwd_bwd(const float* __restrict__ x, float label0, float label1, int n,
+                                                      double* __restrict__ loss0, double* __restrict__ loss1, float* __restrict__ gx) {
+  const double EPS = 1e-12;
+  const int g = blockIdx.x;
+  const double t = g ? label1 : label0;
+  x += (int64_t)g * n;
+  gx += (int64_t)g * n;
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double xv = x[i];
+    s -= log(xv + EPS) * t + log(1. - xv + EPS) * (1. - t);
+    gx[i] = (float)(-(1.0 / (double)n) * (t - xv) / ((1. - xv + EPS) * (xv + EPS)));
+  }
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *(g ? loss1 : loss0) = red[0] / (double)n;
+}
+VF_API int vf_bce_fwd_bwd(vf_ctx* ctx, const float* x, float label0, float label1, int n_per_group, int groups, double* loss0,
+                          double* loss1, float* gx) {
+  VF_REQUIRE(groups == 1 || groups == 2, "vf_bce_fwd_bwd: groups must be 1 or 2 (got %d)", groups);
+  VF_REQUIRE(x && gx && loss0 && (groups == 1 || loss1) && n_per_group > 0, "vf_bce_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(k_bce_fwd_bwd, dim3(groups), dim3(256), 0, ctx->stream, x, label0, label1, n_per_group, loss0, loss1, gx);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
 VF_API int vf_bce_fwd(vf_ctx* ctx, const float* x, float label, int n, double* loss) {
   hipLaunchKernelGGL(k_bce_fwd, dim3(1), dim3(256), 0, ctx->stream, x, label, n, loss);
   VF_LAUNCH_CHECK();

@@ -80,6 +80,7 @@ int vf_net_forward(vf_net* net, const float* x, const float** y);
 int vf_net_backward(vf_net* net, const float* x, const float* gy, const float** gx);
 int vf_net_update_grad_input(vf_net* net, const float* x, const float* gy, const float** gx);
 int vf_net_layer_output(vf_net* net, int layer, const float** y);
+int vf_bce_fwd_bwd(vf_ctx* ctx, const float* x, float label0, float label1, int n_per_group, int groups, double* loss0, double* loss1, float* gx);
 int vf_trace_available(void);
 int vf_trace_enable(int on);
 int vf_range_push(const char* name);

@@ -1146,6 +1146,21 @@ class Sequential(Module):
                 if "Convolution" in m.type_name():
                     get_backend().zero(m.bias)
 
+    def zeroConvBiasesWith(self, other):
+        """this net's sweep and `other`'s (both closures zero the conv biases of BOTH nets, train.lua:279-280) in one launch:
+        the segment table of the two flat buffers, offsets taken from this net's base"""
+        if self._flat is None or other._flat is None or getattr(get_backend(), "name", "") != "hip-gfx950":      # (raw addresses: the HIP backend only)
+            self.zeroConvBiases()
+            other.zeroConvBiases()
+            return
+        key = (self._flat[0].data_ptr(), other._flat[0].data_ptr())
+        if getattr(self, "_both_key", None) != key:
+            delta = (other._flat[0].data_ptr() - self._flat[0].data_ptr()) // 4
+            self._both_offs = torch.cat([self._bias_offs, other._bias_offs + delta]).contiguous()
+            self._both_lens = torch.cat([self._bias_lens, other._bias_lens]).contiguous()
+            self._both_key = key
+        get_backend().zero_segments(self._flat[0], self._both_offs, self._both_lens)
+
     def zeroGradParameters(self):
         """gradParameters:zero() — train.lua:282."""
         if self.lazy_zero:
@@ -1200,6 +1215,17 @@ class BCECriterion(_Criterion):
         g = self._g(input)
         get_backend().bce_bwd(input, float(target), g)
         return g
+
+    def forward_backward(self, input, target):
+        """criterion:forward(input, target) and criterion:backward(input, target) — the closures always call the pair back to
+        back (train.lua:364-366) — as one launch where the backend has it; returns (loss, gradInput)"""
+        B = get_backend()
+        if not hasattr(B, "bce_fwd_bwd") or not input.is_contiguous():
+            return self.forward(input, target), self.backward(input, target)
+        slot, g = self.next_slot(), self._g(input)
+        B.bce_fwd_bwd(input, float(target), float(target), input.numel(), 1, slot, None, g)
+        self.output = DeviceScalar.of(slot)
+        return self.output, g
 
 
 class MSECriterion(_Criterion):

@@ -226,6 +226,8 @@ class _TrainerBase:
         self._graph_stale = False
         self.batch_d = False         # set_batch_d(): netD's real and fake passes as one batch of 2B
         self._cat = self._cat_df = None
+        self._cat_real = None        # (buffer, batch version) the real half of _cat was filled from
+        self._batch_ver = 0
         if world == 1 and os.environ.get("VF_NO_BATCH_D") != "1":
             self.set_batch_d(True)   # single device: measured +5 % on train.lua's nets
 
@@ -264,17 +266,43 @@ class _TrainerBase:
         shp = (2 * n,) + tuple(real_in.shape[1:])
         if self._cat is None or tuple(self._cat.shape) != shp:
             self._cat = B.empty_act(*shp)
-        B.copy(self._cat[:n], real_in)
-        B.copy(self._cat[n:], fake_in)
+            self._cat_real = None
+        # real half: the batch only changes in set_batch(), which refreshes this half itself (_refresh_cat_real): no copy per
+        # iteration.  fake half: the generator's last convolution is pointed at this half, so from the next forward on its output
+        # IS the fake half (no copy either); whatever else arrives (the masked composite, a side-stream buffer) is copied.
+        key = (real_in.data_ptr(), self._batch_ver)
+        if self._cat_real != key:
+            B.copy(self._cat[:n], real_in)
+            self._cat_real = key
+        if fake_in.data_ptr() != self._cat[n:].data_ptr():
+            B.copy(self._cat[n:], fake_in)
+            last = [m for m in self.netG.leaves() if isinstance(m, nn.SpatialConvolution)][-1]
+            lo = getattr(last, "output", None)
+            if lo is not None and lo.data_ptr() == fake_in.data_ptr() and tuple(lo.shape) == tuple(self._cat[n:].shape):
+                last.output = self._cat[n:]
         out = self.netD.forward(self._cat)
         if self._cat_df is None or tuple(self._cat_df.shape) != tuple(out.shape):
             self._cat_df = B.zeros(out.numel()).view(out.shape)
-        errD_real = self.criterion.forward(out[:n], self.real_label)
-        errD_fake = self.criterion.forward(out[n:], self.fake_label)
-        B.bce_bwd(out[:n], self.real_label, self._cat_df[:n])
-        B.bce_bwd(out[n:], self.fake_label, self._cat_df[n:])
+        if hasattr(B, "bce_fwd_bwd") and out.is_contiguous():
+            # criterion:forward and :backward of both halves (train.lua:331-349) in one launch
+            s0, s1 = self.criterion.next_slot(), self.criterion.next_slot()
+            B.bce_fwd_bwd(out, self.real_label, self.fake_label, n, 2, s0, s1, self._cat_df)
+            errD_real, errD_fake = nn.DeviceScalar.of(s0), nn.DeviceScalar.of(s1)
+        else:
+            errD_real = self.criterion.forward(out[:n], self.real_label)
+            errD_fake = self.criterion.forward(out[n:], self.fake_label)
+            B.bce_bwd(out[:n], self.real_label, self._cat_df[:n])
+            B.bce_bwd(out[n:], self.fake_label, self._cat_df[n:])
         self.netD.backward(self._cat, self._cat_df, need_input_grad=not self.skip_dead_grads)
         return errD_real + errD_fake
+
+    def _refresh_cat_real(self, real_in):
+        """set_batch(): a new batch is in the persistent buffers; the real half of the [real; fake] tensor follows here, outside
+        the iteration (and outside a captured graph, which never copies it)"""
+        self._batch_ver += 1
+        if self.batch_d and self._cat is not None and self._cat.shape[0] == 2 * real_in.shape[0] and tuple(self._cat.shape[1:]) == tuple(real_in.shape[1:]):
+            get_backend().copy(self._cat[:real_in.shape[0]], real_in)
+            self._cat_real = (real_in.data_ptr(), self._batch_ver)
 
     def _netD_stale_output(self):
         out = self.netD.output
@@ -598,6 +626,7 @@ class CenterTrainer(_TrainerBase):
         self.input_ctx, self._real_center = data.center_prepare(real_ctx, o["overlapPred"], out=prev)
         self.input_real_center = self._real_center
         self.input_center = self._real_center
+        self._refresh_cat_real(self._real_center)
 
     def _fDx_gen(self):
         """fDx as a generator that yields once, at the point where the generator net's parameters are first needed:
@@ -605,9 +634,10 @@ class CenterTrainer(_TrainerBase):
         previous iteration's gradient exchange run until there (`_TrainerBase.step_pipelined`)."""
         B, o = get_backend(), self.opt
         early_g = self.side_g is not None and not self._pipelined
-        self.netD.zeroConvBiases()
         if not self._pending_g:
-            self.netG.zeroConvBiases()
+            self.netD.zeroConvBiasesWith(self.netG)      # both nets' sweeps (train.lua:279-280), one launch
+        else:
+            self.netD.zeroConvBiases()                   # (netG's follows its deferred Adam step)
         self.netD.zeroGradParameters()
         self.netD.refresh_weight_planes()          # netD: updated by the previous iteration's optim.adam(fDx) (and used by fGx since)
         if not self._pending_g:
@@ -654,14 +684,12 @@ class CenterTrainer(_TrainerBase):
     def fGx(self, x):
         B, o = get_backend(), self.opt
         wt, ov = o["wtl2"], o["overlapPred"]
-        self.netD.zeroConvBiases()
-        self.netG.zeroConvBiases()
+        self.netD.zeroConvBiasesWith(self.netG)      # both nets' sweeps (train.lua:279-280), one launch
         self.netG.zeroGradParameters()
         self.netD.refresh_weight_planes()            # optim.adam(fDx) has just moved netD's weights
         label = self.real_label                      # fake labels are real for the generator cost
         output = self._netD_stale_output()           # reused from fDx (train.lua:363): stale w.r.t. D's Adam step
-        self.errG = self.criterion.forward(output, label)
-        df_do = self.criterion.backward(output, label)
+        self.errG, df_do = self.criterion.forward_backward(output, label)
         df_dg = self._netD_grad_input(self._d_in(self.input_center), df_do)
         if o["conditionAdv"]:
             df_dg = df_dg[1]                         # df_dg[2] because conditional GAN (train.lua:371)
@@ -721,6 +749,7 @@ class VidTrainer(_TrainerBase):
         # the protocol's names, as views onto buffers that already hold the data
         self.input_ctx, self.input_real, self.input_mask = self._real_ctx, self._real_full, self._real_mask
         self.input_inpainted = self._inpaint_buf
+        self._refresh_cat_real(self.input_real)
 
     def set_initializer(self, netI):
         """opt.withInit: `netI = util.load(opt.initName)` (train_vid_weighted.lua:260-264).  The script never calls
@@ -747,9 +776,10 @@ class VidTrainer(_TrainerBase):
     def _fDx_gen(self):
         B, o = get_backend(), self.opt
         early_g = self.side_g is not None and not self._pipelined
-        self.netD.zeroConvBiases()
         if not self._pending_g:
-            self.netG.zeroConvBiases()
+            self.netD.zeroConvBiasesWith(self.netG)      # both nets' sweeps (train.lua:279-280), one launch
+        else:
+            self.netD.zeroConvBiases()                   # (netG's follows its deferred Adam step)
         self.netD.zeroGradParameters()
         self.netD.refresh_weight_planes()          # netD: updated by the previous iteration's optim.adam(fDx) (and used by fGx since)
         if not self._pending_g:
@@ -801,14 +831,12 @@ class VidTrainer(_TrainerBase):
     def fGx(self, x):
         B, o = get_backend(), self.opt
         wt, lam, wtgdl = o["wtl2"], o["weight_nomask"], o["wtgdl"]
-        self.netD.zeroConvBiases()
-        self.netG.zeroConvBiases()
+        self.netD.zeroConvBiasesWith(self.netG)      # both nets' sweeps (train.lua:279-280), one launch
         self.netG.zeroGradParameters()
         self.netD.refresh_weight_planes()            # optim.adam(fDx) has just moved netD's weights
         label = self.real_label
         output = self._netD_stale_output()
-        self.errG = self.criterion.forward(output, label)
-        df_do = self.criterion.backward(output, label)
+        self.errG, df_do = self.criterion.forward_backward(output, label)
         df_dg = self._netD_grad_input(self.input_real, df_do)
         errG_total = self.errG
         if wtgdl != 0:                               # forward value only (train_vid_weighted.lua:524)
