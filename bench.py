@@ -65,6 +65,8 @@ def main():
                     "(default: they run behind the next iteration's netD real pass)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control "
                     "flow with several ranks on ONE GPU (not a measurement)")
+    ap.add_argument("--shard-adam", action="store_true", help="N > 1: reduce-scatter G's gradient, Adam on 1/N of the parameters per "
+                    "rank, all-gather the updated shards (un-pipelined step)")
     ap.add_argument("--comm", default="cabi", choices=["cabi", "torch"], help="N > 1 over RCCL: the exchange through the C-ABI "
                     "(vf_comm_*, default) or through torch.distributed's process group")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -137,7 +139,7 @@ def main():
     gen = torch.Generator().manual_seed(1234 + rank)
     if args.workload == "center":
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, wtl2=0.999, overlapPred=4)
-        tr = CenterTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap)
+        tr = CenterTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam)
         batch = torch.rand((args.batch, 3, 128, 128), generator=gen) * 2 - 1
         tr.set_batch(batch)
         wl = "train.lua inpaintCenter (nBottleneck=%d wtl2=0.999 overlapPred=4) fineSize=128 batchSize=%d/GPU" % (
@@ -148,7 +150,7 @@ def main():
         fs = args.fine_size
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, nc_in=27, nc_out=12, nef=192, ngf=192, ndf=128,
                    weight_nomask=1, wtgdl=0.5, fineSize=fs, ext256=(fs == 256))
-        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap)
+        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam)
         full = torch.rand((args.batch, 12, fs, fs), generator=gen) * 2 - 1
         mask = torch.zeros((args.batch, 12, fs, fs), dtype=torch.uint8)
         mask[:, :, fs // 4:3 * fs // 4, fs // 4:3 * fs // 4] = 1
@@ -162,7 +164,7 @@ def main():
         predLen = 16 if args.workload == "vid16" else 4
         nc = 3 * predLen
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, predLen=predLen)
-        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap)
+        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam)
         full = torch.rand((args.batch, nc, 128, 128), generator=gen) * 2 - 1
         mask = torch.zeros((args.batch, nc, 128, 128), dtype=torch.uint8)
         mask[:, :, 32:96, 32:96] = 1
@@ -177,7 +179,7 @@ def main():
     if args.no_batch_d and tr.batch_d:
         tr.set_batch_d(False)
     use_graph = not args.no_graph and not (dp and args.sync_bn)
-    pipelined = dp and not args.no_pipeline and not args.sync_bn
+    pipelined = dp and not args.no_pipeline and not args.sync_bn and not args.shard_adam
     if dp:
         if use_graph:
             tr.capture_phased(warmup=max(args.warmup, 2), pipelined=pipelined)

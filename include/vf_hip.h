@@ -374,6 +374,10 @@ int vf_comm_world(const vf_comm* c);
 int vf_comm_rank(const vf_comm* c);
 int vf_comm_allreduce_async(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op, int* ticket);
 int vf_comm_allreduce_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t n, int* ticket);
+/* the two halves of an all-reduce (buf: world * shard_count floats; rank r's shard at buf + r * shard_count), for an optimiser
+ * sharded over the ranks: reduce-scatter the gradient (mean), update 1 / world of the parameters, all-gather them */
+int vf_comm_reduce_scatter_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t shard_count, int* ticket);
+int vf_comm_allgather_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t shard_count, int* ticket);
 int vf_comm_wait(vf_comm* c, vf_ctx* ctx, int ticket);
 int vf_comm_allreduce_inline(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op);
 int vf_comm_broadcast(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int root);

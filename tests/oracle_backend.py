@@ -81,6 +81,20 @@ class OracleBackend:
         self.scale_shift(t, 1.0 / world, 0.0)
         return None
 
+    def reduce_scatter_avg(self, t, world, rank, group=None):
+        import torch.distributed as dist
+        n = t.numel() // world
+        assert n * world == t.numel()
+        dist.all_reduce(t, group=group)          # (gloo has no reduce-scatter: average everything, hand out the shard)
+        self.scale_shift(t, 1.0 / world, 0.0)
+        return t[rank * n:(rank + 1) * n]
+
+    def all_gather_shards(self, t, world, rank, group=None):
+        import torch.distributed as dist
+        n = t.numel() // world
+        parts = [t[r * n:(r + 1) * n] for r in range(world)]
+        dist.all_gather(parts, parts[rank].clone(), group=group)
+
     def copy(self, dst, src):
         dst.copy_(src)
 

@@ -46,6 +46,13 @@ def test_one_rank_communicator_entries(hipb):
     assert lib.vf_comm_wait(comm, ctx, t.value) == 0
     torch.cuda.synchronize()
     assert len(seen) == 64
+    # the two halves of an all-reduce (sharded optimiser): one rank -> its shard is the whole vector, both are the identity
+    v = torch.randn(1 << 16, device=B.device)
+    v0 = v.clone()
+    sh = B.reduce_scatter_avg(v, 1, 0)
+    B.all_gather_shards(v, 1, 0)
+    torch.cuda.synchronize()
+    assert sh.data_ptr() == v.data_ptr() and torch.equal(v, v0)
     # argument errors come back as codes with a message, not as crashes
     assert lib.vf_comm_allreduce_async(comm, ctx, C.c_void_p(x.data_ptr()), 16, 7, 0, C.byref(t)) != 0
     assert b"dtype" in lib.vf_last_error()

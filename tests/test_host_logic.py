@@ -313,17 +313,18 @@ def _dp_worker(rank, world, port, kind, out_dir):
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
     vb2.set_backend(OracleBackend())
     local_bn = kind.endswith("_local")           # sync_bn=False: every rank normalises with its own shard's statistics
-    base = kind[:-len("_local")] if local_bn else kind
+    shard = kind.endswith("_shard")              # shard_adam: reduce-scatter G's gradient, Adam on 1 / world of it, all-gather
+    base = kind[:-len("_local")] if local_bn else (kind[:-len("_shard")] if shard else kind)
     B = 2 * world
     if base.startswith("center"):
         opt = dict(SMALL, wtl2=0.999, overlapPred=4, smooth=True)   # smooth nets: see tests/test_gpu_trainers.py
         full_batch = torch.from_numpy(O.synth_center_batch(B, np.random.default_rng(77)))
-        mk = lambda w, r, s: CenterTrainer(opt, seed=11, world=w, rank=r, sync_bn=s)
+        mk = lambda w, r, s: CenterTrainer(opt, seed=11, world=w, rank=r, sync_bn=s, shard_adam=shard and w > 1)
         feed = lambda tr, lo, hi: tr.set_batch(full_batch[lo:hi])
     else:
         opt = dict(SMALL, predLen=2, smooth=True)
         ctx, full, mask = [torch.from_numpy(a) for a in O.synth_vid_batch(B, np.random.default_rng(78), 6)]
-        mk = lambda w, r, s: VidTrainer(opt, seed=11, world=w, rank=r, sync_bn=s)
+        mk = lambda w, r, s: VidTrainer(opt, seed=11, world=w, rank=r, sync_bn=s, shard_adam=shard and w > 1)
         feed = lambda tr, lo, hi: tr.set_batch(ctx[lo:hi], full[lo:hi], mask[lo:hi])
     tr = mk(world, rank, not local_bn)
     per = B // world
@@ -334,7 +335,7 @@ def _dp_worker(rank, world, port, kind, out_dir):
         tr._pipelined = True
         dp_step = tr.step_pipelined
     else:
-        dp_step = tr.step_phased if base == "vid" else tr.step
+        dp_step = tr.step_phased if (base == "vid" or shard) else tr.step
     feed(tr, rank * per, (rank + 1) * per)
     dp_step()
     g1 = tr.gradParametersG.numpy().copy()      # after ONE iteration: gradients are comparable at fp32 precision
@@ -406,6 +407,17 @@ def test_data_parallel_world2_equals_big_batch(kind, tmp_path):
     # sharded gradients are mean-reduced in a different order than the big batch sums: fp32 tolerance
     assert gG < 5e-5 and rm < 1e-5, (gG, rm)
     assert pG < 5e-3 and pD < 5e-3, (pG, pD)     # Adam amplifies rounding on near-zero gradients
+
+
+@pytest.mark.parametrize("kind,world", [("center_shard", 2), ("vid_shard", 4)])
+def test_data_parallel_with_sharded_adam_equals_big_batch(kind, world, tmp_path):
+    """shard_adam: G's gradient is reduce-scattered, every rank updates 1 / world of the parameters with an Adam state of that
+    size, the shards are all-gathered — the big batch's trajectory (every element is updated by exactly one rank from the same
+    mean gradient), replicas bit-identical."""
+    mp.spawn(_dp_worker, args=(world, _dp_port(13 + ["center_shard", "vid_shard"].index(kind)), kind, str(tmp_path)), nprocs=world, join=True)
+    pG, pD, gG, rm = np.load(str(tmp_path / "ok.npy"))
+    assert float(np.load(str(tmp_path / "same.npy"))[0]) == 1.0, "replicas diverged across ranks"
+    assert rm < 1e-5 and pG < 5e-3 and pD < 5e-3, (pG, pD, rm)
 
 
 @pytest.mark.parametrize("kind", ["center", "vid_pipe"])

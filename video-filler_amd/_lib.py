@@ -101,6 +101,8 @@ SIGNATURES = {
     "vf_comm_rank": (i32, [vp]),
     "vf_comm_allreduce_async": (i32, [vp, vp, vp, i64, i32, i32, C.POINTER(i32)]),
     "vf_comm_allreduce_avg_async": (i32, [vp, vp, vp, i64, C.POINTER(i32)]),
+    "vf_comm_reduce_scatter_avg_async": (i32, [vp, vp, vp, i64, C.POINTER(i32)]),
+    "vf_comm_allgather_async": (i32, [vp, vp, vp, i64, C.POINTER(i32)]),
     "vf_comm_wait": (i32, [vp, vp, i32]),
     "vf_comm_allreduce_inline": (i32, [vp, vp, vp, i64, i32, i32]),
     "vf_comm_broadcast": (i32, [vp, vp, vp, i64, i32, i32]),

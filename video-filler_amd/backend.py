@@ -237,6 +237,34 @@ class HipBackend:
         self.scale_shift(t, 1.0 / world, 0.0)
         return None
 
+    def reduce_scatter_avg(self, t, world, rank, group=None):
+        """mean over ranks of shard `rank` of the flat vector t (numel % world == 0), in place at t[rank * n : (rank + 1) * n];
+        returns that shard (a view).  The other shards of t are scratch afterwards."""
+        n = t.numel() // world
+        assert n * world == t.numel() and t.is_contiguous() and t.dtype == torch.float32
+        if self.comm is not None:
+            ticket = C.c_int32(-1)
+            _lib.check(self.lib.vf_comm_reduce_scatter_avg_async(self.comm, self.ctx, _ptr(t), n, C.byref(ticket)))
+            _CommHandle(self, ticket.value).wait()
+        else:       # (gloo has no reduce-scatter: the whole vector is averaged, the shard read out of it)
+            import torch.distributed as dist
+            dist.all_reduce(t, group=group)
+            self.scale_shift(t, 1.0 / world, 0.0)
+        return t[rank * n:(rank + 1) * n]
+
+    def all_gather_shards(self, t, world, rank, group=None):
+        """every rank's shard t[r * n : (r + 1) * n] to all ranks, in place"""
+        n = t.numel() // world
+        assert n * world == t.numel() and t.is_contiguous() and t.dtype == torch.float32
+        if self.comm is not None:
+            ticket = C.c_int32(-1)
+            _lib.check(self.lib.vf_comm_allgather_async(self.comm, self.ctx, _ptr(t), n, C.byref(ticket)))
+            _CommHandle(self, ticket.value).wait()
+            return
+        import torch.distributed as dist
+        parts = [t[r * n:(r + 1) * n] for r in range(world)]
+        dist.all_gather(parts, parts[rank].clone(), group=group)
+
     def _c(self, name, *args):
         _lib.check(getattr(self.lib, name)(self.ctx, *args))
 

@@ -28,6 +28,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -50,6 +52,8 @@ int rccl_bind() {
   VF_SYM(CommDestroy, "ncclCommDestroy");
   VF_SYM(AllReduce, "ncclAllReduce");
   VF_SYM(Broadcast, "ncclBroadcast");
+  VF_SYM(ReduceScatter, "ncclReduceScatter");
+  VF_SYM(AllGather, "ncclAllGather");
   VF_SYM(GetErrorString, "ncclGetErrorString");
 #undef VF_SYM
   g_rccl.h = h;
@@ -146,6 +150,37 @@ VF_API int vf_comm_allreduce_async(vf_comm* c, vf_ctx* ctx, void* buf, int64_t c
 // the mean over ranks of a flat fp32 gradient bucket (averaged inside the collective: no extra pass over the bucket)
 VF_API int vf_comm_allreduce_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t n, int* ticket) {
   return vf_comm_allreduce_async(c, ctx, buf, n, 0, 1, ticket);
+}
+
+// The two halves of an all-reduce, for an optimiser sharded over the ranks: buf holds world * shard_count floats.
+//   reduce_scatter_avg: rank r ends up with the MEAN over ranks of shard r, in place at buf + r * shard_count (the other
+//                       shards of buf are scratch afterwards);
+//   allgather:          every rank's shard r (at buf + r * shard_count) reaches all ranks, in place.
+// Same stream discipline as vf_comm_allreduce_async.  With the gradient vector reduce-scattered, Adam runs on 1 / world of the
+// parameters per rank and the updated shards are gathered: the bytes on the wire of one all-reduce, 1 / world of the update.
+VF_API int vf_comm_reduce_scatter_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t shard_count, int* ticket) {
+  VF_REQUIRE(c != nullptr && ctx != nullptr && ticket != nullptr, "vf_comm_reduce_scatter_avg_async: NULL argument");
+  VF_REQUIRE(shard_count >= 0 && (shard_count == 0 || buf != nullptr), "vf_comm_reduce_scatter_avg_async: bad buffer");
+  VF_CHECK_HIP(hipEventRecord(c->ready, ctx->stream));
+  VF_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+  if (shard_count > 0)
+    VF_CHECK_RCCL(g_rccl.ReduceScatter(buf, buf + (int64_t)c->rank * shard_count, (size_t)shard_count, ncclFloat32, ncclAvg, c->comm, c->stream));
+  const int t = (int)(c->issued++ % RING);
+  VF_CHECK_HIP(hipEventRecord(c->done[t], c->stream));
+  *ticket = t;
+  return 0;
+}
+VF_API int vf_comm_allgather_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t shard_count, int* ticket) {
+  VF_REQUIRE(c != nullptr && ctx != nullptr && ticket != nullptr, "vf_comm_allgather_async: NULL argument");
+  VF_REQUIRE(shard_count >= 0 && (shard_count == 0 || buf != nullptr), "vf_comm_allgather_async: bad buffer");
+  VF_CHECK_HIP(hipEventRecord(c->ready, ctx->stream));
+  VF_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+  if (shard_count > 0)
+    VF_CHECK_RCCL(g_rccl.AllGather(buf + (int64_t)c->rank * shard_count, buf, (size_t)shard_count, ncclFloat32, c->comm, c->stream));
+  const int t = (int)(c->issued++ % RING);
+  VF_CHECK_HIP(hipEventRecord(c->done[t], c->stream));
+  *ticket = t;
+  return 0;
 }
 
 // the context's stream waits (on the device; the host does not block) for collective `ticket` — and, the exchange stream

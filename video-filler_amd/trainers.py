@@ -181,7 +181,7 @@ def _no_range(name):
 
 
 class _TrainerBase:
-    def _finish_init(self, seed, world, rank, group, sync_bn, skip_dead_grads, overlap=True):
+    def _finish_init(self, seed, world, rank, group, sync_bn, skip_dead_grads, overlap=True, shard_adam=False):
         # stream-level overlap: weight gradients beside the data-gradient chain (both nets) and netG's forward
         # beside netD's real pass.  Each side stream has its own context and workspace (backend.fork()).
         self.side_g = None
@@ -199,6 +199,15 @@ class _TrainerBase:
         self.parametersG, self.gradParametersG = self.netG.getParameters()
         self.world, self.rank, self.group = world, rank, group
         self.skip_dead_grads = skip_dead_grads
+        # shard_adam (data parallel, un-pipelined step): the generator's gradient is REDUCE-SCATTERED instead of all-reduced,
+        # every rank applies Adam to its 1 / world of the parameters (its m and v are that size too) and the updated shards
+        # are all-gathered: the bytes on the wire of one all-reduce, 1 / world of the 28-bytes-per-parameter update per rank
+        self.shard_adam = bool(shard_adam) and world > 1
+        if self.shard_adam:
+            assert self.parametersG.numel() % (4 * world) == 0, "shard_adam: the flat vector must split into 16-byte-aligned shards"
+            n = self.parametersG.numel() // world
+            self._shard = (rank * n, (rank + 1) * n)
+            self.optimStateG_shard = dict(self.optimStateG)
         if world > 1 and sync_bn:
             for net in (self.netG, self.netD):
                 for m in net.leaves():
@@ -443,6 +452,10 @@ class _TrainerBase:
             self.netG.backward_range(self._g_in(), self._g_mid, k, 0, not self.skip_dead_grads)
 
     def _phase_c(self):
+        if self.shard_adam:
+            lo, hi = self._shard
+            optim.adam_update(self.parametersG[lo:hi], self.gradParametersG[lo:hi], self.optimStateG_shard)
+            return
         optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
 
     def step_phased(self):
@@ -454,6 +467,12 @@ class _TrainerBase:
         pa()
         B.all_reduce_avg(self.gradParametersD, self.world, self.group)
         pb()
+        if self.shard_adam:
+            pb2()
+            B.reduce_scatter_avg(gG, self.world, self.rank, self.group)       # this rank's shard of the mean gradient
+            pc()                                                             # Adam on that shard
+            B.all_gather_shards(self.parametersG, self.world, self.rank, self.group)
+            return
         h_tail = B.all_reduce_avg(gG[off:], self.world, self.group, async_op=True)
         pb2()
         h_head = B.all_reduce_avg(gG[:off], self.world, self.group, async_op=True) if off > 0 else None
@@ -482,6 +501,7 @@ class _TrainerBase:
     def step_pipelined(self):
         B = get_backend()
         assert self._pipelined, "call capture_phased(pipelined=True) or set _pipelined before the first step"
+        assert not self.shard_adam, "shard_adam belongs to the un-pipelined step (step_phased)"
         pa1, pa2, pb, pb2 = ([g.replay for g in self._graphs] if self._graphs is not None
                              else [self._phase_a1, self._phase_a2, self._phase_b, self._phase_b2])
         assert not self._graph_stale, "flush() was called: the captured graphs would apply Adam(G) twice; capture again"
@@ -569,7 +589,7 @@ class CenterTrainer(_TrainerBase):
     """train.lua: centre-square inpainting; netD judges the 64x64 centre."""
 
     def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
-                 skip_dead_grads=True, overlap=True):
+                 skip_dead_grads=True, overlap=True, shard_adam=False):
         o = dict(DEFAULT_OPT_TRAIN)
         o.update(opt or {})
         self.opt = o
@@ -580,7 +600,7 @@ class CenterTrainer(_TrainerBase):
         if o["conditionAdv"] and skip_dead_grads:
             self.netD.modules[0].skip_grad = (0,)     # nobody reads the gradient w.r.t. the context (train.lua:371)
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
-        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn))
+        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn), shard_adam)
         if o["conditionAdv"] and self.batch_d:
             self.set_batch_d(False)                   # a table-input netD keeps its two passes
         self.real_label, self.fake_label = 1, 0
@@ -713,7 +733,7 @@ class VidTrainer(_TrainerBase):
     """train_vid_weighted.lua / train_wholeim_input.lua: full-frame output, netD judges the whole frame."""
 
     def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
-                 skip_dead_grads=True, overlap=True):
+                 skip_dead_grads=True, overlap=True, shard_adam=False):
         o = dict(DEFAULT_OPT_VID)
         o.update(opt or {})
         self.opt = o
@@ -730,7 +750,7 @@ class VidTrainer(_TrainerBase):
         self._ctx_filled = None
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self.criterionGDL = nn.GDLCriterion(1) if o["wtgdl"] != 0 else None
-        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn))
+        self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn), shard_adam)
         self.real_label, self.fake_label = 1, 0
         self.input_inpainted = None
 
