@@ -67,8 +67,10 @@ def main():
                     "flow with several ranks on ONE GPU (not a measurement)")
     ap.add_argument("--shard-adam", action="store_true", help="N > 1: reduce-scatter G's gradient, Adam on 1/N of the parameters per "
                     "rank, all-gather the updated shards (un-pipelined step)")
-    ap.add_argument("--comm", default="cabi", choices=["cabi", "torch"], help="N > 1 over RCCL: the exchange through the C-ABI "
-                    "(vf_comm_*, default) or through torch.distributed's process group")
+    ap.add_argument("--comm", default="auto", choices=["auto", "cabi", "torch"], help="N > 1 over RCCL: auto (default) = the exchange "
+                    "through the C-ABI (vf_comm_*) if every rank can bring it up AND its start-up self-check of every collective "
+                    "passes on every rank, else — decided by all ranks together — torch.distributed's process group; cabi = "
+                    "vf_comm_* or fail; torch = the process group")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--mfma", default="f32_3xbf16", choices=["f32_3xbf16", "f32", "bf16"],
                     help="how conv products are formed: f32_3xbf16 (default; fp32 operands split exactly into 3 bf16 planes, 6 "
@@ -112,7 +114,7 @@ def main():
         if args.backend != "nccl":          # rehearsal of the control flow (several ranks on one GPU): torch.distributed
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from video_filler_amd.backend import exchange_comm_id, get_backend
+    from video_filler_amd.backend import get_backend
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
 
     B = get_backend()
@@ -122,16 +124,18 @@ def main():
         # rank 0's 128-byte id, through a TCP store at MASTER_ADDR:MASTER_PORT — no torch.distributed process group.
         # (--comm torch, or a failure to bring the communicator up, runs the same iteration over torch.distributed's RCCL
         #  process group instead: the trainers call the backend's all_reduce either way.)
-        if args.comm == "cabi":
-            try:
-                cid, store = exchange_comm_id(B, world, rank)
-                B.init_comm(world, rank, cid)
-            except Exception as e:      # noqa: BLE001 — any failure here must not cost the run
-                sys.stderr.write("bench.py: vf_comm_* could not be brought up (%s: %s); using torch.distributed\n" % (type(e).__name__, e))
-                store = None
-                B.comm = None
+        if args.comm in ("auto", "cabi"):
+            from video_filler_amd.backend import bring_up_comm
+            ok, store = bring_up_comm(B, world, rank)       # every rank gets the same answer (decided through the store)
+            if not ok and args.comm == "cabi":
+                raise SystemExit("bench.py --comm cabi: vf_comm_* could not be brought up and verified on every rank")
+            elif not ok:
+                sys.stderr.write("bench.py: vf_comm_* not available/verified on every rank; all ranks use torch.distributed\n")
         if B.comm is None:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            kw = {}
+            if store is not None:      # the rendezvous store already exists (bring_up_comm): the process group shares it
+                kw["store"] = dist.PrefixStore("vf_pg", store)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), **kw)
     global PEAK_F32_MFMA_TFLOPS
     B.set_mfma_mode(args.mfma)
     if args.mfma == "bf16":
@@ -411,7 +415,8 @@ def main():
                                 "f32": "native v_mfma_f32_32x32x2_f32", "bf16": "operands rounded to bf16"}[args.mfma],
                        "adam_G": "bottleneck weight tensors on a side stream beside the next encoder forward" if tr.adam_overlap else "one launch at the end of the iteration",
                        "netD_passes": "real+fake as one batch of 2B, BatchNorm per half" if tr.batch_d else "separate (as the reference)",
-                       "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device"},
+                       "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device",
+                       "exchange": (("vf_comm_* (C-ABI, RCCL; verified at start-up on every rank)" if B.comm is not None else "torch.distributed (%s)" % args.backend) if dp else None)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "step_ms": step_stats,
@@ -435,10 +440,11 @@ def main():
                 import datetime
                 store.wait(["vf_bench_done"], datetime.timedelta(seconds=1800))
                 store.add("vf_bench_left", 1)
+        elif world > 1 and dist.is_initialized():
+            dist.barrier()
+        if B.comm is not None:
             B.destroy_comm()
-        else:
-            if world > 1:
-                dist.barrier()
+        if dist.is_initialized():
             dist.destroy_process_group()
 
 

@@ -19,8 +19,10 @@
  *      nn.SpatialConvolution      logical [Cout][Cin][kH][kW]  physical [Cout][kH][kW][Cin]
  *      nn.SpatialFullConvolution  logical [Cin][Cout][kH][kW]  physical [Cin][kH][kW][Cout]
  *    vf_nchw_to_nhwc / vf_nhwc_to_nchw convert reference-layout buffers at the boundary.
- *  - kernels: k = 4 only, (stride, pad) in {(2,1), (1,0)} — the only shapes the reference builds
- *    (train.lua:89-146,183-196).  Spatial sizes must be powers of two (fineSize = 128).
+ *  - convolutions: any square kernel / stride / padding is accepted.  The matrix-core kernels serve k = 4 with
+ *    (stride, pad) in {(2,1), (1,0)} on power-of-two maps — the shapes of the reference's main nets
+ *    (train.lua:89-146,183-196; fineSize 64 / 128 / 256) — everything else runs on the general kernels of
+ *    vf_conv_generic.hip behind the same entry points (see "Shapes" below; vf_conv_is_fast tells which).
  */
 #ifndef VF_HIP_H
 #define VF_HIP_H
@@ -356,7 +358,10 @@ int vf_bias_grad_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks1, in
  * a Lua / FFI host needs nothing besides this library.  RCCL is bound at run time (dlopen "librccl.so", or $VF_RCCL_LIB)
  * at the first call; the rest of the library does not depend on it.
  *
+ * vf_comm_available: 0 if RCCL can be bound in this process (local, non-collective: check it on every rank and let the ranks
+ *   agree BEFORE entering the collective vf_comm_init, so that a rank without RCCL does not leave the others waiting).
  * vf_comm_unique_id: rank 0 fills 128 opaque bytes; the host hands them to every rank (file, socket, MPI ...).
+ * vf_comm_init: on any failure the half-built communicator is released (RCCL comm aborted, stream / events destroyed).
  * vf_comm_init: collective over all ranks, on the CURRENT device (hipSetDevice first).
  * vf_comm_allreduce_async: in place, on the communicator's own stream, ordered after the work already given to ctx's
  *   stream; ctx's stream carries on (backward kernels overlap the bucket's flight).  dtype 0 = f32, 1 = f64;
@@ -368,6 +373,7 @@ int vf_bias_grad_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks1, in
  * vf_comm_barrier: host-blocking; both streams of every rank have drained. */
 typedef struct vf_comm vf_comm;
 #define VF_COMM_ID_BYTES 128
+int vf_comm_available(void);
 int vf_comm_unique_id(void* id128);
 int vf_comm_init(vf_comm** out, const void* id128, int world, int rank);
 int vf_comm_world(const vf_comm* c);

@@ -443,6 +443,102 @@ def test_data_parallel_with_local_batchnorm_is_the_mean_of_the_shard_gradients(k
     assert gD < 5e-6 and gG < 5e-5 and rm < 1e-6, (gD, gG, rm)
 
 
+# ------------------------------------------------------------------ collective bring-up of the C-ABI exchange (backend.bring_up_comm)
+class _FakeCommLib:
+    def __init__(self, avail):
+        self._avail = avail
+
+    def vf_comm_available(self):
+        return 0 if self._avail else 2
+
+
+class _FakeCommBackend:
+    """what bring_up_comm touches of a backend, without a GPU: `fail` names the stage this rank fails at"""
+
+    def __init__(self, fail):
+        self.lib = _FakeCommLib(fail != "avail")
+        self.fail, self.comm, self.destroyed = fail, None, 0
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def init_comm(self, world, rank, cid):
+        assert cid == bytes(range(128))
+        if self.fail == "init":
+            raise RuntimeError("ncclCommInitRank failed (injected)")
+        self.comm = object()
+
+    def destroy_comm(self):
+        if self.comm is not None:
+            self.destroyed += 1
+        self.comm = None
+
+
+def _bringup_worker(rank, world, port, fail_rank, stage, out_dir):
+    import json
+    import video_filler_amd.backend as vb
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    b = _FakeCommBackend(stage if rank == fail_rank else None)
+    real_verify = vb.verify_comm
+    vb.verify_comm = lambda backend, w, r, n=4096: not (stage == "verify" and r == fail_rank)
+    try:
+        ok, store = vb.bring_up_comm(b, world, rank)
+    finally:
+        vb.verify_comm = real_verify
+    with open(os.path.join(out_dir, "r%d.json" % rank), "w") as fh:
+        json.dump(dict(ok=ok, has_comm=b.comm is not None, destroyed=b.destroyed), fh)
+    # rank 0 hosts the store: it stays until every rank has written its file
+    import time
+    store.add("bye", 1)                  # (a rank's last use of the store)
+    while rank == 0 and store.add("bye", 0) < world:
+        time.sleep(0.02)
+
+
+@pytest.mark.parametrize("stage", [None, "avail", "init", "verify"])
+def test_comm_bring_up_is_decided_by_all_ranks_together(stage, tmp_path):
+    """a per-rank fallback can leave some ranks on vf_comm_* and others in torch.distributed, which hangs.  With
+    bring_up_comm a failure on ONE rank — RCCL not loadable, vf_comm_init raising, the start-up self-check of the collectives
+    failing — puts EVERY rank on the fallback, and no rank keeps a communicator; with no failure every rank keeps one."""
+    import json
+    world = 3
+    port = _dp_port(17 + [None, "avail", "init", "verify"].index(stage))
+    mp.spawn(_bringup_worker, args=(world, port, 1, stage, str(tmp_path)), nprocs=world, join=True)
+    res = [json.load(open(os.path.join(str(tmp_path), "r%d.json" % r))) for r in range(world)]
+    assert all(r["ok"] == (stage is None) for r in res), res
+    assert all(r["has_comm"] == (stage is None) for r in res), res
+    if stage == "verify":
+        assert all(r["destroyed"] == 1 for r in res)       # everyone had one, everyone dropped it
+
+
+def test_weight_planes_follow_the_parameter_version(cpu_backend):
+    """with the trainers managing the weight planes, a direct netG.forward after the iteration's last optim.adam
+    must not run on planes of the previous weights.  Host logic: every writer of a flat parameter vector bumps its version,
+    and a managed Sequential whose planes are older refreshes before it runs."""
+    from video_filler_amd import nn, optim
+    from video_filler_amd.backend import param_version
+    net = nn.Sequential().add(nn.SpatialConvolution(4, 8, 4, 4, 2, 2, 1, 1)).add(nn.LeakyReLU(0.2, True))
+    p, g = net.getParameters()
+    net.set_weight_planes_managed(True)
+    calls = []
+    real = net.refresh_weight_planes
+    net.refresh_weight_planes = lambda: (calls.append(1), real())[1]
+    x = torch.randn(2, 8, 8, 4).permute(0, 3, 1, 2)
+    net.forward(x)
+    n0 = len(calls)                       # first use: planes never split for this version
+    assert n0 == 1
+    net.forward(x)
+    assert len(calls) == n0               # nothing moved the parameters: no refresh
+    v = param_version(p)
+    optim.adam_update(p, g, {"learningRate": 1e-3})
+    assert param_version(p) == v + 1
+    net.forward(x)
+    assert len(calls) == n0 + 1           # the Adam step was seen
+    net.load_reference_flat(net.reference_flat().clone())
+    net.backward(x, torch.randn(2, 4, 4, 8).permute(0, 3, 1, 2))
+    assert len(calls) == n0 + 2           # a checkpoint load too, by the backward walk as well
+
+
 def test_whole_image_batched_tiles_equal_the_tile_loop(cpu_backend):
     """inference.WholeImageInpainter (all tiles in one batch) against the oracle's tile-by-tile restatement of
     test_vid_wholeim.lua:150-226, both on the CPU: the batching, the vflip rule and the masked paste."""

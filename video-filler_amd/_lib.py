@@ -95,6 +95,7 @@ SIGNATURES = {
     "vf_conv_is_fast": (i32, [i32, i32, i32, i32, i32]),
     "vf_conv2d_bwd_weight_planes": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32]),
     "vf_deconv2d_bwd_weight_planes": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32]),
+    "vf_comm_available": (i32, []),
     "vf_comm_unique_id": (i32, [vp]),
     "vf_comm_init": (i32, [C.POINTER(vp), vp, i32, i32]),
     "vf_comm_world": (i32, [vp]),

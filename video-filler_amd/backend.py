@@ -70,6 +70,109 @@ def exchange_comm_id(backend, world, rank, addr=None, port=None, timeout_s=300):
     return bytes(store.get("vf_comm_id")), store
 
 
+def bring_up_comm(backend, world, rank, addr=None, port=None, verify=True):
+    """Collective bring-up of the C-ABI exchange (vf_comm_*): EVERY rank ends up on the same path.
+
+    Returns (ok, store).  ok = True: `backend.comm` is a verified communicator on all ranks.  ok = False: no rank holds
+    one (any that had been created is destroyed) and the host runs the exchange through torch.distributed instead.
+    The ranks agree through the TCP store the launcher serves, never through a collective that a failed rank would miss:
+      1. every rank checks locally that RCCL can be bound (vf_comm_available) and publishes the result; all read all;
+      2. only if every rank can: rank 0's id goes round, vf_comm_init (collective);
+      3. verify: an all-reduce (sum, average), a reduce-scatter + all-gather and a broadcast of known vectors are compared
+         with their closed-form results on every rank; the verdicts go round the same way."""
+    import datetime
+    from torch.distributed import TCPStore
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or os.environ["MASTER_PORT"])
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = TCPStore(addr, port, world, (rank == 0) and not agent, timeout=datetime.timedelta(seconds=300))
+    if agent:
+        from torch.distributed import PrefixStore
+        store = PrefixStore("vf_comm/%s" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), store)
+
+    def agree(tag, ok):
+        store.set("%s/%d" % (tag, rank), "1" if ok else "0")
+        return all(bytes(store.get("%s/%d" % (tag, r))) == b"1" for r in range(world))
+
+    local_ok = backend.lib.vf_comm_available() == 0
+    if not agree("vf_comm_avail", local_ok):
+        return False, store
+    if rank == 0:
+        store.set("vf_comm_id", backend.comm_unique_id())
+    cid = bytes(store.get("vf_comm_id"))
+    try:
+        backend.init_comm(world, rank, cid)
+        init_ok = True
+    except Exception as e:      # noqa: BLE001 — reported, and decided on by all ranks together below
+        import sys
+        sys.stderr.write("video-filler_amd: vf_comm_init failed on rank %d (%s: %s)\n" % (rank, type(e).__name__, e))
+        init_ok = False
+    if not agree("vf_comm_init", init_ok):
+        backend.destroy_comm()
+        return False, store
+    ver_ok = True
+    if verify:
+        try:
+            ver_ok = verify_comm(backend, world, rank)
+        except Exception as e:  # noqa: BLE001
+            import sys
+            sys.stderr.write("video-filler_amd: vf_comm self-check raised on rank %d (%s: %s)\n" % (rank, type(e).__name__, e))
+            ver_ok = False
+    if not agree("vf_comm_verify", ver_ok):
+        backend.destroy_comm()
+        return False, store
+    return True, store
+
+
+def verify_comm(backend, world, rank, n=4096):
+    """closed-form checks of every collective the iteration uses, on this rank's communicator (bring_up_comm, tests)"""
+    dev = backend.device
+    base = torch.arange(n, dtype=torch.float32, device=dev) * 0.25 + 1.0
+    # all-reduce average of (rank + 1) * base  ->  base * (world + 1) / 2 ; async form with a wait
+    t = base * float(rank + 1)
+    backend.all_reduce_avg(t, world)
+    ok = bool(torch.allclose(t, base * ((world + 1) / 2.0), rtol=1e-6, atol=0))
+    # inline sum in double (SyncBN's sums)
+    d = torch.full((64,), float(rank + 1), dtype=torch.float64, device=dev)
+    backend.all_reduce(d)
+    ok = ok and bool((d == world * (world + 1) / 2.0).all())
+    # reduce-scatter (mean) + all-gather: every shard of the result is the mean over ranks
+    m = (n // world) * world
+    t = (base[:m] * float(rank + 1)).contiguous()
+    shard = backend.reduce_scatter_avg(t, world, rank)
+    k = m // world
+    ok = ok and bool(torch.allclose(shard, base[rank * k:(rank + 1) * k] * ((world + 1) / 2.0), rtol=1e-6, atol=0))
+    t[rank * k:(rank + 1) * k] = float(rank)            # every rank marks its own shard, all-gather spreads the marks
+    backend.all_gather_shards(t, world, rank)
+    want = torch.arange(world, dtype=torch.float32, device=dev).repeat_interleave(k)
+    ok = ok and bool((t == want).all())
+    # broadcast from rank 0
+    b = torch.full((256,), float(rank + 7), dtype=torch.float32, device=dev)
+    backend.comm_broadcast(b, 0)
+    ok = ok and bool((b == 7.0).all())
+    torch.cuda.synchronize(dev)
+    return ok
+
+
+# ---- parameter versions: who moved a flat parameter vector last.  optim.adam_update / load_reference_flat bump the
+#      version of the storage they wrote; a net whose weight planes (bf16 shadows of its conv weights, vf_pgemm.hip) were
+#      split from an older version refreshes them before its next forward / backward, whoever calls it.
+_PARAM_VERSION = {}
+
+
+def _storage_key(t):
+    return t.untyped_storage().data_ptr()
+
+
+def bump_param_version(t):
+    k = _storage_key(t)
+    _PARAM_VERSION[k] = _PARAM_VERSION.get(k, 0) + 1
+
+
+def param_version(t):
+    return _PARAM_VERSION.get(_storage_key(t), 0)
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -26,6 +26,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional (older RCCLs): NULL -> CommDestroy
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -56,6 +57,7 @@ int rccl_bind() {
   VF_SYM(AllGather, "ncclAllGather");
   VF_SYM(GetErrorString, "ncclGetErrorString");
 #undef VF_SYM
+  *(void**)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
   g_rccl.h = h;
   return 0;
 }
@@ -107,21 +109,52 @@ VF_API int vf_comm_unique_id(void* id128) {
   return 0;
 }
 
-// one communicator per process, on the CURRENT device (hipSetDevice first); collective over all `world` ranks
+// everything vf_comm_init builds after `new vf_comm`: a failure at any step returns non-zero with `c` half-built, and the
+// caller releases exactly what exists (comm_release)
+static int comm_build(vf_comm* c, const void* id128) {
+  VF_CHECK_HIP(hipGetDevice(&c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  VF_CHECK_RCCL(g_rccl.CommInitRank(&c->comm, c->world, id, c->rank));
+  VF_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  VF_CHECK_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+  for (int i = 0; i < RING; ++i) VF_CHECK_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+  return 0;
+}
+
+// releases whatever of a communicator exists (also a half-built one); never touches the error message of the failure
+// that brought us here
+static void comm_release(vf_comm* c, bool abort_comm) {
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) {
+    if (abort_comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+    else (void)g_rccl.CommDestroy(c->comm);
+  }
+  for (int i = 0; i < RING; ++i)
+    if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+  if (c->ready) (void)hipEventDestroy(c->ready);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// 0 when RCCL can be bound in this process (non-collective: a host checks this on EVERY rank, and lets the ranks agree,
+// before any of them enters the collective vf_comm_init — a rank that cannot load RCCL must not leave the others waiting in it)
+VF_API int vf_comm_available(void) { return rccl_bind(); }
+
+// one communicator per process, on the CURRENT device (hipSetDevice first); collective over all `world` ranks.
+// On failure nothing is leaked: the partial RCCL communicator is aborted, stream and events destroyed, *out left NULL.
 VF_API int vf_comm_init(vf_comm** out, const void* id128, int world, int rank) {
   VF_REQUIRE(out != nullptr && id128 != nullptr, "vf_comm_init: NULL argument");
   VF_REQUIRE(world >= 1 && rank >= 0 && rank < world, "vf_comm_init: rank %d of %d", rank, world);
+  *out = nullptr;
   if (int rc = rccl_bind()) return rc;
   vf_comm* c = new vf_comm();
   c->world = world;
   c->rank = rank;
-  VF_CHECK_HIP(hipGetDevice(&c->device));
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof(id));
-  VF_CHECK_RCCL(g_rccl.CommInitRank(&c->comm, world, id, rank));
-  VF_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  VF_CHECK_HIP(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-  for (int i = 0; i < RING; ++i) VF_CHECK_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+  if (int rc = comm_build(c, id128)) {
+    comm_release(c, true);
+    return rc;
+  }
   *out = c;
   return 0;
 }
@@ -231,12 +264,6 @@ VF_API int vf_comm_barrier(vf_comm* c, vf_ctx* ctx) {
 
 VF_API int vf_comm_destroy(vf_comm* c) {
   if (!c) return 0;
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  if (c->comm) VF_CHECK_RCCL(g_rccl.CommDestroy(c->comm));
-  for (int i = 0; i < RING; ++i)
-    if (c->done[i]) (void)hipEventDestroy(c->done[i]);
-  if (c->ready) (void)hipEventDestroy(c->ready);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
-  delete c;
+  comm_release(c, false);
   return 0;
 }

@@ -91,6 +91,7 @@ int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
 int vf_wgrad_group_abort(vf_ctx* ctx);
 typedef struct vf_comm vf_comm;
+int vf_comm_available(void);
 int vf_comm_unique_id(void* id128);
 int vf_comm_init(vf_comm** out, const void* id128, int world, int rank);
 int vf_comm_allreduce_async(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op, int* ticket);

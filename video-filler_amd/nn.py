@@ -19,7 +19,7 @@ Differences from Torch7 that are deliberate and documented in DESIGN.md:
 """
 import torch
 
-from .backend import get_backend, is_nhwc, to_nhwc
+from .backend import bump_param_version, get_backend, is_nhwc, param_version, to_nhwc
 
 
 # ---------------------------------------------------------------------------------------------- scalars
@@ -791,7 +791,7 @@ class Sequential(Module):
         pre_rows = 0
         cur_pl = None             # bf16 planes of `cur`, when its producer wrote them
         managed = self._wp_managed
-        if not managed:
+        if not managed or self._wp_stale():
             self.refresh_weight_planes()
             managed = True
         for idx, (m, a) in enumerate(plan):
@@ -867,7 +867,7 @@ class Sequential(Module):
         bn_pre, pre = 0, [0]      # partial rows the data-gradient pass above left for the BatchNorm about to be walked
         g_pl = None               # bf16 planes of `g`, when its producer (a BatchNorm backward) wrote them
         managed = self._wp_managed
-        if not managed:
+        if not managed or self._wp_stale():
             self.refresh_weight_planes()
             managed = True
         if hi < len(plan) and self._bn_pre_at is not None and self._bn_pre_at[0] == hi:
@@ -1009,6 +1009,8 @@ class Sequential(Module):
         A trainer calls this after each optim.adam (set_weight_planes_managed); on its own a Sequential refreshes at the
         start of every forward and backward call, so edits of the weights by any means are always seen."""
         B = get_backend()
+        if self._flat is not None:
+            self._wp_version = param_version(self._flat[0])
         if _NO_PCONV or getattr(B, "mfma_mode", None) != "f32_3xbf16" or not hasattr(B, "weight_planes_multi"):
             return
         # the layers that have taken the planes path at least once (SpatialConvolution.weight_planes marks them)
@@ -1020,6 +1022,12 @@ class Sequential(Module):
         if self._wp_plan is None or self._wp_plan[3] != key:
             self._wp_plan = B.weight_planes_multi([(m.weight, m._wp[0], m._wp[1]) for m in mods])
         B.weight_planes_run(self._wp_plan)
+
+    def _wp_stale(self):
+        """managed mode: has anyone (optim.adam_update, load_reference_flat) written the flat parameters since the planes were
+        last split?  The owner's explicit refresh points make this False on the hot path; a forward after the last Adam step
+        of an iteration (train.lua:437-439's display pass, evaluation, a checkpointed net) finds it True and refreshes."""
+        return self._flat is not None and param_version(self._flat[0]) != getattr(self, "_wp_version", -1)
 
     def set_weight_planes_managed(self, on=True):
         self._wp_managed = bool(on)
@@ -1133,6 +1141,7 @@ class Sequential(Module):
             t.copy_(vec[off:off + n].reshape(t.shape))
             off += n
         assert off == vec.numel()
+        bump_param_version(self._flat[0])
 
     def n_parameters(self):
         return sum(n for *_, n in self._flat[2])

@@ -6,7 +6,7 @@ itself is ONE fused kernel pass (vf_adam_step).  Defaults as optim.adam: beta1 0
 """
 import torch
 
-from .backend import get_backend
+from .backend import bump_param_version, get_backend
 
 
 def adam(opfunc, x, state):
@@ -38,6 +38,7 @@ def adam_update(x, dfdx, state):
         adam_init(x, state)
     state["t"] += 1          # host mirror of the device counter (informational)
     B.adam_step(x, dfdx, state["m"], state["v"], lr, beta1, beta2, eps, state["t_dev"])
+    bump_param_version(x)    # (weight planes split from the old values are stale now: nn.Sequential checks)
 
 
 def adam_update_split(x, dfdx, state, side_ranges, side):
@@ -61,3 +62,4 @@ def adam_update_split(x, dfdx, state, side_ranges, side):
         if lo > pos:
             B.adam_apply(x[pos:lo], dfdx[pos:lo], m[pos:lo], v[pos:lo], beta1, beta2, eps, t_dev)
         pos = hi
+    bump_param_version(x)

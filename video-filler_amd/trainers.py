@@ -180,6 +180,18 @@ def _no_range(name):
     return contextlib.nullcontext()
 
 
+def _eager_sync_every():
+    """Bound on un-synchronised eager iterations (~150-270 launches each).  Under a counter-collecting profiler every dispatch is
+    serialised behind the tool's own packets and ~12 k queued dispatches ended in a fault inside the runtime/profiler dispatch
+    path; so with a rocprofiler tool library in the process (or VF_EAGER_SYNC_EVERY set) the eager loop drains
+    the device every N iterations.  0 = never (the default without a profiler: nothing is gained by waiting)."""
+    v = os.environ.get("VF_EAGER_SYNC_EVERY")
+    if v is not None:
+        return max(int(v), 0)
+    tools = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    return 64 if "rocprof" in tools else 0
+
+
 class _TrainerBase:
     def _finish_init(self, seed, world, rank, group, sync_bn, skip_dead_grads, overlap=True, shard_adam=False):
         # stream-level overlap: weight gradients beside the data-gradient chain (both nets) and netG's forward
@@ -354,6 +366,13 @@ class _TrainerBase:
         28 B/param HBM-bound update then overlaps MFMA-bound work.  Same arithmetic, same order on every buffer;
         `flush()` applies a pending update (call it before reading parametersG)."""
         B = get_backend()
+        every = self.__dict__.get("_sync_every")
+        if every is None:
+            every = self._sync_every = _eager_sync_every()
+        if every and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            self._eager_n = self.__dict__.get("_eager_n", 0) + 1
+            if self._eager_n % every == 0:
+                torch.cuda.synchronize()
         rng = B.range if hasattr(B, "range") else _no_range         # roctx ranges of the two optimiser calls (rocprofv3 --marker-trace)
         with rng("optim.adam(fDx)"):
             optim.adam(self.fDx, self.parametersD, self.optimStateD)
