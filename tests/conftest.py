@@ -21,13 +21,29 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def hipb():
-    """The HIP backend.  No skip: on a GPU box a missing GPU/library must fail loudly."""
+    """The HIP backend, exactly as shipped (no skip: on a GPU box a missing GPU/library must fail loudly).  In particular the
+    planes gate (nn._PCONV_MIN_GFLOP: which conv passes take the pre-split-operand kernels of vf_pgemm.hip) is the shipped one;
+    tests that must exercise the planes path on the suite's small nets ask for the `planes_gate` fixture."""
     import video_filler_amd  # noqa: F401
-    from video_filler_amd import nn
     from video_filler_amd.backend import get_backend
-    # The trainers route a conv pass through the planes kernels (vf_pgemm.hip) only from 3 GFLOP per pass up
-    # (nn._PCONV_MIN_GFLOP: below that the path's fixed costs outweigh its faster GEMMs).  The suite's nets are small: drop the
-    # gate so that every pass with >= 1024 GEMM rows takes the planes path and its BatchNorm / weight-plane plumbing is what
-    # the parity tests exercise; test_planes_path_gate checks the shipped threshold itself.
-    nn._PCONV_MIN_GFLOP = 0.0
     return get_backend()
+
+
+PLANES_GATES = ["planes", "shipped"]
+
+
+@pytest.fixture(params=PLANES_GATES)
+def planes_gate(request, hipb):
+    """Both routings of the 4x4 stride-2 conv passes, per test:
+      planes   gate dropped to 0: every pass with >= 1024 GEMM rows takes the planes kernels (k_pconv_dma / k_pwgrad_group), their
+               BatchNorm-written operand planes and the weight-plane refresh — what configs[1] runs at batchSize 64, here on the
+               suite's small nets;
+      shipped  the shipped threshold (3 GFLOP per pass): on small nets / batches every pass stays on k_igemm with the BatchNorm
+               statistics from its epilogue — what configs[2] and configs[4] run at their batch sizes (VERDICT r2 weak #2)."""
+    from video_filler_amd import nn
+    old = nn._PCONV_MIN_GFLOP
+    nn._PCONV_MIN_GFLOP = 0.0 if request.param == "planes" else nn.PCONV_MIN_GFLOP_SHIPPED
+    try:
+        yield request.param
+    finally:
+        nn._PCONV_MIN_GFLOP = old

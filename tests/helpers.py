@@ -86,6 +86,9 @@ class KinkSync:
         self.pos = {}
         self.touched = 0
         self.checked = 0
+        self.calls = 0
+        self.edited_calls = 0
+        self.max_touched_frac = 1e-4
 
     def _oleaves(self, m):
         if hasattr(m, "modules"):
@@ -107,10 +110,10 @@ class KinkSync:
             self.rec.setdefault(id(m), []).append(y)
         return out
 
-    def __call__(self, a, y):                 # nn.Sequential.act_hook
+    def __call__(self, a, y):                 # nn.Sequential.act_hook; returns True iff it edited `y`
         ra = self.map.get(id(a))
         if ra is None:
-            return
+            return False
         passes = self.rec[id(ra)]
         k = self.pos.get(id(ra), 0)
         ref = passes[k]
@@ -122,18 +125,34 @@ class KinkSync:
         assert tuple(y.shape) == ref.shape, (tuple(y.shape), ref.shape)
         r = torch.from_numpy(ref).to(y.device)
         near = r.abs() < self.delta * max(1.0, float(np.abs(ref).max()))
-        self.touched += int((near & (r != y)).sum().item())
+        n_edit = int((near & (r != y)).sum().item())
+        self.touched += n_edit
         self.checked += y.numel()
-        y.copy_(torch.where(near, r, y))
+        self.calls += 1
+        if n_edit:
+            y.copy_(torch.where(near, r, y))
+        self.edited_calls += 1 if n_edit else 0
+        return n_edit > 0
 
     def hip_step(self, fn):
         import video_filler_amd.nn as hnn
         hnn.Sequential.act_hook = self
+        t0, c0 = self.touched, self.checked
         try:
-            return fn()
+            out = fn()
         finally:
             hnn.Sequential.act_hook = None
-        # every recorded pass must have been consumed
+        # every recorded pass must have been consumed: a HIP-side (Leaky)ReLU the hook never saw would go unpinned
+        for rid, passes in self.rec.items():
+            assert self.pos.get(rid, 0) == len(passes), "an oracle activation pass was not consumed by the HIP run (%d of %d)" % (
+                self.pos.get(rid, 0), len(passes))
+        # the pin is a handful of elements: if it ever rewrites more than 1e-4 of what it looks at, the forward pass is wrong
+        # in the neighbourhood of 0 and the pin would be hiding it
+        touched, checked = self.touched - t0, self.checked - c0
+        assert checked > 0, "the hook was never called: nothing was pinned"
+        assert touched <= max(self.max_touched_frac * checked, 8), "KinkSync rewrote %d of %d activations (> %g): forward error near 0" % (
+            touched, checked, self.max_touched_frac)
+        return out
 
 
 def attach_world1_comm(hipb):

@@ -166,7 +166,7 @@ def _vid_batch(Bn, nc_in, nc_out, seed):
 
 
 @pytest.mark.parametrize("cfg", ["vid16", "wholeim", "wholeim-bf16"])
-def test_full_width_video_iterations_are_deterministic_and_finite(cfg, hipb):
+def test_full_width_video_iterations_are_deterministic_and_finite(cfg, hipb, planes_gate):
     """configs[2] at its batch size (16 clips of 48 channels) and configs[4] at its per-GPU batch size (4, with the GDL value
     path on), three iterations, twice: finite, in range, bitwise repeatable.  `wholeim-bf16` is BASELINE.json's bf16 variant
     of configs[4]: operands of the conv products rounded to bf16 (vf_ctx_set_mfma_mode 1), everything else fp32; its
@@ -236,7 +236,7 @@ def _golden_full():
 
 
 @pytest.mark.parametrize("name", ["center8", "vid16", "wholeim"])
-def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb):
+def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb, planes_gate):
     """One whole iteration (fDx + Adam + fGx + Adam) at FULL net width against the CPU oracle's result for the same seeds,
     computed in the build container and committed (tests/golden/full_<name>.npz; `center8` is BASELINE.json configs[0]: the
     train.lua recipe at batchSize 8, nBottleneck 4000).  Bars: losses 2e-5; generator output 1e-4 of its max; gradient
@@ -279,7 +279,7 @@ def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb):
 
 
 @pytest.mark.parametrize("cfg", ["vid16", "wholeim-half"])
-def test_video_nets_against_the_oracle_at_run_time(cfg, oracle, hipb):
+def test_video_nets_against_the_oracle_at_run_time(cfg, oracle, hipb, planes_gate):
     """The oracle itself beside the HIP path, from identical weights and batches, one iteration with every (Leaky)ReLU
     kink pinned (helpers.KinkSync) so that gradients are held to 1e-4:
       vid16         configs[2] at FULL width (48 channels, nBottleneck 4000), batchSize 4 of its 16;

@@ -156,3 +156,191 @@ def test_weight_gradient_from_planes(Bn, Cin, H, Cout, grouped, hipb):
         got = hipb.zeros(Cout, 4, 4, Cin).permute(0, 3, 1, 2)
         hipb.conv2d_bwd_weight(x, gy, got, None, 4, 2, 1, 0.0, xp, gp)
         assert float((got.cpu().double() - wz.grad).abs().max() / wz.grad.abs().max()) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ against the ORACLE
+# (the comparisons above are HIP against HIP.)  The same passes against the CPU oracle's im2col + GEMM
+# restatement of THNN (oracle.SpatialConvolution / SpatialFullConvolution), at the bar of tests/test_gpu_ops.py: 2e-5 of the
+# tensor's max-norm.  Sizes the oracle finishes in seconds with 16 threads.
+ORACLE_CASES = [(4, 64, 32, 128), (8, 64, 64, 64), (4, 128, 16, 256), (3, 256, 8, 512), (2, 192, 32, 384), (6, 32, 32, 96),
+                (16, 64, 32, 64)]
+
+
+def _to_dev(a, dev):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) if t.dim() == 4 else t
+
+
+def _np(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+def _err(got, want):
+    return float(np.abs(_np(got).astype(np.float64) - want).max() / (np.abs(want).max() + 1e-30))
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout", ORACLE_CASES, ids=lambda v: str(v))
+def test_planes_conv_passes_against_the_oracle(Bn, Cin, H, Cout, oracle, hipb):
+    """nn.SpatialConvolution Cin -> Cout, 4x4 stride 2 pad 1, every pass from pre-split planes: forward (+ bias + LeakyReLU)
+    on vf_pconv_gather, data-gradient on vf_pconv_scatter, weight gradient on vf_conv2d_bwd_weight_planes (k_pwgrad_group where
+    the shape allows, the fp32-operand kernel otherwise) — against oracle.SpatialConvolution (train.lua:89-101)."""
+    dev = hipb.device
+    rng = np.random.default_rng(Bn * 1000 + Cin + Cout)
+    oracle.set_num_threads(16)
+    try:
+        ref = oracle.SpatialConvolution(Cin, Cout, 4, 4, 2, 2, 1, 1)
+        ref.weight[...] = rng.standard_normal(ref.weight.shape).astype(np.float32) * 0.05
+        ref.bias[...] = rng.standard_normal(Cout).astype(np.float32) * 0.1
+        x = rng.standard_normal((Bn, Cin, H, H)).astype(np.float32)
+        y = ref.forward(x).copy()
+        gy = rng.standard_normal(y.shape).astype(np.float32)
+        ref.gradWeight[...] = 0
+        ref.gradBias[...] = 0
+        ref.backward(x, gy)
+    finally:
+        oracle.set_num_threads(1)
+    dx, dw, db, dgy = _to_dev(x, dev), _to_dev(ref.weight, dev), _to_dev(ref.bias, dev), _to_dev(gy, dev)
+    xp, gp = hipb.planes_split(dx), hipb.planes_split(dgy)
+    wn, wt = hipb.weight_planes(dw)
+    assert hipb.pconv_supported(Bn, H, H, Cin, Cout, 4, 2, 1, False)
+    got = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+    hipb.pconv_gather(xp, wn, db, got, Bn, H, H, Cin, Cout, "lrelu", 0.2)
+    assert _err(got, np.where(y > 0, y, 0.2 * y)) <= 2e-5
+    if hipb.pconv_supported(Bn, H // 2, H // 2, Cout, Cin, 4, 2, 1, True):
+        gx = hipb.empty_act(Bn, Cin, H, H)
+        hipb.pconv_scatter(gp, wt, None, gx, Bn, H // 2, H // 2, Cout, Cin)
+        assert _err(gx, ref.gradInput) <= 2e-5
+    gw = torch.zeros_like(dw)
+    gb = hipb.zeros(Cout)
+    hipb.conv2d_bwd_weight(dx, dgy, gw, gb, 4, 2, 1, 0.0, xp, gp)
+    assert _err(gw, ref.gradWeight) <= 2e-5
+    assert _err(gb, ref.gradBias) <= 2e-5
+    hipb.wgrad_group_begin()                                   # and recorded into a group, accumulating: exactly twice
+    hipb.conv2d_bwd_weight(dx, dgy, gw, gb, 4, 2, 1, 1.0, xp, gp)
+    hipb.wgrad_group_end()
+    assert _err(gw, 2 * ref.gradWeight) <= 2e-5
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout", ORACLE_CASES, ids=lambda v: str(v))
+def test_planes_full_conv_passes_against_the_oracle(Bn, Cin, H, Cout, oracle, hipb):
+    """nn.SpatialFullConvolution Cout -> Cin (the decoder direction over the same pair of maps: H/2 -> H), every pass from
+    planes: forward (+ bias + ReLU) on vf_pconv_scatter, data-gradient on vf_pconv_gather, weight gradient on
+    vf_deconv2d_bwd_weight_planes — against oracle.SpatialFullConvolution (train.lua:134-146)."""
+    dev = hipb.device
+    rng = np.random.default_rng(Bn * 1000 + Cin + Cout + 1)
+    Hl = H // 2
+    if not hipb.pconv_supported(Bn, Hl, Hl, Cout, Cin, 4, 2, 1, True):
+        pytest.skip("the low-resolution operand's channel count is not a multiple of 32")
+    oracle.set_num_threads(16)
+    try:
+        ref = oracle.SpatialFullConvolution(Cout, Cin, 4, 4, 2, 2, 1, 1)
+        ref.weight[...] = rng.standard_normal(ref.weight.shape).astype(np.float32) * 0.05
+        ref.bias[...] = rng.standard_normal(Cin).astype(np.float32) * 0.1
+        x = rng.standard_normal((Bn, Cout, Hl, Hl)).astype(np.float32)
+        y = ref.forward(x).copy()
+        gy = rng.standard_normal(y.shape).astype(np.float32)
+        ref.gradWeight[...] = 0
+        ref.gradBias[...] = 0
+        ref.backward(x, gy)
+    finally:
+        oracle.set_num_threads(1)
+    dx, dw, db, dgy = _to_dev(x, dev), _to_dev(ref.weight, dev), _to_dev(ref.bias, dev), _to_dev(gy, dev)
+    xp, gp = hipb.planes_split(dx), hipb.planes_split(dgy)
+    wn, wt = hipb.weight_planes(dw)                            # physical [Cout][16][Cin]; transposed [Cin][16][Cout]
+    got = hipb.empty_act(Bn, Cin, H, H)
+    hipb.pconv_scatter(xp, wt, db, got, Bn, Hl, Hl, Cout, Cin, "relu", 0.0)
+    assert _err(got, np.maximum(y, 0)) <= 2e-5
+    gx = hipb.empty_act(Bn, Cout, Hl, Hl)
+    hipb.pconv_gather(gp, wn, None, gx, Bn, H, H, Cin, Cout)
+    assert _err(gx, ref.gradInput) <= 2e-5
+    gw = torch.zeros_like(dw)
+    gb = hipb.zeros(Cin)
+    hipb.deconv2d_bwd_weight(dx, dgy, gw, gb, 4, 2, 1, 0.0, xp, gp)
+    assert _err(gw, ref.gradWeight) <= 2e-5
+    assert _err(gb, ref.gradBias) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ producer-written planes
+def _same_planes(a, b):
+    return torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("Bn,C,H,groups,act", [(4, 64, 32, 1, "lrelu"), (8, 128, 16, 2, "lrelu"), (6, 256, 8, 1, "relu"),
+                                               (4, 64, 16, 2, "none"), (64, 64, 32, 1, "lrelu")])
+def test_batchnorm_written_planes_are_the_split_of_its_output(Bn, C, H, groups, act, hipb):
+    """The planes a BatchNorm writes beside its output (forward: y_planes; backward: gx_planes) for a planes-fed consumer must
+    be BIT FOR BIT vf_planes_split of the fp32 tensor it wrote — otherwise the consumer convolves another tensor than the one
+    the weight gradient, the next BatchNorm and the oracle comparison see.  Both forms: statistics pass included
+    (vf_bn_train_fwd_planes / vf_bn_bwd_planes) and statistics from the neighbouring GEMM (vf_bn_train_fwd_pre / vf_bn_bwd_pre)."""
+    from video_filler_amd import nn
+    dev = hipb.device
+    x = _act(Bn, C, H, 11, dev) * 1.3 + 0.2
+    gy = _act(Bn, C, H, 12, dev)
+    gamma, beta = _rand((C,), 13, dev, 0.1) + 1.0, _rand((C,), 14, dev, 0.1)
+    rm, rv = hipb.zeros(C), hipb.zeros(C) + 1.0
+    sm, si = hipb.zeros(groups * C), hipb.zeros(groups * C)
+    sums = hipb.zeros(groups * 2 * C, dtype=torch.float64)
+    y = hipb.empty_act(Bn, C, H, H)
+    yp = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=dev)
+    hipb.bn_train_fwd_groups(x, y, gamma, beta, rm, rv, sm, si, sums, groups, 0.1, 1e-5, act, 0.2, y_planes=yp)
+    assert _same_planes(yp, hipb.planes_split(y))
+    gx = hipb.empty_act(Bn, C, H, H)
+    gxp = torch.empty((3, gx.numel()), dtype=torch.bfloat16, device=dev)
+    gg, gb = hipb.zeros(C), hipb.zeros(C)
+    hipb.bn_bwd_groups(x, y if act != "none" else None, gy, gx, gg, gb, gamma, sm, si, sums, groups, act, 0.2, 0.0, gx_planes=gxp)
+    assert _same_planes(gxp, hipb.planes_split(gx))
+    # the same two through nn.Sequential with the statistics coming out of the GEMMs on either side (the _pre forms):
+    # conv -> BN -> act -> conv, gate dropped so that the second conv is planes-fed and asks the BatchNorm for planes
+    old = nn._PCONV_MIN_GFLOP
+    nn._PCONV_MIN_GFLOP = 0.0
+    try:
+        A = (lambda: nn.LeakyReLU(0.2, True)) if act != "relu" else (lambda: nn.ReLU(True))
+        net = nn.Sequential()
+        net.add(nn.SpatialConvolution(C, C, 4, 4, 2, 2, 1, 1)).add(nn.SpatialBatchNormalization(C))
+        if act != "none":
+            net.add(A())
+        net.add(nn.SpatialConvolution(C, C, 4, 4, 2, 2, 1, 1)).add(nn.SpatialBatchNormalization(C))
+        if act != "none":
+            net.add(A())
+        net.add(nn.SpatialConvolution(C, 64, 4, 4, 2, 2, 1, 1))
+        net.getParameters()
+        gen = torch.Generator().manual_seed(3)
+        for m in net.leaves():
+            if isinstance(m, nn.SpatialConvolution):
+                m.weight.copy_((torch.randn(m.weight.shape, generator=gen) * 0.05).to(dev))
+        net.setBatchGroups(groups)
+        xin = _act(Bn, C, 4 * H, 15, dev)
+        out = net.forward(xin)
+        bns = [m for m in net.leaves() if isinstance(m, nn.SpatialBatchNormalization)]
+        seen = 0
+        for m in bns:
+            if m.output_planes is not None:
+                assert _same_planes(m.output_planes, hipb.planes_split(m.output)), "forward planes of a BatchNorm (pre form)"
+                seen += 1
+        net.zeroGradParameters()
+        net.backward(xin, _act(Bn, 64, out.shape[2], 16, dev))
+        for m in bns:
+            if m.grad_planes is not None:
+                assert _same_planes(m.grad_planes, hipb.planes_split(m.gradInput)), "gradient planes of a BatchNorm (pre form)"
+                seen += 1
+        if Bn * H * H >= 1024:
+            assert seen >= 2, "the planes hand-off did not happen: nothing was checked"
+    finally:
+        nn._PCONV_MIN_GFLOP = old
+
+
+@pytest.mark.parametrize("Bn,H,Cout,act", [(4, 64, 64, "lrelu"), (8, 128, 64, "lrelu"), (2, 32, 128, "none"), (64, 64, 64, "lrelu")])
+def test_thin_input_conv_written_planes_are_the_split_of_its_output(Bn, H, Cout, act, hipb):
+    """vf_conv2d_fwd_planes (the 3-channel image-side layers, train.lua:89,183): planes from the epilogue == split of y, and y
+    itself == vf_conv2d_fwd's, bit for bit."""
+    dev = hipb.device
+    x = _act(Bn, 3, H, 21, dev)
+    w = _rand((Cout, 4, 4, 3), 22, dev, 0.05).permute(0, 3, 1, 2)
+    b = _rand((Cout,), 23, dev, 0.1)
+    y = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+    yp = torch.empty((3, y.numel()), dtype=torch.bfloat16, device=dev)
+    hipb.conv2d_fwd_planes(x, w, b, y, yp, 4, 2, 1, act, 0.2)
+    assert _same_planes(yp, hipb.planes_split(y))
+    y2 = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+    hipb.conv2d_fwd(x, w, b, y2, 4, 2, 1, act, 0.2)
+    assert torch.equal(y, y2)

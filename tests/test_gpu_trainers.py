@@ -120,7 +120,7 @@ def _load(tr, ref):
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("fuse,lazy,skip,batch_d", [(True, True, True, False), (False, False, False, False),
                                                     (True, True, True, True), (False, False, False, True)])
-def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle, hipb):
+def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle, hipb, planes_gate):
     """batch_d: netD's real and fake passes as one batch of 2B with two BatchNorm groups — same oracle, same bars."""
     from video_filler_amd.trainers import CenterTrainer
     opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4, smooth=smooth)
@@ -142,7 +142,7 @@ def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle
 
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("variant", ["conditionAdv", "noiseGen", "both"])
-def test_center_trainer_option_branches(variant, smooth, oracle, hipb):
+def test_center_trainer_option_branches(variant, smooth, oracle, hipb, planes_gate):
     """train.lua's option branches: conditionAdv (netD over {context, prediction}: two 5x5 stride-2 convs, pad 2 and
     2+32, joined; df_dg[2]) and noiseGen (netG over {context, noise}: 1x1 noise conv joined to the bottleneck; noise
     drawn per iteration from the counter-based generator both sides restate).  Same bars as the main recipe."""
@@ -169,7 +169,7 @@ def test_center_trainer_option_branches(variant, smooth, oracle, hipb):
 @pytest.mark.parametrize("batch_d", [False, True])
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim", "logoNet", "withInit", "ext256"])
-def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
+def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb, planes_gate):
     from video_filler_amd.trainers import VidTrainer, build_netG
     if variant == "weighted":          # train_vid_weighted.lua defaults, predLen = 2
         opt = dict(nBottleneck=64, predLen=2)
@@ -222,7 +222,7 @@ def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb):
         _resync(ref, tr)
 
 
-def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hipb):
+def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hipb, planes_gate):
     """Nothing is carried over from the oracle: after the common start both sides run three whole iterations on their
     own parameters, Adam moments and BatchNorm running statistics.  Adam's first steps move a weight by up to one
     learning rate whatever the size of its gradient, and the sign of a gradient that is pure rounding noise (conv biases
@@ -263,7 +263,8 @@ def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hip
     import json
     import os
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", "drift_report.json"), "w") as fh:
+    report["kink_pin"] = dict(touched=ks.touched, checked=ks.checked, frac=ks.touched / max(ks.checked, 1))
+    with open(os.path.join("gpurun_out", "drift_report_%s.json" % planes_gate), "w") as fh:
         json.dump(report, fh)
     for k in ("errD", "errG", "errG_l2"):
         assert report[k] <= 5e-3, (k, report)
@@ -273,7 +274,7 @@ def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hip
     print("drift after 3 un-synchronised iterations (units of lr):", report)
 
 
-def test_graph_replay_matches_eager(oracle, hipb):
+def test_graph_replay_matches_eager(oracle, hipb, planes_gate):
     """A captured HIP graph of the iteration must walk the same trajectory as eager launches."""
     from video_filler_amd.trainers import CenterTrainer
     opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
@@ -297,7 +298,7 @@ def test_graph_replay_matches_eager(oracle, hipb):
 
 
 @pytest.mark.parametrize("kind", ["center", "vid"])
-def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb):
+def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb, planes_gate):
     """Adam(G) split over two streams (the two bottleneck weight tensors beside the next iteration's encoder forward,
     joined in front of the bottleneck conv), eager and captured: element for element optim.adam's arithmetic, so the
     parameters are BITWISE those of the plain loop."""
@@ -334,7 +335,7 @@ def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb):
 
 @pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("kind", ["center", "vid"])
-def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hipb):
+def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hipb, planes_gate):
     """The data-parallel iteration (4 HIP graphs with RCCL all-reduce-average between them, G's gradient in two
     buckets, the tail one in flight during the encoder's backward) on a world of ONE rank must walk exactly the
     trajectory of the plain loop body: averaging over one rank is the identity.  The exchange is the C-ABI's
@@ -373,7 +374,7 @@ def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hi
 
 
 @pytest.mark.parametrize("kind", ["center", "vid"])
-def test_captured_graph_sees_new_batches(kind, oracle, hipb):
+def test_captured_graph_sees_new_batches(kind, oracle, hipb, planes_gate):
     """set_batch() after capture() writes into the buffers the graph was captured with: replaying on a new batch
     equals eager steps on that batch (a graph that kept reading the first batch would fail this)."""
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
@@ -482,6 +483,7 @@ def test_planes_path_gate(hipb, monkeypatch):
     """nn._pconv_ok with the shipped threshold (3 GFLOP per pass, 1024 rows): train.lua's layers at batchSize 64 take the planes
     kernels, the same layers at the video recipes' batchSize 16 and the small-row deep layers do not."""
     from video_filler_amd import nn
+    assert nn._PCONV_MIN_GFLOP == nn.PCONV_MIN_GFLOP_SHIPPED == 3.0      # the session default IS the shipped gate
     monkeypatch.setattr(nn, "_PCONV_MIN_GFLOP", 3.0)
     c1 = nn.SpatialConvolution(64, 128, 4, 4, 2, 2, 1, 1)
     e4 = nn.SpatialConvolution(256, 512, 4, 4, 2, 2, 1, 1)

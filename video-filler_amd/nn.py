@@ -706,7 +706,8 @@ _NO_BN_GROUPS = bool(__import__("os").environ.get("VF_NO_BN_GROUPS"))
 _NO_BN_FUSE = bool(__import__("os").environ.get("VF_NO_BN_FUSE"))       # BatchNorm statistics from the neighbouring GEMMs
 _NO_PCONV = bool(__import__("os").environ.get("VF_NO_PCONV"))           # convolutions from pre-split bf16 planes
 _PCONV_MIN_ROWS = int(__import__("os").environ.get("VF_PCONV_MIN_ROWS", "1024"))
-_PCONV_MIN_GFLOP = float(__import__("os").environ.get("VF_PCONV_MIN_GFLOP", "3.0"))
+PCONV_MIN_GFLOP_SHIPPED = 3.0
+_PCONV_MIN_GFLOP = float(__import__("os").environ.get("VF_PCONV_MIN_GFLOP", str(PCONV_MIN_GFLOP_SHIPPED)))
 # Weight gradients from the planes too (k_pwgrad_group, single-stage form: 18-23 % faster than k_wgrad_group on its layers).  The
 # bottleneck weight gradients of the same walk ride in the same launch in their fp32-fed form (vf_conv.hip's recorder), as
 # they did in k_wgrad_group: write-bound tiles under MFMA-bound ones.  Same-box A/B of the iteration: +0.5 .. +1.2 %
@@ -816,9 +817,7 @@ class Sequential(Module):
                 cur_pl = m.output_planes
                 if a is not None:
                     a.output = cur
-                    if Sequential.act_hook is not None and a.act in ("lrelu", "relu"):
-                        Sequential.act_hook(a, cur)
-                        cur_pl = None        # (a test hook may have edited the tensor)
+                    self._run_act_hook(a, cur, cur_pl)
                 continue
             if isinstance(m, SpatialConvolution):
                 Ho, Wo = m.out_hw(cur.shape[2], cur.shape[3])
@@ -829,9 +828,7 @@ class Sequential(Module):
                 cur_pl = m.output_planes
                 if a is not None:
                     a.output = cur
-                    if Sequential.act_hook is not None and a.act in ("lrelu", "relu"):
-                        Sequential.act_hook(a, cur)
-                        cur_pl = None
+                    self._run_act_hook(a, cur, cur_pl)
                 continue
             cur_pl = None
             if a is None:
@@ -845,6 +842,16 @@ class Sequential(Module):
                     Sequential.act_hook(a, cur)
         self.output = cur
         return cur
+
+    @staticmethod
+    def _run_act_hook(a, cur, cur_pl):
+        """the parity tests' hook on a fused (Leaky)ReLU output.  The producer's planes of `cur` stay the consumer's operand
+        (that hand-off is what ships); only if the hook reports that it EDITED the tensor are they re-split from it."""
+        if Sequential.act_hook is None or a.act not in ("lrelu", "relu"):
+            return
+        edited = Sequential.act_hook(a, cur)
+        if cur_pl is not None and edited is not False:
+            get_backend().planes_split(cur, cur_pl)
 
     def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0, group=None):
         """Backward over plan entries hi-1 .. lo (default: all of them).  A partial walk lets the caller cut the
