@@ -71,6 +71,10 @@ def main():
                     "through the C-ABI (vf_comm_*) if every rank can bring it up AND its start-up self-check of every collective "
                     "passes on every rank, else — decided by all ranks together — torch.distributed's process group; cabi = "
                     "vf_comm_* or fail; torch = the process group")
+    ap.add_argument("--host", default="cabi", choices=["cabi", "mirror"], help="who drives netG / netD: cabi (default) = the library's own "
+                    "net object, one vf_net_* call per Torch7 method with the whole fast path inside libvf_hip.so (what a Lua host gets "
+                    "through hipnn.Net); mirror = the module-by-module Python mirror of the nn protocol (every layer call crosses the "
+                    "C-ABI on its own).  Same kernels, same plan")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--mfma", default="f32_3xbf16", choices=["f32_3xbf16", "f32", "bf16"],
                     help="how conv products are formed: f32_3xbf16 (default; fp32 operands split exactly into 3 bf16 planes, 6 "
@@ -143,7 +147,7 @@ def main():
     gen = torch.Generator().manual_seed(1234 + rank)
     if args.workload == "center":
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, wtl2=0.999, overlapPred=4)
-        tr = CenterTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam)
+        tr = CenterTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam, host=args.host)
         batch = torch.rand((args.batch, 3, 128, 128), generator=gen) * 2 - 1
         tr.set_batch(batch)
         wl = "train.lua inpaintCenter (nBottleneck=%d wtl2=0.999 overlapPred=4) fineSize=128 batchSize=%d/GPU" % (
@@ -154,7 +158,7 @@ def main():
         fs = args.fine_size
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, nc_in=27, nc_out=12, nef=192, ngf=192, ndf=128,
                    weight_nomask=1, wtgdl=0.5, fineSize=fs, ext256=(fs == 256))
-        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam)
+        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam, host=args.host)
         full = torch.rand((args.batch, 12, fs, fs), generator=gen) * 2 - 1
         mask = torch.zeros((args.batch, 12, fs, fs), dtype=torch.uint8)
         mask[:, :, fs // 4:3 * fs // 4, fs // 4:3 * fs // 4] = 1
@@ -168,7 +172,7 @@ def main():
         predLen = 16 if args.workload == "vid16" else 4
         nc = 3 * predLen
         opt = dict(batchSize=args.batch, nBottleneck=args.nBottleneck, predLen=predLen)
-        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam)
+        tr = VidTrainer(opt, seed=1234, world=world, rank=rank, sync_bn=args.sync_bn, overlap=args.overlap, shard_adam=args.shard_adam, host=args.host)
         full = torch.rand((args.batch, nc, 128, 128), generator=gen) * 2 - 1
         mask = torch.zeros((args.batch, nc, 128, 128), dtype=torch.uint8)
         mask[:, :, 32:96, 32:96] = 1
@@ -415,6 +419,8 @@ def main():
                                 "f32": "native v_mfma_f32_32x32x2_f32", "bf16": "operands rounded to bf16"}[args.mfma],
                        "adam_G": "bottleneck weight tensors on a side stream beside the next encoder forward" if tr.adam_overlap else "one launch at the end of the iteration",
                        "netD_passes": "real+fake as one batch of 2B, BatchNorm per half" if tr.batch_d else "separate (as the reference)",
+                       "host": ("vf_net_* (C-ABI net object: forward / backward / updateGradInput are one library call each)" if tr.host == "cabi"
+                                else "nn.py mirror (module by module over the C-ABI)"),
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device",
                        "exchange": (("vf_comm_* (C-ABI, RCCL; verified at start-up on every rank)" if B.comm is not None else "torch.distributed (%s)" % args.backend) if dp else None)},
             "roofline": roofline,

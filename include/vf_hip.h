@@ -399,14 +399,23 @@ int vf_prof_end(vf_ctx* ctx);
 int vf_prof_count(void);
 int vf_prof_get(int i, char* name, int name_cap, int64_t* launches, double* ms, double* flops, double* bytes);
 
-/* ---- nn.Sequential as one object (net_{create, forward, backward, update_grad_input, parameters}) ---------
- * For a host that does not want to mirror the module protocol itself: hand over the layer list the reference builds with
- * netG:add(...) / netD:add(...) (train.lua:87-199) and drive the net with one call per Torch7 method.  Pure host code over
- * the entry points above (same kernels; an activation behind a convolution / BatchNorm is applied in its producer's epilogue
- * and undone in its backward; all weight gradients of a backward call in one grouped launch).  It does not carry the
- * cross-layer shortcuts of video-filler_amd/nn.py (BatchNorm statistics out of the GEMMs, planes): the simple surface.
+/* ---- nn.Sequential as one object: the FAST path behind the boundary (net_{create, forward, backward,
+ * update_grad_input, parameters}) ---------------------------------------------------------------------------------------------
+ * util.cudnn(net) (util.lua:108-131) is where the reference swaps a net onto a GPU backend; from then on its drivers only call
+ * net:forward / :backward / :updateGradInput / :getParameters / :apply(bias:zero()) / :zeroGradParameters / :evaluate
+ * (train.lua:245-263, 278-410; train_vid_weighted.lua:330-355, 373-537).  vf_net is that net: hand over the layer list the
+ * reference builds with netG:add(...) / netD:add(...) (train.lua:87-199) and drive it with one call per Torch7 method.  It
+ * executes the plan with every cross-layer shortcut of the hot path (csrc/vf_net.hip): activations in their producer's
+ * epilogue, BatchNorm statistics as a by-product of the neighbouring GEMMs (vf_bn_fuse_next_* / vf_bn_*_pre), operands as bf16
+ * planes handed from producer to consumer (vf_pconv_*), weight planes of the whole net refreshed in one launch per parameter
+ * update, every weight gradient of a walk in one grouped launch and every conv bias gradient in two, lazy gradient zeroing,
+ * netD's real + fake passes as one batch of 2B with BatchNorm per half (vf_net_set_batch_groups), backward walks cut at a
+ * gradient bucket (vf_net_backward_range), SyncBN over vf_comm_*.  The benched iteration runs through exactly these calls
+ * (bench.py --host cabi; video-filler_amd/cnet.py and lua/hipnn.lua's hipnn.Net are thin hosts of it).
+ * Chain nets only (the table modules of train.lua's option branches stay with a module-by-module host).
  * Activations NHWC, weights channels-last; the flat parameter buffer holds {weight, bias} ({gamma, beta}) module by module,
- * segments padded to 64 floats (vf_net_param_offset).  Shapes are fixed at creation. */
+ * segments padded to 64 floats (vf_net_param_offset).  All calls enqueue on the context's stream; buffers whose need depends on
+ * the path a pass takes (planes) are allocated at first use, so run one iteration before capturing a hipGraph. */
 enum { VF_L_CONV = 1, VF_L_FULLCONV = 2, VF_L_BN = 3, VF_L_ACT = 4, VF_L_VIEW = 5 };
 typedef struct vf_layer_desc {
   int kind;             /* VF_L_* */
@@ -419,15 +428,62 @@ typedef struct vf_layer_desc {
 typedef struct vf_net vf_net;
 int vf_net_create(vf_ctx* ctx, vf_net** out, const vf_layer_desc* layers, int nlayers, int B, int C, int H, int W);
 int vf_net_destroy(vf_net* net);
+/* a new input shape: activations / planes / BatchNorm scratch re-planned, parameters and running statistics kept (Torch7
+ * modules resize their outputs on the fly).  Synchronises; not inside a capture. */
+int vf_net_reshape(vf_net* net, int B, int C, int H, int W);
 int vf_net_parameters(vf_net* net, float** params, float** grads, int64_t* count);   /* net:getParameters() */
+/* host-owned flat storage (count >= vf_net_parameters' count floats each, 16-byte aligned, same layout) instead of the net's
+ * own: Torch7 keeps parameters in Lua-owned tensors, whose weight / bias views all alias ONE storage after getParameters().
+ * Nothing is copied.  NULL, NULL: back to the net's own buffers. */
+int vf_net_bind_parameters(vf_net* net, float* params, float* grads, int64_t count);
 int64_t vf_net_param_offset(const vf_net* net, int layer, int which, int64_t* length); /* which: 0 weight/gamma, 1 bias/beta; -1 if none */
 int vf_net_bn_running(vf_net* net, int layer, float** running_mean, float** running_var);
+int vf_net_bind_bn_running(vf_net* net, int layer, float* running_mean, float* running_var);   /* host-owned running statistics */
+int vf_net_bn_saved(vf_net* net, int layer, float** save_mean, float** save_invstd);          /* [groups][C] of the last forward */
 int vf_net_training(vf_net* net, int train);                                          /* net:training() / net:evaluate() */
-int vf_net_zero_grad(vf_net* net);                                                    /* net:zeroGradParameters() */
+int vf_net_zero_grad(vf_net* net);                                                    /* net:zeroGradParameters() (lazy) */
+/* the conv-bias sweep of both closures (train.lua:279-280), one launch; `other` (may be NULL): the second net of the sweep */
+int vf_net_zero_conv_biases(vf_net* net, vf_net* other);
 int vf_net_forward(vf_net* net, const float* x, const float** y);                     /* net:forward(input) */
 int vf_net_backward(vf_net* net, const float* x, const float* gy, const float** gx);  /* net:backward(input, gradOutput) */
 int vf_net_update_grad_input(vf_net* net, const float* x, const float* gy, const float** gx); /* train.lua:366 */
+/* vf_net_backward leaves out the first layer's gradInput (*gx = NULL): Torch7 always computes it, the drivers never read it for
+ * netD's two full backward passes nor for netG's (train.lua:318,348,403) */
+int vf_net_set_skip_input_grad(vf_net* net, int on);
+/* The next forwards carry G concatenated, independent batches (netD's [real; fake], train.lua:331-349): BatchNorm statistics,
+ * running-average updates (in group order) and backward sums per group — what G separate calls compute — while the convolutions
+ * see one batch.  vf_net_update_grad_input_group: updateGradInput over group g alone (x / gy hold that group's samples; saved
+ * activations and statistics are that group's): fGx's pass over the fake half. */
+int vf_net_set_batch_groups(vf_net* net, int G);
+int vf_net_update_grad_input_group(vf_net* net, const float* x, const float* gy, int g, int G, const float** gx);
+/* Data parallel: the walk cut where a gradient bucket is complete.  The net's execution plan has vf_net_plan_size entries (an
+ * absorbed activation shares its producer's); vf_net_bucket_split gives the plan index k and flat offset of the shortest tail
+ * plan[k:] owning >= frac of the parameters; vf_net_backward_range(hi, lo) runs backward over entries hi-1 .. lo (hi < 0: from
+ * the top; gy = what the entry above hi returned).  After the walk over [k, top) the flat gradient [offset, end) is final. */
+int vf_net_plan_size(const vf_net* net);
+int vf_net_bucket_split(const vf_net* net, double frac, int* plan_index, int64_t* flat_offset);
+int vf_net_backward_range(vf_net* net, const float* x, const float* gy, int hi, int lo, int need_input_grad, const float** gx);
+/* SyncBN: BatchNorm sums all-reduced over `comm` (world ranks; statistics of the global batch).  force: take that path at world 1
+ * too.  comm NULL / world 1 / force 0: device-local statistics. */
+int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);
+/* Weight planes (bf16 shadows of the conv weights the planes kernels read).  Unmanaged (default): refreshed at the start of every
+ * forward / backward call.  Managed: the host calls vf_net_refresh_weight_planes once after each parameter update (optim.adam, a
+ * checkpoint load) — one launch per net and update instead of one per call. */
+int vf_net_set_weight_planes_managed(vf_net* net, int on);
+int vf_net_refresh_weight_planes(vf_net* net);
+/* where the planes kernels are used (process-wide; defaults 3 GFLOP per pass and 1024 GEMM rows) */
+int vf_net_set_planes_gate(double min_gflop_per_pass, int min_rows);
 int vf_net_layer_output(vf_net* net, int layer, const float** y);                     /* net.modules[i].output */
+int vf_net_layer_grad_input(vf_net* net, int layer, const float** gx);                /* net.modules[i].gradInput */
+int vf_net_layer_shape(const vf_net* net, int layer, int* B, int* C, int* H, int* W, int* Co, int* Ho, int* Wo);
+/* module `layer` writes its output into the host's buffer (e.g. netG's last convolution straight into the fake half of netD's
+ * [real; fake] input); NULL: the net's own buffer again */
+int vf_net_bind_output(vf_net* net, int layer, float* y);
+/* Observer of every (Leaky)ReLU output of a forward pass, called on the host right after the producing launch was enqueued:
+ * fn(user, layer index of the activation module, device pointer, element count) -> 1 if it edited the tensor (on the context's
+ * stream), 0 if not, < 0 on error.  The parity tests pin derivative choices at the kink with it; NULL: none. */
+typedef int (*vf_net_act_observer)(void* user, int layer, float* y, int64_t numel);
+int vf_net_set_act_observer(vf_net* net, vf_net_act_observer fn, void* user);
 
 /* ---- roctx ranges (the reference's tracing is three torch.Timers; this is the profiler-visible counterpart) ----
  * vf_range_push / vf_range_pop / vf_mark forward to roctx when a roctx library is present (librocprofiler-sdk-roctx.so as

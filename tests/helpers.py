@@ -88,7 +88,14 @@ class KinkSync:
         self.checked = 0
         self.calls = 0
         self.edited_calls = 0
-        self.max_touched_frac = 1e-4
+        # The band |oracle value| < delta * max holds ~1e-4 .. 1.5e-3 of a net's activations (measured over the suite: a LeakyReLU
+        # output maps pre-activations in (-5 delta, delta) into it; narrow test nets have the heavier tails), and nearly all of
+        # them differ from the oracle in the last bit, so that is also the share the pin rewrites.  Two guards keep the pin from
+        # hiding a forward error: every rewritten element must already agree with the oracle to `near_tol` of the tensor's max
+        # (checked in __call__), and the rewritten share stays below `max_touched_frac`.
+        self.max_touched_frac = 3e-3
+        self.near_tol = 1e-4
+        self.worst_near = 0.0
 
     def _oleaves(self, m):
         if hasattr(m, "modules"):
@@ -124,8 +131,15 @@ class KinkSync:
         self.pos[id(ra)] = k + used
         assert tuple(y.shape) == ref.shape, (tuple(y.shape), ref.shape)
         r = torch.from_numpy(ref).to(y.device)
-        near = r.abs() < self.delta * max(1.0, float(np.abs(ref).max()))
+        scale = max(1.0, float(np.abs(ref).max()))
+        near = r.abs() < self.delta * scale
         n_edit = int((near & (r != y)).sum().item())
+        if n_edit:
+            # what is about to be rewritten must already BE the oracle's value to the forward tolerance: a forward error that
+            # only shows on elements near 0 would otherwise be overwritten silently
+            worst = float((y - r).abs()[near].max().item())
+            self.worst_near = max(self.worst_near, worst / scale)
+            assert worst <= self.near_tol * scale, "KinkSync: an element within the kink band differs from the oracle by %.3e (> %g of the tensor's max %.3e): forward error near 0" % (worst, self.near_tol, scale)
         self.touched += n_edit
         self.checked += y.numel()
         self.calls += 1
@@ -146,12 +160,20 @@ class KinkSync:
         for rid, passes in self.rec.items():
             assert self.pos.get(rid, 0) == len(passes), "an oracle activation pass was not consumed by the HIP run (%d of %d)" % (
                 self.pos.get(rid, 0), len(passes))
-        # the pin is a handful of elements: if it ever rewrites more than 1e-4 of what it looks at, the forward pass is wrong
-        # in the neighbourhood of 0 and the pin would be hiding it
+        # the pin is the band's population (see __init__): beyond max_touched_frac the forward pass is wrong near 0
         touched, checked = self.touched - t0, self.checked - c0
         assert checked > 0, "the hook was never called: nothing was pinned"
         assert touched <= max(self.max_touched_frac * checked, 8), "KinkSync rewrote %d of %d activations (> %g): forward error near 0" % (
             touched, checked, self.max_touched_frac)
+        try:        # evidence for DESIGN.md 6: what the pin looked at, rewrote, and how far the rewritten values were off
+            import json
+            import os
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(os.path.join("gpurun_out", "kinksync_stats.jsonl"), "a") as fh:
+                fh.write(json.dumps(dict(test=os.environ.get("PYTEST_CURRENT_TEST", ""), touched=touched, checked=checked,
+                                         frac=touched / checked, worst_near=self.worst_near)) + "\n")
+        except OSError:
+            pass
         return out
 
 

@@ -85,13 +85,16 @@ def test_syncbn_collectives_are_captured_with_the_phases(kind, oracle, hipb):
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
     attach_world1_comm(hipb)
     if kind == "center":
-        opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4)
+        opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4, smooth=True)
         batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)
         mk = lambda **kw: CenterTrainer(opt, seed=3, **kw)
     else:
-        opt = dict(nBottleneck=128, predLen=2)
+        opt = dict(nBottleneck=128, predLen=2, smooth=True)
         batch = tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(4, np.random.default_rng(5), 6))
         mk = lambda **kw: VidTrainer(opt, seed=3, **kw)
+    # smooth nets (LeakyReLU(1.0) everywhere: same graph, same kernels): the first-iteration comparison below is between two
+    # BatchNorm statistics paths that round differently, and on the real nets one pre-activation within rounding distance of
+    # its kink moves a batch-of-4 gradient by ~1e-3 of its norm — this test is about the collectives
 
     def synced():
         t = mk(overlap=False)                  # what the trainers do for world > 1 with sync_bn (one stream)

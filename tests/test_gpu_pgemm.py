@@ -162,7 +162,7 @@ def test_weight_gradient_from_planes(Bn, Cin, H, Cout, grouped, hipb):
 # (the comparisons above are HIP against HIP.)  The same passes against the CPU oracle's im2col + GEMM
 # restatement of THNN (oracle.SpatialConvolution / SpatialFullConvolution), at the bar of tests/test_gpu_ops.py: 2e-5 of the
 # tensor's max-norm.  Sizes the oracle finishes in seconds with 16 threads.
-ORACLE_CASES = [(4, 64, 32, 128), (8, 64, 64, 64), (4, 128, 16, 256), (3, 256, 8, 512), (2, 192, 32, 384), (6, 32, 32, 96),
+ORACLE_CASES = [(4, 64, 32, 128), (8, 64, 64, 64), (4, 128, 16, 256), (16, 256, 8, 512), (2, 192, 32, 384), (6, 32, 32, 96),
                 (16, 64, 32, 64)]
 
 

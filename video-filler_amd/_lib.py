@@ -120,6 +120,25 @@ SIGNATURES = {
     "vf_net_backward": (i32, [vp, vp, vp, C.POINTER(vp)]),
     "vf_net_update_grad_input": (i32, [vp, vp, vp, C.POINTER(vp)]),
     "vf_net_layer_output": (i32, [vp, i32, C.POINTER(vp)]),
+    "vf_net_layer_grad_input": (i32, [vp, i32, C.POINTER(vp)]),
+    "vf_net_layer_shape": (i32, [vp, i32] + [C.POINTER(i32)] * 7),
+    "vf_net_reshape": (i32, [vp, i32, i32, i32, i32]),
+    "vf_net_bind_parameters": (i32, [vp, vp, vp, i64]),
+    "vf_net_bind_bn_running": (i32, [vp, i32, vp, vp]),
+    "vf_net_bn_saved": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp)]),
+    "vf_net_zero_conv_biases": (i32, [vp, vp]),
+    "vf_net_set_skip_input_grad": (i32, [vp, i32]),
+    "vf_net_set_batch_groups": (i32, [vp, i32]),
+    "vf_net_update_grad_input_group": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp)]),
+    "vf_net_plan_size": (i32, [vp]),
+    "vf_net_bucket_split": (i32, [vp, f64, C.POINTER(i32), C.POINTER(i64)]),
+    "vf_net_backward_range": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]),
+    "vf_net_set_sync_bn": (i32, [vp, vp, i32, i32]),
+    "vf_net_set_weight_planes_managed": (i32, [vp, i32]),
+    "vf_net_refresh_weight_planes": (i32, [vp]),
+    "vf_net_set_planes_gate": (i32, [f64, i32]),
+    "vf_net_bind_output": (i32, [vp, i32, vp]),
+    "vf_net_set_act_observer": (i32, [vp, vp, vp]),
     "vf_trace_available": (i32, []),
     "vf_trace_enable": (i32, [i32]),
     "vf_range_push": (i32, [C.c_char_p]),

@@ -173,6 +173,19 @@ def param_version(t):
     return _PARAM_VERSION.get(_storage_key(t), 0)
 
 
+class _DevPtr:
+    """a device allocation of the library as a __cuda_array_interface__ object (what torch.as_tensor adopts without a copy)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def tensor_from_ptr(ptr, shape, device, typestr="<f4"):
+    """a torch view (no copy, no ownership) of library-owned device memory — plumbing for hosts of vf_net_*"""
+    return torch.as_tensor(_DevPtr(ptr, shape, typestr), device=device)
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -1,165 +1,788 @@
-// vf_net.hip — nn.Sequential behind the C-ABI (graph-level net_{create, forward, backward, update_grad_input,
-// parameters}).  A host that does not want to mirror the module protocol (video-filler_amd/nn.py does) can hand the library a
-// flat list of layers — exactly what the reference builds with netG:add(...) / netD:add(...) (train.lua:87-199) — and drive the
-// whole net with one call per Torch7 method:
+// vf_net.hip — nn.Sequential behind the C-ABI: the FAST path of the training iteration as one library object.
+//
+// The reference plugs a GPU backend in at one place: util.cudnn(net) walks netG / netD and swaps their modules
+// (util.lua:108-131, called at train.lua:245-258 / train_vid_weighted.lua:330-355); from then on the drivers only call
 //     net:forward(input)                      -> vf_net_forward
 //     net:backward(input, gradOutput)         -> vf_net_backward           (updateGradInput + accGradParameters, scale 1)
 //     net:updateGradInput(input, gradOutput)  -> vf_net_update_grad_input  (train.lua:366: netD in fGx)
-//     net:getParameters()                     -> vf_net_parameters         (ONE flat fp32 buffer + one for the gradients)
+//     net:getParameters()                     -> vf_net_parameters / vf_net_bind_parameters
+//     net:apply(bias:zero())                  -> vf_net_zero_conv_biases   (train.lua:279-280)
 //     net:zeroGradParameters(), :training(), :evaluate()
-// Pure host code over the library's own entry points (vf_conv2d_*, vf_deconv2d_*, vf_bn_*, vf_act_*): the same kernels, the same
-// in-place activation semantics (an activation that follows a convolution or a BatchNorm is applied in its producer's
-// epilogue and undone in its backward, as nn.Sequential(fuse=True) does), every weight gradient of a backward call in one
-// grouped launch.  What it does NOT carry is the mirror's cross-layer plumbing (BatchNorm statistics out of the GEMM epilogues,
-// planes handed from producer to consumer): this is the simple protocol surface, nn.py the fast one.
-// Layout: activations NHWC, weights channels-last as everywhere in this library (include/vf_hip.h); the flat parameter buffer
-// holds, module by module, {weight, bias} ({gamma, beta} for BatchNorm), every segment padded to 64 floats.
+// This file is that net: the layer list the reference builds with netG:add(...) / netD:add(...) (train.lua:87-199,
+// train_vid_weighted.lua:112-236) executed with every cross-layer shortcut of the hot path, on the host side of the same
+// entry points a module-by-module host would call (vf_conv2d_*, vf_pconv_*, vf_bn_*, ...):
+//   * an in-place LeakyReLU / ReLU (and a Tanh / Sigmoid right behind a convolution) is applied in its producer's epilogue
+//     and undone in the producer's backward — or, for conv -> LeakyReLU -> conv, in the NEXT conv's data-gradient epilogue;
+//   * BatchNorm statistics are a by-product of the GEMM that produces the tensor (forward) and of the data-gradient GEMM
+//     above it (backward): vf_bn_fuse_next_* / vf_bn_*_pre — no statistics pass over the tensor;
+//   * operands of the 4x4 stride-2 passes are bf16 PLANES split once by their producer (BatchNorm apply / backward, the
+//     thin-input convolution) and handed to the consumer (vf_pconv_*, k_pwgrad_group); weight planes of the whole net are
+//     refreshed in one launch per parameter update;
+//   * every weight gradient of a backward walk runs in one grouped launch, every conv bias gradient in two;
+//   * gradParameters:zero() is lazy (the next accumulation overwrites);
+//   * netD's real and fake passes as ONE batch of 2B (train.lua:331-349): vf_net_set_batch_groups(2) makes every BatchNorm
+//     keep the halves apart (statistics, running averages, backward sums per half, in order), and the generator's
+//     third pass runs over the fake half only (vf_net_update_grad_input_group);
+//   * a backward walk can be cut where a gradient bucket is complete (vf_net_backward_range, vf_net_bucket_split) so that
+//     the data-parallel exchange of that bucket overlaps the rest of the walk; SyncBN through vf_comm_* (vf_net_set_sync_bn).
+// video-filler_amd/nn.py's nn.Sequential is the module-by-module mirror of the same plan (it also serves the table modules of
+// the option branches); video-filler_amd/cnet.py and lua/hipnn.lua (hipnn.Net) are the thin hosts of THIS object.
+//
+// Memory: activations, gradInputs, planes, BatchNorm save / partial buffers and the weight planes belong to the net; the
+// flat parameter / gradient buffers and the BatchNorm running statistics are the net's own unless the host binds its own
+// storage (vf_net_bind_parameters / vf_net_bind_bn_running: Torch7 keeps them in Lua-owned tensors).  Buffers that depend on
+// which path a pass takes (planes) are allocated at their first use: run one iteration before capturing a hipGraph.
+// Layout: activations NHWC, weights channels-last (include/vf_hip.h); the flat buffers hold {weight, bias} ({gamma, beta})
+// module by module, every segment padded to 64 floats — the layout of nn.py's getParameters().
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "vf_common.h"
 
-// (vf_common.h brings include/vf_hip.h: the entry points used below, vf_layer_desc and the VF_L_* kinds)
-
 namespace {
+
+// where the planes kernels pay: from 3 GFLOP per pass and 1024 GEMM rows; process-wide, like nn.py's gate
+double g_gate_gflop = getenv("VF_PCONV_MIN_GFLOP") ? atof(getenv("VF_PCONV_MIN_GFLOP")) : 3.0;
+int g_gate_rows = getenv("VF_PCONV_MIN_ROWS") ? atoi(getenv("VF_PCONV_MIN_ROWS")) : 1024;
+const bool g_no_pconv = getenv("VF_NO_PCONV") != nullptr;
+const bool g_no_bn_fuse = getenv("VF_NO_BN_FUSE") != nullptr;
+const bool g_pwgrad = !(getenv("VF_PWGRAD") && strcmp(getenv("VF_PWGRAD"), "1") != 0);
+
+struct VfColsumDescH {      // = VfColsumDesc of vf_bn.hip (64 bytes)
+  const float* g;
+  float* gb;
+  double* part;
+  int64_t P;
+  int C, cq, rows_per_block, gx, gy;
+  int blk1_off, blk2_off;
+  float beta;
+};
+static_assert(sizeof(VfColsumDescH) == 64, "descriptor layout is shared with vf_bn.hip");
+struct VfWpDescH {          // = VfWpDesc of vf_pgemm.hip (48 bytes)
+  const float* w;
+  void* nat;
+  void* tr;
+  int d0, d1, gx, gz, blk_off, pad;
+};
+static_assert(sizeof(VfWpDescH) == 48, "descriptor layout is shared with vf_pgemm.hip");
 
 struct Layer {
   vf_layer_desc d;
-  int C, H, W;            // input shape of the layer
-  int Co, Ho, Wo;         // output shape
+  int C = 0, H = 0, W = 0;       // input shape of the layer
+  int Co = 0, Ho = 0, Wo = 0;    // output shape
   int64_t w_off = -1, b_off = -1, w_n = 0, b_n = 0;      // offsets into the flat buffers
-  float* y = nullptr;     // output [B][Ho][Wo][Co] (NULL: in place on the producer's output / a view)
-  float* gx = nullptr;    // gradInput [B][H][W][C]
-  // BatchNorm state
+  float* y = nullptr;            // output [B][Ho][Wo][Co] (NULL: in place on the producer's output / a view)
+  float* y_own = nullptr;        // the net's own allocation behind y (y may be re-bound: vf_net_bind_output)
+  float* gx = nullptr;           // gradInput [B][H][W][C]
+  float* gtmp = nullptr;         // fused activation: its updateGradInput when it cannot run in place on the incoming gradient
+  // BatchNorm state: running statistics [C] (own or bound), save_mean / save_invstd [G][C], sums [G][2C], partial rows
   float *rm = nullptr, *rv = nullptr, *sm = nullptr, *si = nullptr;
   double* sums = nullptr;
-  int fused_act = VF_ACT_NONE;      // activation applied in this layer's epilogue (the next layer is a VF_L_ACT)
+  double* part = nullptr;
+  int part_rows_cap = 0;
+  // planes (bf16 [3][n]), allocated at first use
+  void* xp = nullptr;            // conv: split of its input when the producer did not write planes
+  void* gp = nullptr;            // conv: split of its gradOutput for the data-gradient pass
+  void* yp = nullptr;            // BatchNorm / thin-input conv: planes of the own output, written beside it
+  void* bgp = nullptr;           // BatchNorm: planes of its gradInput, written by its backward
+  const void* out_planes = nullptr;     // set by the last forward: planes of y (or NULL)
+  const void* grad_planes = nullptr;    // set by the last backward: planes of gx (or NULL)
+  void *wp_nat = nullptr, *wp_tr = nullptr;      // weight planes, native and transposed
+  bool wp_live = false;
+  // operands the two GEMM passes of this layer were fed with: the weight gradient takes the same planes
+  const float* x_seen = nullptr;
+  const void* xp_seen = nullptr;
+  const float* g_seen = nullptr;
+  const void* gp_seen = nullptr;
+  int fused_act = VF_ACT_NONE;   // activation applied in this layer's epilogue (the next layer is an absorbed VF_L_ACT)
   float fused_slope = 0.f;
-  bool absorbed = false;            // a VF_L_ACT that its producer applies
-  bool fresh = true;                // zeroGradParameters() was called: the next accGradParameters overwrites (beta = 0)
+  bool absorbed = false;         // a VF_L_ACT that its producer applies
+  bool fresh = true;             // zeroGradParameters(): the next accGradParameters overwrites (beta = 0)
 };
+
+struct Entry {
+  int main;       // layer index
+  int act;        // absorbed activation layer index, or -1
+};
+
+inline bool is_conv(const Layer& l) { return l.d.kind == VF_L_CONV || l.d.kind == VF_L_FULLCONV; }
+inline bool is_full(const Layer& l) { return l.d.kind == VF_L_FULLCONV; }
+inline bool is_s2(const Layer& l) { return l.d.k == 4 && l.d.stride == 2 && l.d.pad == 1; }
+inline bool relu_like(int act) { return act == VF_ACT_LRELU || act == VF_ACT_RELU; }
 
 }  // namespace
 
 struct vf_net {
   vf_ctx* ctx = nullptr;
-  int B = 0;
+  int B = 0, C0 = 0, H0 = 0, W0 = 0;
   std::vector<Layer> L;
-  float *params = nullptr, *grads = nullptr;
+  std::vector<Entry> plan;
+  float *params = nullptr, *grads = nullptr;          // own or bound
+  float *params_own = nullptr, *grads_own = nullptr;
   int64_t nparams = 0;
   bool train = true;
-  std::vector<void*> owned;
+  int groups = 1;                  // batch groups of the next forward (BatchNorm statistics per group)
+  int gcap = 0;                    // groups the BatchNorm state buffers are sized for
+  bool skip_input_grad = false;    // vf_net_backward leaves out the first layer's gradInput (the drivers never read it)
+  bool wp_managed = false;         // the host calls vf_net_refresh_weight_planes after every parameter update
+  int act_done_at = -1;            // a cut walk resumes: the activation backward of entry `at`'s output is already applied
+  int bn_pre_at = -1, bn_pre_rows = 0;
+  vf_comm* comm = nullptr;         // SyncBN: sums all-reduced over the communicator
+  int sync_world = 1;
+  bool sync_force = false;
+  vf_net_act_observer observer = nullptr;
+  void* observer_user = nullptr;
+  // device tables built once per combination and kept (the same walk recurs every iteration)
+  std::map<std::string, std::pair<void*, std::vector<int>>> colsum_plans;
+  void* wp_table = nullptr;
+  int wp_n = 0, wp_blocks = 0;
+  std::vector<int> wp_key;
+  int64_t* bias_offs = nullptr;    // device: conv bias segments of the flat buffer (train.lua:279)
+  int64_t* bias_lens = nullptr;
+  int nbias = 0;
+  struct BothTable {
+    int64_t *offs, *lens;
+    const float *base, *other_base;      // the flat buffers the offsets were computed between
+  };
+  std::map<const vf_net*, BothTable> both_tables;
+  std::vector<void*> owned;        // parameter-lifetime allocations
+  std::vector<void*> act_owned;    // shape-lifetime allocations (freed by vf_net_reshape)
 };
 
-static int net_alloc(vf_net* n, void** out, size_t bytes) {
+namespace {
+
+int net_alloc(std::vector<void*>& pool, void** out, size_t bytes) {
   void* p = nullptr;
   VF_CHECK_HIP(hipMalloc(&p, bytes ? bytes : 4));
-  n->owned.push_back(p);
+  pool.push_back(p);
   *out = p;
   return 0;
 }
 
+bool sync_on(const vf_net* n) { return (n->comm && n->sync_world > 1) || n->sync_force; }
+bool bn_fusable(const vf_net* n, const Layer& l) { return n->train && !sync_on(n) && l.C % 4 == 0 && !g_no_bn_fuse; }
+
+// could any pass of this layer use the planes kernels (4x4 stride 2, wide enough)?
+bool pconv_layer(const Layer& l) {
+  return is_conv(l) && is_s2(l) && std::min(l.d.nin, l.d.nout) >= 32 && l.d.nin % 4 == 0 && l.d.nout % 4 == 0;
+}
+bool pconv_ok(const vf_net* n, const Layer& l, int Bn, int Hg, int Wg, int Cgather, int Cout, bool transposed) {
+  if (g_no_pconv || n->ctx->mfma_bf16 != 3 || !is_s2(l)) return false;
+  const int64_t rows = (int64_t)Bn * Hg * Wg / (transposed ? 1 : 4);
+  const double gflop = 2.0 * (double)rows * 16.0 * Cgather * Cout * 1e-9;
+  if (rows < g_gate_rows || gflop < g_gate_gflop) return false;
+  return vf_pconv_supported(Bn, Hg, Wg, Cgather, Cout, 4, 2, 1, transposed ? 1 : 0) != 0;
+}
+
+int ensure_planes(vf_net* n, void** slot, int64_t numel) {
+  if (*slot) return 0;
+  return net_alloc(n->act_owned, slot, (size_t)numel * 6);
+}
+
+// the entry's output tensor (what the next entry reads): the nearest layer at or before it that owns one
+const float* entry_out(const vf_net* n, int idx, const float* x_in) {
+  for (int e = idx; e >= 0; --e) {
+    const Layer& l = n->L[n->plan[e].main];
+    if (l.y) return l.y;
+  }
+  return x_in;
+}
+
+int run_observer(vf_net* n, int act_layer, float* y, int64_t numel, const void* planes) {
+  if (!n->observer) return 0;
+  VF_CHECK_HIP(hipGetLastError());
+  const int edited = n->observer(n->observer_user, act_layer, y, numel);
+  if (edited < 0) {
+    vf_set_error("vf_net: the activation observer reported an error at layer %d", act_layer);
+    return 2;
+  }
+  // the producer's planes stay the consumer's operand (that hand-off is what ships); only an EDITED tensor is re-split
+  if (edited > 0 && planes) return vf_planes_split(n->ctx, y, const_cast<void*>(planes), numel);
+  return 0;
+}
+
+// ---- weight planes -------------------------------------------------------------------------------------------------
+int weight_planes(vf_net* n, Layer& l, bool transposed, const void** out) {
+  const float* w = n->params + l.w_off;
+  const int d0 = is_full(l) ? l.d.nin : l.d.nout, d1 = is_full(l) ? l.d.nout : l.d.nin;
+  if (!l.wp_live) {
+    // first use: split now; from here on the net's one-launch refresh keeps this layer's planes current
+    if (!l.wp_nat) {
+      if (int rc = net_alloc(n->owned, &l.wp_nat, (size_t)l.w_n * 6)) return rc;
+      if (int rc = net_alloc(n->owned, &l.wp_tr, (size_t)l.w_n * 6)) return rc;
+    }
+    if (int rc = vf_weight_planes(n->ctx, w, l.wp_nat, l.wp_tr, d0, d1)) return rc;
+    l.wp_live = true;
+  }
+  *out = transposed ? l.wp_tr : l.wp_nat;
+  return 0;
+}
+
+int refresh_weight_planes(vf_net* n) {
+  if (g_no_pconv || n->ctx->mfma_bf16 != 3) return 0;
+  std::vector<int> live;
+  for (size_t i = 0; i < n->L.size(); ++i)
+    if (n->L[i].wp_live) live.push_back((int)i);
+  if (live.empty()) return 0;
+  if (live != n->wp_key || !n->wp_table) {
+    std::vector<VfWpDescH> desc(live.size());
+    int blocks = 0;
+    for (size_t j = 0; j < live.size(); ++j) {
+      Layer& l = n->L[live[j]];
+      const int d0 = is_full(l) ? l.d.nin : l.d.nout, d1 = is_full(l) ? l.d.nout : l.d.nin;
+      const int gx = (d0 + 31) / 32, gz = (d1 + 31) / 32;
+      desc[j] = VfWpDescH{n->params + l.w_off, l.wp_nat, l.wp_tr, d0, d1, gx, gz, blocks, 0};
+      blocks += gx * 16 * gz;
+    }
+    void* dev = nullptr;       // a fresh table: a launch still in flight may be reading the old one (kept until destroy)
+    if (int rc = net_alloc(n->owned, &dev, desc.size() * sizeof(VfWpDescH))) return rc;
+    VF_CHECK_HIP(hipMemcpy(dev, desc.data(), desc.size() * sizeof(VfWpDescH), hipMemcpyHostToDevice));
+    n->wp_table = dev;
+    n->wp_n = (int)live.size();
+    n->wp_blocks = blocks;
+    n->wp_key = live;
+  }
+  return vf_weight_planes_multi(n->ctx, n->wp_table, n->wp_n, n->wp_blocks);
+}
+
+// ---- forward pieces ------------------------------------------------------------------------------------------------
+int conv_forward(vf_net* n, Layer& l, const float* x, const void* in_planes, int Bn, int act, float slope, bool want_planes) {
+  vf_ctx* ctx = n->ctx;
+  const float* w = n->params + l.w_off;
+  const float* b = n->params + l.b_off;
+  const bool full = is_full(l);
+  l.out_planes = nullptr;
+  const bool simple_act = act == VF_ACT_NONE || relu_like(act);
+  if (want_planes && !full && l.C == 3 && simple_act && is_s2(l) && l.Co % 64 == 0 && l.H % 16 == 0 && l.W % 16 == 0) {
+    if (int rc = ensure_planes(n, &l.yp, (int64_t)n->B * l.Ho * l.Wo * l.Co)) return rc;
+    if (int rc = vf_conv2d_fwd_planes(ctx, x, w, b, l.y, l.yp, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, act, slope)) return rc;
+    l.out_planes = l.yp;
+    l.x_seen = nullptr;
+    return 0;
+  }
+  if (simple_act && pconv_ok(n, l, Bn, l.H, l.W, l.C, l.Co, full)) {
+    const void* xp = in_planes;
+    if (!xp) {
+      if (int rc = ensure_planes(n, &l.xp, (int64_t)n->B * l.H * l.W * l.C)) return rc;
+      if (int rc = vf_planes_split(ctx, x, l.xp, (int64_t)Bn * l.H * l.W * l.C)) return rc;
+      xp = l.xp;
+    }
+    l.x_seen = x;
+    l.xp_seen = xp;
+    const void* wp = nullptr;
+    if (int rc = weight_planes(n, l, full, &wp)) return rc;
+    return full ? vf_pconv_scatter(ctx, xp, wp, b, l.y, Bn, l.H, l.W, l.C, l.Co, act, slope, nullptr, VF_ACT_NONE, 0.f)
+                : vf_pconv_gather(ctx, xp, wp, b, l.y, Bn, l.H, l.W, l.C, l.Co, act, slope);
+  }
+  l.x_seen = nullptr;
+  return full ? vf_deconv2d_fwd(ctx, x, w, b, l.y, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, act, slope)
+              : vf_conv2d_fwd(ctx, x, w, b, l.y, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, act, slope);
+}
+
+int bn_forward(vf_net* n, Layer& l, const float* x, int Bn, int act, float slope, int pre_rows, bool want_planes) {
+  vf_ctx* ctx = n->ctx;
+  const float* gamma = n->params + l.w_off;
+  const float* beta = n->params + l.b_off;
+  const int G = n->groups;
+  const int64_t npix = (int64_t)Bn * l.H * l.W;
+  l.out_planes = nullptr;
+  if (!n->train) return vf_bn_eval_fwd(ctx, x, l.y, gamma, beta, l.rm, l.rv, npix, l.C, l.d.eps, act, slope);
+  VF_REQUIRE(Bn % G == 0, "vf_net_forward: the batch (%d) does not divide into %d groups", Bn, G);
+  void* yp = nullptr;
+  if (want_planes && !sync_on(n)) {
+    if (int rc = ensure_planes(n, &l.yp, (int64_t)n->B * l.H * l.W * l.C)) return rc;
+    yp = l.yp;
+  }
+  if (pre_rows > 0) {
+    int rc = vf_bn_train_fwd_pre(ctx, l.part, pre_rows, x, l.y, gamma, beta, l.rm, l.rv, l.sm, l.si, l.sums, npix / G, l.C, G,
+                                 l.d.momentum, l.d.eps, act, slope, yp);
+    l.out_planes = yp;
+    return rc;
+  }
+  if (!sync_on(n)) {
+    int rc = yp ? vf_bn_train_fwd_planes(ctx, x, l.y, gamma, beta, l.rm, l.rv, l.sm, l.si, l.sums, npix / G, l.C, G, l.d.momentum,
+                                         l.d.eps, act, slope, yp)
+                : vf_bn_train_fwd_groups(ctx, x, l.y, gamma, beta, l.rm, l.rv, l.sm, l.si, l.sums, npix / G, l.C, G, l.d.momentum,
+                                         l.d.eps, act, slope);
+    l.out_planes = yp;
+    return rc;
+  }
+  // SyncBN: the per-channel sums of all ranks, then statistics of the global batch
+  VF_REQUIRE(G == 1, "SyncBN with batch groups is not part of the path");
+  if (int rc = vf_bn_stats(ctx, x, l.rm, l.sums, npix, l.C)) return rc;
+  if (n->comm)
+    if (int rc = vf_comm_allreduce_inline(n->comm, ctx, l.sums, 2 * l.C, 1, 0)) return rc;
+  if (int rc = vf_bn_finalize(ctx, l.sums, l.rm, l.rv, l.sm, l.si, npix * n->sync_world, l.C, l.d.momentum, l.d.eps)) return rc;
+  return vf_bn_apply(ctx, x, l.y, gamma, beta, l.sm, l.si, npix, l.C, act, slope);
+}
+
+// ---- backward pieces -----------------------------------------------------------------------------------------------
+// in_act != NONE: `x` is the in-place activated output of the module below; its updateGradInput rides in this epilogue
+int conv_bwd_data(vf_net* n, Layer& l, const float* x, const float* go, int Bn, int in_act, float in_slope, const void* g_planes) {
+  vf_ctx* ctx = n->ctx;
+  const float* w = n->params + l.w_off;
+  const bool full = is_full(l);
+  if (pconv_ok(n, l, Bn, l.Ho, l.Wo, l.Co, l.C, !full) && (in_act == VF_ACT_NONE || !full)) {
+    const void* gp = g_planes;
+    if (!gp) {
+      if (int rc = ensure_planes(n, &l.gp, (int64_t)n->B * l.Ho * l.Wo * l.Co)) return rc;
+      if (int rc = vf_planes_split(ctx, go, l.gp, (int64_t)Bn * l.Ho * l.Wo * l.Co)) return rc;
+      gp = l.gp;
+    }
+    l.g_seen = go;
+    l.gp_seen = gp;
+    const void* wp = nullptr;
+    if (int rc = weight_planes(n, l, !full, &wp)) return rc;
+    if (full) return vf_pconv_gather(ctx, gp, wp, nullptr, l.gx, Bn, l.Ho, l.Wo, l.Co, l.C, VF_ACT_NONE, 0.f);
+    return vf_pconv_scatter(ctx, gp, wp, nullptr, l.gx, Bn, l.Ho, l.Wo, l.Co, l.C, VF_ACT_NONE, 0.f,
+                            in_act != VF_ACT_NONE ? x : nullptr, in_act, in_slope);
+  }
+  l.g_seen = nullptr;
+  if (in_act != VF_ACT_NONE)
+    return vf_conv2d_bwd_data_act(ctx, go, w, l.gx, x, in_act, in_slope, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad);
+  return full ? vf_deconv2d_bwd_data(ctx, go, w, l.gx, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad)
+              : vf_conv2d_bwd_data(ctx, go, w, l.gx, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad);
+}
+
+struct Deferred {
+  const float* g;
+  float* gb;
+  int64_t P;
+  int C;
+  float beta;
+};
+
+int conv_acc(vf_net* n, Layer& l, const float* x, const float* go, int Bn, std::vector<Deferred>* deferred) {
+  vf_ctx* ctx = n->ctx;
+  const bool full = is_full(l);
+  float* gw = n->grads + l.w_off;
+  float* gb = n->grads + l.b_off;
+  const float beta = l.fresh ? 0.f : 1.f;
+  l.fresh = false;
+  if (deferred && l.Co % 4 == 0 && ((uintptr_t)go & 15) == 0) {
+    deferred->push_back(Deferred{go, gb, (int64_t)Bn * l.Ho * l.Wo, l.Co, beta});
+    gb = nullptr;
+  }
+  const bool planes = g_pwgrad && !g_no_pconv && l.x_seen == x && l.xp_seen && l.g_seen == go && l.gp_seen;
+  const void *xp = l.xp_seen, *gp = l.gp_seen;
+  l.g_seen = nullptr;        // single use: only a data-gradient pass of THIS walk may hand its planes over
+  l.gp_seen = nullptr;
+  if (planes)
+    return full ? vf_deconv2d_bwd_weight_planes(ctx, x, go, xp, gp, gw, gb, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, beta)
+                : vf_conv2d_bwd_weight_planes(ctx, x, go, xp, gp, gw, gb, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, beta);
+  return full ? vf_deconv2d_bwd_weight(ctx, x, go, gw, gb, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, beta)
+              : vf_conv2d_bwd_weight(ctx, x, go, gw, gb, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, beta);
+}
+
+// gsel >= 0: x / gy / y_act hold batch group gsel only (a pass over one of the concatenated batches): its saved statistics.
+// pre_rows > 0: gy arrives ALREADY MASKED by the activation's derivative and its sums sit in the partial buffer.
+int bn_backward(vf_net* n, Layer& l, const float* x, const float* gy, int Bn, bool want_gx, bool want_gp, int act, float slope,
+                const float* y_act, int gsel, int pre_rows, bool want_planes) {
+  vf_ctx* ctx = n->ctx;
+  VF_REQUIRE(n->train, "vf_net_backward: BatchNorm backward in evaluate mode is not part of the path");
+  const float* gamma = n->params + l.w_off;
+  float* gg = want_gp ? n->grads + l.w_off : nullptr;
+  float* gbt = want_gp ? n->grads + l.b_off : nullptr;
+  float* gx = want_gx ? l.gx : nullptr;
+  float pbeta = 1.f;
+  if (want_gp) {
+    pbeta = l.fresh ? 0.f : 1.f;
+    l.fresh = false;
+  }
+  l.grad_planes = nullptr;
+  const int G = gsel >= 0 ? 1 : n->groups;
+  const int row = gsel >= 0 ? gsel : 0;
+  float *sm = l.sm + (int64_t)row * l.C, *si = l.si + (int64_t)row * l.C;
+  double* su = l.sums + (int64_t)row * 2 * l.C;
+  const int64_t npix_g = (int64_t)Bn * l.H * l.W / G;
+  void* gp = nullptr;
+  if (want_planes && gx && !sync_on(n)) {
+    if (int rc = ensure_planes(n, &l.bgp, (int64_t)n->B * l.H * l.W * l.C)) return rc;
+    gp = l.bgp;
+  }
+  if (pre_rows > 0) {
+    int rc = vf_bn_bwd_pre(ctx, l.part, pre_rows, x, gy, gx, gg, gbt, gamma, sm, si, su, npix_g, l.C, G, pbeta, gp);
+    l.grad_planes = gp;
+    return rc;
+  }
+  if (!sync_on(n)) {
+    int rc = gp ? vf_bn_bwd_planes(ctx, x, y_act, gy, gx, gg, gbt, gamma, sm, si, su, npix_g, l.C, G, act, slope, pbeta, gp)
+                : vf_bn_bwd_groups(ctx, x, y_act, gy, gx, gg, gbt, gamma, sm, si, su, npix_g, l.C, G, act, slope, pbeta);
+    l.grad_planes = gp;
+    return rc;
+  }
+  // SyncBN: gamma / beta gradients come from THIS rank's sums (the flat-gradient exchange adds the other ranks' shares
+  // later); gradInput needs the sums over the whole global batch
+  VF_REQUIRE(G == 1 && gsel < 0, "SyncBN with batch groups is not part of the path");
+  const int64_t npix = (int64_t)Bn * l.H * l.W, n_total = npix * n->sync_world;
+  if (int rc = vf_bn_bwd_stats(ctx, x, y_act, gy, sm, su, npix, l.C, act, slope)) return rc;
+  if (want_gp)
+    if (int rc = vf_bn_bwd_apply(ctx, x, y_act, gy, nullptr, gg, gbt, gamma, sm, si, su, npix, n_total, l.C, act, slope, pbeta)) return rc;
+  if (n->comm)
+    if (int rc = vf_comm_allreduce_inline(n->comm, ctx, su, 2 * l.C, 1, 0)) return rc;
+  if (want_gx) return vf_bn_bwd_apply(ctx, x, y_act, gy, gx, nullptr, nullptr, gamma, sm, si, su, npix, n_total, l.C, act, slope, 1.f);
+  return 0;
+}
+
+// every deferred gradBias of a walk: two launches; the descriptor table is built once per combination and kept on the device
+int bias_grad_flush(vf_net* n, const std::vector<Deferred>& items) {
+  if (items.empty()) return 0;
+  std::string key((const char*)items.data(), items.size() * sizeof(Deferred));
+  auto it = n->colsum_plans.find(key);
+  if (it == n->colsum_plans.end()) {
+    std::vector<VfColsumDescH> desc(items.size());
+    char* ws = vf_ws_ptr(n->ctx);
+    size_t off = 0;
+    int b1 = 0, b2 = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+      const Deferred& d = items[i];
+      int cq, rpb, gx, gy;
+      if (int rc = vf_bias_grad_plan(d.P, d.C, &cq, &rpb, &gx, &gy)) return rc;
+      desc[i] = VfColsumDescH{d.g, d.gb, (double*)(ws + off), d.P, d.C, cq, rpb, gx, gy, b1, b2, d.beta};
+      off += ((size_t)gx * d.C * 8 + 255) / 256 * 256;
+      b1 += gx * gy;
+      b2 += (d.C + 3) / 4;
+    }
+    VF_REQUIRE(off <= vf_ws_avail(n->ctx), "vf_net: workspace too small for the bias-gradient partials");
+    void* dev = nullptr;
+    if (int rc = net_alloc(n->owned, &dev, desc.size() * sizeof(VfColsumDescH))) return rc;
+    VF_CHECK_HIP(hipMemcpy(dev, desc.data(), desc.size() * sizeof(VfColsumDescH), hipMemcpyHostToDevice));
+    it = n->colsum_plans.emplace(key, std::make_pair(dev, std::vector<int>{(int)items.size(), b1, b2})).first;
+  }
+  const std::vector<int>& g = it->second.second;
+  return vf_bias_grad_multi(n->ctx, it->second.first, g[0], g[1], g[2]);
+}
+
+// Backward over plan entries hi-1 .. lo.  gi >= 0: the pass covers batch group gi of the G the last forward ran
+// concatenated — saved activations are sliced to that group's samples; x_in / gy hold that group only.
+int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** gx_out, bool want_gp, bool need_input_grad, int hi,
+                  int lo, int gi, int G) {
+  vf_ctx* ctx = n->ctx;
+  const int np = (int)n->plan.size();
+  if (hi < 0 || hi > np) hi = np;
+  VF_REQUIRE(lo >= 0 && lo <= hi, "vf_net backward: bad plan range [%d, %d)", lo, hi);
+  VF_REQUIRE(gi < 0 || (!want_gp && G >= 1 && gi < G && n->B % G == 0), "vf_net: bad batch group %d of %d", gi, G);
+  const int Bn = gi >= 0 ? n->B / G : n->B;
+  const float* g = gy;
+  const void* g_pl = nullptr;
+  std::vector<Deferred> deferred;
+  bool act_done = hi < np ? (n->act_done_at == hi) : false;
+  int bn_pre = 0, pre = 0;
+  if (!n->wp_managed)
+    if (int rc = refresh_weight_planes(n)) return rc;
+  if (hi < np && n->bn_pre_at == hi) bn_pre = n->bn_pre_rows;      // a walk cut between a convolution and the BatchNorm below it
+  n->bn_pre_at = -1;
+  int rc = 0;
+  if (want_gp && (rc = vf_wgrad_group_begin(ctx))) return rc;
+  auto slice = [&](const float* p, int64_t per_sample) { return (gi >= 0 && p) ? p + (int64_t)gi * Bn * per_sample : p; };
+  for (int idx = hi - 1; idx >= lo && !rc; --idx) {
+    const Entry& e = n->plan[idx];
+    Layer& l = n->L[e.main];
+    const float* x = idx == 0 ? x_in : slice(entry_out(n, idx - 1, nullptr), (int64_t)l.H * l.W * l.C);
+    const float* mout = slice(entry_out(n, idx, nullptr), (int64_t)l.Ho * l.Wo * l.Co);
+    const bool want_gx = need_input_grad || idx > 0;
+    const int64_t out_e = (int64_t)Bn * l.Ho * l.Wo * l.Co;
+    if (l.d.kind == VF_L_BN) {
+      const int rows = bn_pre;
+      bn_pre = 0;
+      // the convolution below consumes this gradient in its data-gradient pass: write its planes here
+      bool want_pl = false;
+      if (want_gx && idx > 0) {
+        const Layer& below = n->L[n->plan[idx - 1].main];
+        want_pl = is_conv(below) && pconv_layer(below) && (idx - 1 > 0 || need_input_grad) &&
+                  pconv_ok(n, below, Bn, l.H, l.W, below.Co, below.C, !is_full(below));
+      }
+      rc = bn_backward(n, l, x, g, Bn, want_gx, want_gp, l.fused_act, l.fused_slope, l.fused_act != VF_ACT_NONE ? mout : nullptr,
+                       gi, rows, want_pl);
+      g = l.gx;
+      g_pl = l.grad_planes;
+      act_done = false;
+      continue;
+    }
+    if (is_conv(l)) {
+      const float* go = g;
+      if (l.fused_act != VF_ACT_NONE && !act_done) {
+        // undo the activation applied in this layer's epilogue: in place on the incoming gradient where that is ours (an
+        // in-place module does exactly that), else — the caller's gradOutput, Tanh / Sigmoid — into a buffer of its own
+        const bool ours = g != gy;
+        if (relu_like(l.fused_act) && ours) {
+          rc = vf_act_bwd(ctx, mout, g, const_cast<float*>(g), out_e, l.fused_act, l.fused_slope);
+        } else {
+          if (!l.gtmp && (rc = net_alloc(n->act_owned, (void**)&l.gtmp, sizeof(float) * (size_t)n->B * l.Ho * l.Wo * l.Co))) break;
+          rc = vf_act_bwd(ctx, mout, g, l.gtmp, out_e, l.fused_act, l.fused_slope);
+          go = l.gtmp;
+          g_pl = nullptr;
+        }
+        if (rc) break;
+      }
+      // the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this module's
+      // data-gradient epilogue (x IS that activated output)
+      int in_act = VF_ACT_NONE;
+      float in_slope = 0.f;
+      if (want_gx && idx > 0 && l.d.kind == VF_L_CONV && is_s2(l)) {
+        const Layer& pm = n->L[n->plan[idx - 1].main];
+        if (is_conv(pm) && relu_like(pm.fused_act)) {
+          in_act = pm.fused_act;
+          in_slope = pm.fused_slope;
+        }
+      }
+      // the module below is a BatchNorm (+ activation): this module's data-gradient pass also sums what that BatchNorm's
+      // backward needs, and stores its output masked by the activation's derivative
+      bool fuse_below = false;
+      if (want_gx && idx > 1) {
+        Layer& pm = n->L[n->plan[idx - 1].main];
+        if (pm.d.kind == VF_L_BN && bn_fusable(n, pm) && (pm.fused_act == VF_ACT_NONE || relu_like(pm.fused_act)) && pm.C == l.C &&
+            (gi < 0 || n->groups == G)) {
+          const float* xbn = slice(entry_out(n, idx - 2, nullptr), (int64_t)pm.H * pm.W * pm.C);      // the BatchNorm's input
+          const float* yact = pm.fused_act != VF_ACT_NONE ? x : nullptr;                              // (x IS pm's output)
+          const float* smv = gi >= 0 ? pm.sm + (int64_t)gi * pm.C : pm.sm;
+          if ((rc = vf_bn_fuse_next_bwd(ctx, xbn, yact, pm.fused_act, pm.fused_slope, smv, pm.part, pm.part_rows_cap,
+                                        gi >= 0 ? 1 : n->groups)))
+            break;
+          fuse_below = true;
+        }
+      }
+      if (want_gx) {
+        rc = conv_bwd_data(n, l, x, go, Bn, fuse_below ? VF_ACT_NONE : in_act, in_slope, g_pl);
+        if (fuse_below && !rc) rc = vf_bn_fuse_result(ctx, &pre);
+        if (rc) break;
+      }
+      if (want_gp && (rc = conv_acc(n, l, x, go, Bn, &deferred))) break;
+      g = want_gx ? l.gx : nullptr;
+      g_pl = nullptr;
+      act_done = !fuse_below && in_act != VF_ACT_NONE && want_gx;
+      bn_pre = pre;
+      pre = 0;
+      continue;
+    }
+    if (l.d.kind == VF_L_ACT && !l.absorbed) {
+      rc = vf_act_bwd(ctx, mout, g, l.gx, out_e, l.d.act, l.d.slope);
+      g = l.gx;
+      g_pl = nullptr;
+    }
+    // (nn.View, an absorbed activation: same storage, same gradient)
+    act_done = false;
+  }
+  if (want_gp) {
+    if (rc) {
+      (void)vf_wgrad_group_abort(ctx);      // a failure in mid-walk must not leave the group open
+      return rc;
+    }
+    if ((rc = vf_wgrad_group_end(ctx))) return rc;
+    if ((rc = bias_grad_flush(n, deferred))) return rc;
+  }
+  if (rc) return rc;
+  n->act_done_at = act_done ? lo : -1;      // a partial walk resumes at `lo`
+  if (bn_pre && lo > 0) {
+    n->bn_pre_at = lo;
+    n->bn_pre_rows = bn_pre;
+  }
+  if (gx_out) *gx_out = g;
+  return 0;
+}
+
+void free_pool(std::vector<void*>& pool) {
+  for (void* p : pool) (void)hipFree(p);
+  pool.clear();
+}
+
+// shapes, activation buffers and BatchNorm scratch for input [B][H][W][C]; parameters are untouched
+int net_shape(vf_net* n, int B, int C, int H, int W) {
+  free_pool(n->act_owned);
+  n->colsum_plans.clear();      // (the tables name activation buffers that no longer exist; the device copies live in `owned`)
+  n->B = B; n->C0 = C; n->H0 = H; n->W0 = W;
+  n->act_done_at = n->bn_pre_at = -1;
+  int c = C, h = H, w = W;
+  for (size_t i = 0; i < n->L.size(); ++i) {
+    Layer& l = n->L[i];
+    l.C = c; l.H = h; l.W = w;
+    l.Co = c; l.Ho = h; l.Wo = w;
+    switch (l.d.kind) {
+      case VF_L_CONV:
+        VF_REQUIRE(l.d.nin == c, "vf_net: layer %d expects %d input planes, gets %d", (int)i, l.d.nin, c);
+        l.Co = l.d.nout;
+        l.Ho = (h + 2 * l.d.pad - l.d.k) / l.d.stride + 1;
+        l.Wo = (w + 2 * l.d.pad - l.d.k) / l.d.stride + 1;
+        break;
+      case VF_L_FULLCONV:
+        VF_REQUIRE(l.d.nin == c, "vf_net: layer %d expects %d input planes, gets %d", (int)i, l.d.nin, c);
+        l.Co = l.d.nout;
+        l.Ho = (h - 1) * l.d.stride - 2 * l.d.pad + l.d.k;
+        l.Wo = (w - 1) * l.d.stride - 2 * l.d.pad + l.d.k;
+        break;
+      case VF_L_BN:
+        VF_REQUIRE(l.d.nout == c, "vf_net: BatchNorm layer %d has %d channels, gets %d", (int)i, l.d.nout, c);
+        break;
+      default:
+        break;
+    }
+    VF_REQUIRE(l.Ho > 0 && l.Wo > 0, "vf_net: layer %d has an empty output", (int)i);
+    c = l.Co; h = l.Ho; w = l.Wo;
+    l.y = l.y_own = l.gx = l.gtmp = nullptr;
+    l.xp = l.gp = l.yp = l.bgp = nullptr;
+    l.out_planes = l.grad_planes = nullptr;
+    l.x_seen = l.g_seen = nullptr;
+    l.xp_seen = l.gp_seen = nullptr;
+    l.part = nullptr;
+    l.sm = l.si = nullptr;
+    l.sums = nullptr;
+  }
+  n->gcap = std::max(n->groups, 2);
+  for (size_t i = 0; i < n->L.size(); ++i) {
+    Layer& l = n->L[i];
+    const size_t in_e = (size_t)B * l.H * l.W * l.C, out_e = (size_t)B * l.Ho * l.Wo * l.Co;
+    const bool own_out = is_conv(l) || l.d.kind == VF_L_BN || (l.d.kind == VF_L_ACT && !l.absorbed);
+    if (own_out) {
+      if (int rc = net_alloc(n->act_owned, (void**)&l.y_own, sizeof(float) * out_e)) return rc;
+      l.y = l.y_own;
+    }
+    if (is_conv(l) || l.d.kind == VF_L_BN || (l.d.kind == VF_L_ACT && !l.absorbed))
+      if (int rc = net_alloc(n->act_owned, (void**)&l.gx, sizeof(float) * in_e)) return rc;
+    if (l.d.kind == VF_L_BN) {
+      const size_t gc = (size_t)n->gcap * l.C;
+      if (int rc = net_alloc(n->act_owned, (void**)&l.sm, 4 * gc)) return rc;
+      if (int rc = net_alloc(n->act_owned, (void**)&l.si, 4 * gc)) return rc;
+      if (int rc = net_alloc(n->act_owned, (void**)&l.sums, 16 * gc)) return rc;
+      // [rows][2C] double partials: one row per 64-pixel output tile of the producing GEMM (or per block of its split-K
+      // combine, at most ~512)
+      const int64_t npix = (int64_t)B * l.H * l.W;
+      l.part_rows_cap = (int)std::max<int64_t>(npix / 64, 512) + 8 * n->gcap;
+      if (int rc = net_alloc(n->act_owned, (void**)&l.part, sizeof(double) * (size_t)l.part_rows_cap * 2 * l.C)) return rc;
+      (void)hipMemsetAsync(l.sm, 0, 4 * gc, n->ctx->stream);
+      (void)hipMemsetAsync(l.si, 0, 4 * gc, n->ctx->stream);
+      (void)hipMemsetAsync(l.sums, 0, 16 * gc, n->ctx->stream);
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
 VF_API int vf_net_destroy(vf_net* n) {
   if (!n) return 0;
-  for (void* p : n->owned) (void)hipFree(p);
+  if (n->ctx) (void)hipStreamSynchronize(n->ctx->stream);
+  free_pool(n->act_owned);
+  free_pool(n->owned);
   delete n;
   return 0;
 }
 
-// layers[0..nlayers): the modules in order; the input is [B][H][W][C] (NHWC).  Buffers are sized once, here.
+// layers[0..nlayers): the modules in order; the input is [B][H][W][C] (NHWC)
 VF_API int vf_net_create(vf_ctx* ctx, vf_net** out, const vf_layer_desc* layers, int nlayers, int B, int C, int H, int W) {
   VF_REQUIRE(ctx && out && layers && nlayers > 0 && B > 0 && C > 0 && H > 0 && W > 0, "vf_net_create: bad arguments");
+  *out = nullptr;
   vf_net* n = new vf_net();
   n->ctx = ctx;
-  n->B = B;
-  int c = C, h = H, w = W;
   int64_t off = 0;
   auto seg = [&](int64_t len) {
     const int64_t o = off;
     off += (len + 63) & ~(int64_t)63;
     return o;
   };
-  for (int i = 0; i < nlayers; ++i) {
+  int rc = 0;
+  for (int i = 0; i < nlayers && !rc; ++i) {
     Layer l;
     l.d = layers[i];
-    l.C = c; l.H = h; l.W = w;
-    l.Co = c; l.Ho = h; l.Wo = w;
     switch (l.d.kind) {
       case VF_L_CONV:
-        if (l.d.nin != c) { vf_set_error("vf_net_create: layer %d expects %d input planes, gets %d", i, l.d.nin, c); vf_net_destroy(n); return 2; }
-        l.Co = l.d.nout;
-        l.Ho = (h + 2 * l.d.pad - l.d.k) / l.d.stride + 1;
-        l.Wo = (w + 2 * l.d.pad - l.d.k) / l.d.stride + 1;
         l.w_n = (int64_t)l.d.nout * l.d.k * l.d.k * l.d.nin;
         l.b_n = l.d.nout;
         break;
       case VF_L_FULLCONV:
-        if (l.d.nin != c) { vf_set_error("vf_net_create: layer %d expects %d input planes, gets %d", i, l.d.nin, c); vf_net_destroy(n); return 2; }
-        l.Co = l.d.nout;
-        l.Ho = (h - 1) * l.d.stride - 2 * l.d.pad + l.d.k;
-        l.Wo = (w - 1) * l.d.stride - 2 * l.d.pad + l.d.k;
         l.w_n = (int64_t)l.d.nin * l.d.k * l.d.k * l.d.nout;
         l.b_n = l.d.nout;
         break;
       case VF_L_BN:
-        if (l.d.nout != c) { vf_set_error("vf_net_create: BatchNorm layer %d has %d channels, gets %d", i, l.d.nout, c); vf_net_destroy(n); return 2; }
         if (l.d.eps == 0.f) l.d.eps = 1e-5f;
         if (l.d.momentum == 0.f) l.d.momentum = 0.1f;
-        l.w_n = c;
-        l.b_n = c;
+        l.w_n = l.b_n = l.d.nout;
         break;
       case VF_L_ACT:
       case VF_L_VIEW:
         break;
       default:
         vf_set_error("vf_net_create: unknown layer kind %d at %d", l.d.kind, i);
-        vf_net_destroy(n);
-        return 2;
+        rc = 2;
+        break;
     }
-    if (l.Ho <= 0 || l.Wo <= 0) { vf_set_error("vf_net_create: layer %d has an empty output", i); vf_net_destroy(n); return 2; }
-    if (l.w_n) { l.w_off = seg(l.w_n); l.b_off = seg(l.b_n); }
-    c = l.Co; h = l.Ho; w = l.Wo;
+    if (rc) break;
+    if ((l.d.kind == VF_L_CONV || l.d.kind == VF_L_FULLCONV) && (l.d.nin <= 0 || l.d.nout <= 0 || l.d.k <= 0 || l.d.stride <= 0 || l.d.pad < 0)) {
+      vf_set_error("vf_net_create: layer %d: bad convolution geometry", i);
+      rc = 2;
+      break;
+    }
+    if (l.w_n) {
+      l.w_off = seg(l.w_n);
+      l.b_off = seg(l.b_n);
+    }
     n->L.push_back(l);
   }
-  // an activation directly behind a conv / full-conv / BatchNorm is applied by that layer (in place, as the reference's
-  // nn.LeakyReLU(0.2, true) / nn.ReLU(true) are; Tanh / Sigmoid own no state either)
-  for (size_t i = 0; i + 1 < n->L.size(); ++i) {
-    Layer& p = n->L[i];
-    Layer& a = n->L[i + 1];
-    if (a.d.kind == VF_L_ACT && (p.d.kind == VF_L_CONV || p.d.kind == VF_L_FULLCONV || p.d.kind == VF_L_BN)) {
-      p.fused_act = a.d.act;
-      p.fused_slope = a.d.slope;
-      a.absorbed = true;
-    }
-  }
-  n->nparams = off;
-  int rc = 0;
-  if ((rc = net_alloc(n, (void**)&n->params, sizeof(float) * (size_t)off)) || (rc = net_alloc(n, (void**)&n->grads, sizeof(float) * (size_t)off))) {
+  if (rc) {
     vf_net_destroy(n);
     return rc;
   }
+  // execution plan: an in-place (Leaky)ReLU behind a conv / full-conv / BatchNorm and a Tanh / Sigmoid right behind a
+  // convolution are applied by that layer (nn.Sequential(fuse=True)'s rule; the reference's activations are in-place modules)
+  for (size_t i = 0; i < n->L.size();) {
+    Layer& p = n->L[i];
+    Entry e{(int)i, -1};
+    if (i + 1 < n->L.size() && n->L[i + 1].d.kind == VF_L_ACT) {
+      Layer& a = n->L[i + 1];
+      const bool ok = (is_conv(p) || p.d.kind == VF_L_BN) ? (relu_like(a.d.act) || (is_conv(p) && (a.d.act == VF_ACT_TANH || a.d.act == VF_ACT_SIGMOID)))
+                                                          : false;
+      if (ok) {
+        p.fused_act = a.d.act;
+        p.fused_slope = a.d.slope;
+        a.absorbed = true;
+        e.act = (int)i + 1;
+      }
+    }
+    n->plan.push_back(e);
+    i += e.act >= 0 ? 2 : 1;
+  }
+  n->nparams = off;
+  if ((rc = net_alloc(n->owned, (void**)&n->params_own, sizeof(float) * (size_t)off)) ||
+      (rc = net_alloc(n->owned, (void**)&n->grads_own, sizeof(float) * (size_t)off))) {
+    vf_net_destroy(n);
+    return rc;
+  }
+  n->params = n->params_own;
+  n->grads = n->grads_own;
   (void)hipMemsetAsync(n->params, 0, sizeof(float) * (size_t)off, ctx->stream);
   (void)hipMemsetAsync(n->grads, 0, sizeof(float) * (size_t)off, ctx->stream);
+  // BatchNorm running statistics (mean 0, variance 1) and the conv-bias segment table of the sweep (train.lua:279)
+  std::vector<int64_t> boffs, blens;
   for (Layer& l : n->L) {
-    const size_t in_e = (size_t)B * l.H * l.W * l.C, out_e = (size_t)B * l.Ho * l.Wo * l.Co;
-    const bool own_out = l.d.kind == VF_L_CONV || l.d.kind == VF_L_FULLCONV || l.d.kind == VF_L_BN || (l.d.kind == VF_L_ACT && !l.absorbed);
-    if (own_out && (rc = net_alloc(n, (void**)&l.y, sizeof(float) * out_e))) break;
-    // gradInput: every computing module; an absorbed activation behind a (full-)convolution lends its slot to that
-    // convolution's backward (the activation's own updateGradInput, written there: the caller's gradOutput is not ours to edit)
-    const size_t li = (size_t)(&l - &n->L[0]);
-    const bool lend = l.d.kind == VF_L_ACT && l.absorbed && li > 0 && n->L[li - 1].d.kind != VF_L_BN;
-    if (((l.d.kind != VF_L_VIEW && !(l.d.kind == VF_L_ACT && l.absorbed)) || lend) && (rc = net_alloc(n, (void**)&l.gx, sizeof(float) * in_e))) break;
     if (l.d.kind == VF_L_BN) {
-      if ((rc = net_alloc(n, (void**)&l.rm, 4 * (size_t)l.C)) || (rc = net_alloc(n, (void**)&l.rv, 4 * (size_t)l.C)) ||
-          (rc = net_alloc(n, (void**)&l.sm, 4 * (size_t)l.C)) || (rc = net_alloc(n, (void**)&l.si, 4 * (size_t)l.C)) ||
-          (rc = net_alloc(n, (void**)&l.sums, 16 * (size_t)l.C)))
+      const int Cc = l.d.nout;
+      if ((rc = net_alloc(n->owned, (void**)&l.rm, 4 * (size_t)Cc)) || (rc = net_alloc(n->owned, (void**)&l.rv, 4 * (size_t)Cc))) break;
+      std::vector<float> ones((size_t)Cc, 1.f);
+      (void)hipMemsetAsync(l.rm, 0, 4 * (size_t)Cc, ctx->stream);
+      if (hipMemcpy(l.rv, ones.data(), 4 * (size_t)Cc, hipMemcpyHostToDevice) != hipSuccess) {
+        vf_set_error("vf_net_create: hipMemcpy failed");
+        rc = 1;
         break;
-      (void)hipMemsetAsync(l.rm, 0, 4 * (size_t)l.C, ctx->stream);
-      std::vector<float> ones((size_t)l.C, 1.f);
-      (void)hipMemcpyAsync(l.rv, ones.data(), 4 * (size_t)l.C, hipMemcpyHostToDevice, ctx->stream);
-      (void)hipStreamSynchronize(ctx->stream);      // (`ones` leaves scope)
+      }
+    } else if (is_conv(l)) {
+      boffs.push_back(l.b_off);
+      blens.push_back(l.b_n);
     }
   }
+  if (!rc && !boffs.empty()) {
+    n->nbias = (int)boffs.size();
+    if (!(rc = net_alloc(n->owned, (void**)&n->bias_offs, 8 * boffs.size())) && !(rc = net_alloc(n->owned, (void**)&n->bias_lens, 8 * boffs.size()))) {
+      if (hipMemcpy(n->bias_offs, boffs.data(), 8 * boffs.size(), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(n->bias_lens, blens.data(), 8 * blens.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        vf_set_error("vf_net_create: hipMemcpy failed");
+        rc = 1;
+      }
+    }
+  }
+  if (!rc) rc = net_shape(n, B, C, H, W);
   if (rc) {
     vf_net_destroy(n);
     return rc;
@@ -168,13 +791,42 @@ VF_API int vf_net_create(vf_ctx* ctx, vf_net** out, const vf_layer_desc* layers,
   return 0;
 }
 
-// net:getParameters(): the flat buffers (device pointers) and their length in floats.  Segment i of module m starts at
-// vf_net_param_offset(net, m, which) (which: 0 = weight / gamma, 1 = bias / beta); the host fills them (weights_init, a checkpoint).
+// a new input shape (Torch7 modules resize their outputs on the fly; this object sizes them once per shape): activations,
+// planes and BatchNorm scratch are re-planned, parameters / running statistics / weight planes stay.  Not during a capture.
+VF_API int vf_net_reshape(vf_net* n, int B, int C, int H, int W) {
+  VF_REQUIRE(n && B > 0 && C > 0 && H > 0 && W > 0, "vf_net_reshape: bad arguments");
+  if (B == n->B && C == n->C0 && H == n->H0 && W == n->W0) return 0;
+  VF_CHECK_HIP(hipStreamSynchronize(n->ctx->stream));
+  return net_shape(n, B, C, H, W);
+}
+
+// net:getParameters(): the flat buffers (device pointers) and their length in floats.  Segment `which` of module `layer`
+// starts at vf_net_param_offset (0 = weight / gamma, 1 = bias / beta); the host fills them (weights_init, a checkpoint).
 VF_API int vf_net_parameters(vf_net* n, float** params, float** grads, int64_t* count) {
   VF_REQUIRE(n != nullptr, "vf_net_parameters: NULL net");
   if (params) *params = n->params;
   if (grads) *grads = n->grads;
   if (count) *count = n->nparams;
+  return 0;
+}
+// Host-owned flat storage instead of the net's own (Torch7 keeps parameters in Lua-owned tensors; after getParameters()
+// every weight / bias is a view of ONE storage — this is that storage): count floats each, the layout of
+// vf_net_param_offset, 16-byte aligned.  Nothing is copied.  NULL, NULL goes back to the net's own buffers.
+VF_API int vf_net_bind_parameters(vf_net* n, float* params, float* grads, int64_t count) {
+  VF_REQUIRE(n != nullptr, "vf_net_bind_parameters: NULL net");
+  if (!params && !grads) {
+    n->params = n->params_own;
+    n->grads = n->grads_own;
+  } else {
+    VF_REQUIRE(params && grads && count >= n->nparams, "vf_net_bind_parameters: need both buffers of >= %lld floats", (long long)n->nparams);
+    VF_REQUIRE((((uintptr_t)params | (uintptr_t)grads) & 15) == 0, "vf_net_bind_parameters: buffers must be 16-byte aligned");
+    n->params = params;
+    n->grads = grads;
+  }
+  for (Layer& l : n->L) l.wp_live = false;      // the planes were split from the other storage
+  n->wp_key.clear();
+  n->colsum_plans.clear();
+  n->both_tables.clear();
   return 0;
 }
 VF_API int64_t vf_net_param_offset(const vf_net* n, int layer, int which, int64_t* length) {
@@ -190,17 +842,64 @@ VF_API int vf_net_bn_running(vf_net* n, int layer, float** running_mean, float**
   if (running_var) *running_var = n->L[layer].rv;
   return 0;
 }
+VF_API int vf_net_bind_bn_running(vf_net* n, int layer, float* running_mean, float* running_var) {
+  VF_REQUIRE(n && layer >= 0 && layer < (int)n->L.size() && n->L[layer].d.kind == VF_L_BN, "vf_net_bind_bn_running: layer %d is not a BatchNorm", layer);
+  VF_REQUIRE(running_mean && running_var, "vf_net_bind_bn_running: NULL buffer");
+  n->L[layer].rm = running_mean;
+  n->L[layer].rv = running_var;
+  return 0;
+}
+// save_mean / save_invstd of the last training forward ([groups][C]; THNN's save_mean / save_std)
+VF_API int vf_net_bn_saved(vf_net* n, int layer, float** save_mean, float** save_invstd) {
+  VF_REQUIRE(n && layer >= 0 && layer < (int)n->L.size() && n->L[layer].d.kind == VF_L_BN, "vf_net_bn_saved: layer %d is not a BatchNorm", layer);
+  if (save_mean) *save_mean = n->L[layer].sm;
+  if (save_invstd) *save_invstd = n->L[layer].si;
+  return 0;
+}
 VF_API int vf_net_training(vf_net* n, int train) {
   VF_REQUIRE(n != nullptr, "vf_net_training: NULL net");
   n->train = train != 0;
   return 0;
 }
-VF_API int vf_net_zero_grad(vf_net* n) {      // lazily, like the mirror: the next accGradParameters of each module overwrites
+VF_API int vf_net_zero_grad(vf_net* n) {      // lazily: the next accGradParameters of each module overwrites
   VF_REQUIRE(n != nullptr, "vf_net_zero_grad: NULL net");
   for (Layer& l : n->L) l.fresh = true;
   return 0;
 }
-// output of module `layer` after a forward call (net.modules[i].output), device pointer
+// netX:apply(function(m) if torch.type(m):find('Convolution') then m.bias:zero() end end) (train.lua:279-280): one launch
+// for this net — and for `other` too when given (both closures sweep BOTH nets), its segments addressed from this net's base
+VF_API int vf_net_zero_conv_biases(vf_net* n, vf_net* other) {
+  VF_REQUIRE(n != nullptr, "vf_net_zero_conv_biases: NULL net");
+  if (!other || other == n || other->nbias == 0) {
+    if (n->nbias == 0) return 0;
+    return vf_zero_segments(n->ctx, n->params, n->bias_offs, n->bias_lens, n->nbias);
+  }
+  auto it = n->both_tables.find(other);
+  if (it != n->both_tables.end() && (it->second.base != n->params || it->second.other_base != other->params)) {
+    n->both_tables.erase(it);       // one of the nets was re-bound to other storage since
+    it = n->both_tables.end();
+  }
+  if (it == n->both_tables.end()) {
+    std::vector<int64_t> offs((size_t)n->nbias + other->nbias), lens(offs.size());
+    if (n->nbias) {
+      VF_CHECK_HIP(hipMemcpy(offs.data(), n->bias_offs, 8 * (size_t)n->nbias, hipMemcpyDeviceToHost));
+      VF_CHECK_HIP(hipMemcpy(lens.data(), n->bias_lens, 8 * (size_t)n->nbias, hipMemcpyDeviceToHost));
+    }
+    VF_CHECK_HIP(hipMemcpy(offs.data() + n->nbias, other->bias_offs, 8 * (size_t)other->nbias, hipMemcpyDeviceToHost));
+    VF_CHECK_HIP(hipMemcpy(lens.data() + n->nbias, other->bias_lens, 8 * (size_t)other->nbias, hipMemcpyDeviceToHost));
+    const int64_t delta = other->params - n->params;      // in floats
+    for (int i = 0; i < other->nbias; ++i) offs[n->nbias + i] += delta;
+    int64_t *d_offs = nullptr, *d_lens = nullptr;
+    if (int rc = net_alloc(n->owned, (void**)&d_offs, 8 * offs.size())) return rc;
+    if (int rc = net_alloc(n->owned, (void**)&d_lens, 8 * lens.size())) return rc;
+    VF_CHECK_HIP(hipMemcpy(d_offs, offs.data(), 8 * offs.size(), hipMemcpyHostToDevice));
+    VF_CHECK_HIP(hipMemcpy(d_lens, lens.data(), 8 * lens.size(), hipMemcpyHostToDevice));
+    it = n->both_tables.emplace(other, vf_net::BothTable{d_offs, d_lens, n->params, other->params}).first;
+  }
+  return vf_zero_segments(n->ctx, n->params, it->second.offs, it->second.lens, n->nbias + other->nbias);
+}
+
+// output of module `layer` after a forward call (net.modules[i].output), gradInput after a backward call; device pointers
 VF_API int vf_net_layer_output(vf_net* n, int layer, const float** y) {
   VF_REQUIRE(n && y && layer >= 0 && layer < (int)n->L.size(), "vf_net_layer_output: bad layer");
   const float* p = nullptr;
@@ -209,123 +908,172 @@ VF_API int vf_net_layer_output(vf_net* n, int layer, const float** y) {
   *y = p;
   return 0;
 }
+VF_API int vf_net_layer_grad_input(vf_net* n, int layer, const float** gx) {
+  VF_REQUIRE(n && gx && layer >= 0 && layer < (int)n->L.size(), "vf_net_layer_grad_input: bad layer");
+  *gx = n->L[layer].gx;
+  return 0;
+}
+// shape of module `layer`: input (C, H, W) and output (Co, Ho, Wo) per sample, and the batch size
+VF_API int vf_net_layer_shape(const vf_net* n, int layer, int* B, int* C, int* H, int* W, int* Co, int* Ho, int* Wo) {
+  VF_REQUIRE(n && layer >= 0 && layer < (int)n->L.size(), "vf_net_layer_shape: bad layer");
+  const Layer& l = n->L[layer];
+  if (B) *B = n->B;
+  if (C) *C = l.C;
+  if (H) *H = l.H;
+  if (W) *W = l.W;
+  if (Co) *Co = l.Co;
+  if (Ho) *Ho = l.Ho;
+  if (Wo) *Wo = l.Wo;
+  return 0;
+}
+// Let module `layer` (a convolution / BatchNorm) write its output into the host's buffer instead of the net's own — e.g.
+// the generator's last convolution straight into the fake half of netD's [real; fake] input (no copy per iteration).
+// NULL restores the net's buffer.
+VF_API int vf_net_bind_output(vf_net* n, int layer, float* y) {
+  VF_REQUIRE(n && layer >= 0 && layer < (int)n->L.size() && n->L[layer].y_own, "vf_net_bind_output: layer %d owns no output", layer);
+  n->L[layer].y = y ? y : n->L[layer].y_own;
+  return 0;
+}
+
+// the next forwards carry G concatenated, independent batches (BatchNorm statistics, running averages and backward sums
+// per group, in group order — what G separate calls would compute)
+VF_API int vf_net_set_batch_groups(vf_net* n, int G) {
+  VF_REQUIRE(n && G >= 1 && G <= 64, "vf_net_set_batch_groups: bad group count %d", G);
+  if (G > n->gcap) {
+    n->groups = G;
+    VF_CHECK_HIP(hipStreamSynchronize(n->ctx->stream));
+    return net_shape(n, n->B, n->C0, n->H0, n->W0);
+  }
+  n->groups = G;
+  return 0;
+}
+VF_API int vf_net_set_skip_input_grad(vf_net* n, int on) {
+  VF_REQUIRE(n != nullptr, "vf_net_set_skip_input_grad: NULL net");
+  n->skip_input_grad = on != 0;
+  return 0;
+}
+VF_API int vf_net_set_weight_planes_managed(vf_net* n, int on) {
+  VF_REQUIRE(n != nullptr, "vf_net_set_weight_planes_managed: NULL net");
+  n->wp_managed = on != 0;
+  return 0;
+}
+VF_API int vf_net_refresh_weight_planes(vf_net* n) {
+  VF_REQUIRE(n != nullptr, "vf_net_refresh_weight_planes: NULL net");
+  return refresh_weight_planes(n);
+}
+VF_API int vf_net_set_planes_gate(double min_gflop, int min_rows) {
+  g_gate_gflop = min_gflop;
+  g_gate_rows = min_rows;
+  return 0;
+}
+VF_API int vf_net_set_sync_bn(vf_net* n, vf_comm* comm, int world, int force) {
+  VF_REQUIRE(n && world >= 1, "vf_net_set_sync_bn: bad arguments");
+  n->comm = comm;
+  n->sync_world = world;
+  n->sync_force = force != 0;
+  return 0;
+}
+VF_API int vf_net_set_act_observer(vf_net* n, vf_net_act_observer fn, void* user) {
+  VF_REQUIRE(n != nullptr, "vf_net_set_act_observer: NULL net");
+  n->observer = fn;
+  n->observer_user = user;
+  return 0;
+}
+VF_API int vf_net_plan_size(const vf_net* n) { return n ? (int)n->plan.size() : -1; }
+// (plan index k, flat offset): the shortest tail plan[k:] that owns at least `frac` of the parameters.  After a backward walk
+// over plan[k:] the flat gradient [offset, end) is final: its exchange can start while the rest of the walk runs.
+VF_API int vf_net_bucket_split(const vf_net* n, double frac, int* plan_index, int64_t* flat_offset) {
+  VF_REQUIRE(n && plan_index && flat_offset, "vf_net_bucket_split: NULL argument");
+  double total = 0;
+  for (const Layer& l : n->L) total += (double)(l.w_n + l.b_n);
+  double acc = 0;
+  *plan_index = 0;
+  *flat_offset = 0;
+  for (int idx = (int)n->plan.size() - 1; idx >= 0; --idx) {
+    const Layer& l = n->L[n->plan[idx].main];
+    if (l.w_off < 0) continue;
+    acc += (double)(l.w_n + l.b_n);
+    *plan_index = idx;
+    *flat_offset = l.w_off;
+    if (acc >= frac * total) break;
+  }
+  return 0;
+}
 
 VF_API int vf_net_forward(vf_net* n, const float* x, const float** y) {
   VF_REQUIRE(n && x, "vf_net_forward: NULL argument");
   vf_ctx* ctx = n->ctx;
   const float* cur = x;
-  for (Layer& l : n->L) {
-    const float* w = l.w_off >= 0 ? n->params + l.w_off : nullptr;
-    const float* b = l.b_off >= 0 ? n->params + l.b_off : nullptr;
+  const void* cur_pl = nullptr;      // bf16 planes of `cur`, when its producer wrote them
+  int pre_rows = 0;
+  if (!n->wp_managed)
+    if (int rc = refresh_weight_planes(n)) return rc;
+  const int np = (int)n->plan.size();
+  for (int idx = 0; idx < np; ++idx) {
+    const Entry& e = n->plan[idx];
+    Layer& l = n->L[e.main];
+    Layer* nxt = idx + 1 < np ? &n->L[n->plan[idx + 1].main] : nullptr;
     int rc = 0;
-    switch (l.d.kind) {
-      case VF_L_CONV:
-        rc = vf_conv2d_fwd(ctx, cur, w, b, l.y, n->B, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, l.fused_act, l.fused_slope);
+    if (is_conv(l)) {
+      if (l.fused_act == VF_ACT_NONE && nxt && nxt->d.kind == VF_L_BN && bn_fusable(n, *nxt) && nxt->d.nout == l.Co) {
+        // the BatchNorm behind this convolution gets its statistics from the convolution's own epilogue
+        if ((rc = vf_bn_fuse_next_fwd(ctx, nxt->rm, nxt->part, nxt->part_rows_cap, n->groups))) return rc;
+        if ((rc = conv_forward(n, l, cur, cur_pl, n->B, VF_ACT_NONE, 0.f, false))) return rc;
+        if ((rc = vf_bn_fuse_result(ctx, &pre_rows))) return rc;
         cur = l.y;
-        break;
-      case VF_L_FULLCONV:
-        rc = vf_deconv2d_fwd(ctx, cur, w, b, l.y, n->B, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, l.fused_act, l.fused_slope);
-        cur = l.y;
-        break;
-      case VF_L_BN: {
-        const int64_t npix = (int64_t)n->B * l.H * l.W;
-        if (n->train)
-          rc = vf_bn_train_fwd(ctx, cur, l.y, w, b, l.rm, l.rv, l.sm, l.si, l.sums, npix, l.C, l.d.momentum, l.d.eps, l.fused_act, l.fused_slope);
-        else
-          rc = vf_bn_eval_fwd(ctx, cur, l.y, w, b, l.rm, l.rv, npix, l.C, l.d.eps, l.fused_act, l.fused_slope);
-        cur = l.y;
-        break;
+        cur_pl = nullptr;
+        continue;
       }
-      case VF_L_ACT:
-        if (!l.absorbed) {
-          rc = vf_act_fwd(ctx, cur, l.y, (int64_t)n->B * l.H * l.W * l.C, l.d.act, l.d.slope);
-          cur = l.y;
-        }
-        break;
-      default:
-        break;      // nn.View: same storage
+      const bool want_pl = nxt && is_conv(*nxt) && pconv_layer(*nxt) &&
+                           pconv_ok(n, *nxt, n->B, l.Ho, l.Wo, nxt->d.nin, nxt->d.nout, is_full(*nxt));
+      if ((rc = conv_forward(n, l, cur, cur_pl, n->B, l.fused_act, l.fused_slope, want_pl))) return rc;
+      cur = l.y;
+      cur_pl = l.out_planes;
+      if (relu_like(l.fused_act) && (rc = run_observer(n, e.act, l.y, (int64_t)n->B * l.Ho * l.Wo * l.Co, cur_pl))) return rc;
+      continue;
     }
-    if (rc) return rc;
+    if (l.d.kind == VF_L_BN) {
+      const int rows = pre_rows;
+      pre_rows = 0;
+      const bool want_pl = n->train && nxt && is_conv(*nxt) && pconv_layer(*nxt) && (l.fused_act == VF_ACT_NONE || relu_like(l.fused_act)) &&
+                           pconv_ok(n, *nxt, n->B, l.H, l.W, nxt->d.nin, nxt->d.nout, is_full(*nxt));
+      if ((rc = bn_forward(n, l, cur, n->B, l.fused_act, l.fused_slope, rows, want_pl))) return rc;
+      cur = l.y;
+      cur_pl = l.out_planes;
+      if (relu_like(l.fused_act) && (rc = run_observer(n, e.act, l.y, (int64_t)n->B * l.H * l.W * l.C, cur_pl))) return rc;
+      continue;
+    }
+    cur_pl = nullptr;
+    if (l.d.kind == VF_L_ACT && !l.absorbed) {
+      if ((rc = vf_act_fwd(ctx, cur, l.y, (int64_t)n->B * l.H * l.W * l.C, l.d.act, l.d.slope))) return rc;
+      cur = l.y;
+      if (relu_like(l.d.act) && (rc = run_observer(n, e.main, l.y, (int64_t)n->B * l.H * l.W * l.C, nullptr))) return rc;
+    }
+    // nn.View: same storage
   }
   if (y) *y = cur;
   return 0;
 }
 
-// the walk shared by backward (acc = true) and updateGradInput (acc = false)
-static int net_walk_back(vf_net* n, const float* x, const float* gy, const float** gx_out, bool acc) {
-  vf_ctx* ctx = n->ctx;
-  const float* g = gy;
-  int rc = 0;
-  if (acc && (rc = vf_wgrad_group_begin(ctx))) return rc;
-  for (int i = (int)n->L.size() - 1; i >= 0 && !rc; --i) {
-    Layer& l = n->L[i];
-    const float* in = x;                    // input of layer i = output of the nearest earlier layer that owns one
-    for (int j = i - 1; j >= 0; --j)
-      if (n->L[j].y) { in = n->L[j].y; break; }
-    const float* w = l.w_off >= 0 ? n->params + l.w_off : nullptr;
-    float* gw = l.w_off >= 0 ? n->grads + l.w_off : nullptr;
-    float* gb = l.b_off >= 0 ? n->grads + l.b_off : nullptr;
-    const float beta = l.fresh ? 0.f : 1.f;
-    const int64_t out_e = (int64_t)n->B * l.Ho * l.Wo * l.Co;
-    switch (l.d.kind) {
-      case VF_L_CONV:
-      case VF_L_FULLCONV: {
-        const bool full = l.d.kind == VF_L_FULLCONV;
-        const float* go = g;
-        if (l.fused_act != VF_ACT_NONE) {      // undo the activation applied in this layer's epilogue (needs its own buffer:
-          float* tmp = n->L[i + 1].gx;         // the caller's gradOutput is not ours to overwrite) — the absorbed module's slot
-          if ((rc = vf_act_bwd(ctx, l.y, g, tmp, out_e, l.fused_act, l.fused_slope))) break;
-          go = tmp;
-        }
-        if (acc) {
-          rc = full ? vf_deconv2d_bwd_weight(ctx, in, go, gw, gb, n->B, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, beta)
-                    : vf_conv2d_bwd_weight(ctx, in, go, gw, gb, n->B, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, beta);
-          l.fresh = false;
-          if (rc) break;
-        }
-        rc = full ? vf_deconv2d_bwd_data(ctx, go, w, l.gx, n->B, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad)
-                  : vf_conv2d_bwd_data(ctx, go, w, l.gx, n->B, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad);
-        g = l.gx;
-        break;
-      }
-      case VF_L_BN: {
-        const int64_t npix = (int64_t)n->B * l.H * l.W;
-        if (!n->train) { vf_set_error("vf_net_backward: BatchNorm backward in evaluate mode is not part of the path"); rc = 2; break; }
-        rc = vf_bn_bwd(ctx, in, l.fused_act != VF_ACT_NONE ? l.y : nullptr, g, l.gx, acc ? gw : nullptr, acc ? gb : nullptr, w, l.sm, l.si,
-                       l.sums, npix, l.C, l.fused_act, l.fused_slope, beta);
-        if (acc) l.fresh = false;
-        g = l.gx;
-        break;
-      }
-      case VF_L_ACT:
-        if (!l.absorbed) {
-          rc = vf_act_bwd(ctx, l.y, g, l.gx, out_e, l.d.act, l.d.slope);
-          g = l.gx;
-        }
-        break;
-      default:
-        break;
-    }
-  }
-  if (acc) {
-    if (rc) {
-      (void)vf_wgrad_group_abort(ctx);
-      return rc;
-    }
-    if ((rc = vf_wgrad_group_end(ctx))) return rc;
-  }
-  if (rc) return rc;
-  if (gx_out) *gx_out = g;
-  return 0;
-}
-
-// net:backward(input, gradOutput): gradInput + accumulated parameter gradients (every weight gradient in one grouped launch)
+// net:backward(input, gradOutput): gradInput + accumulated parameter gradients (every weight gradient in one grouped launch).
+// With vf_net_set_skip_input_grad the first layer's gradInput is left out and *gx is NULL.
 VF_API int vf_net_backward(vf_net* n, const float* x, const float* gy, const float** gx) {
   VF_REQUIRE(n && x && gy, "vf_net_backward: NULL argument");
-  return net_walk_back(n, x, gy, gx, true);
+  return net_walk_back(n, x, gy, gx, true, !n->skip_input_grad, -1, 0, -1, 1);
+}
+// backward() restricted to plan entries hi-1 .. lo (hi < 0: from the top); gy is what the entry above `hi` returned
+VF_API int vf_net_backward_range(vf_net* n, const float* x, const float* gy, int hi, int lo, int need_input_grad, const float** gx) {
+  VF_REQUIRE(n && x && gy, "vf_net_backward_range: NULL argument");
+  return net_walk_back(n, x, gy, gx, true, need_input_grad != 0, hi, lo, -1, 1);
 }
 // net:updateGradInput(input, gradOutput): gradInput only (parameter gradients untouched; train.lua:366)
 VF_API int vf_net_update_grad_input(vf_net* n, const float* x, const float* gy, const float** gx) {
   VF_REQUIRE(n && x && gy, "vf_net_update_grad_input: NULL argument");
-  return net_walk_back(n, x, gy, gx, false);
+  return net_walk_back(n, x, gy, gx, false, true, -1, 0, -1, 1);
+}
+// the same over batch group g of the G the last forward ran concatenated: x / gy hold that group's samples only; saved
+// activations and BatchNorm statistics are that group's (fGx's pass over the fake half of netD's 2B batch)
+VF_API int vf_net_update_grad_input_group(vf_net* n, const float* x, const float* gy, int g, int G, const float** gx) {
+  VF_REQUIRE(n && x && gy, "vf_net_update_grad_input_group: NULL argument");
+  return net_walk_back(n, x, gy, gx, false, true, -1, 0, g, G);
 }

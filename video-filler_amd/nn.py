@@ -1040,6 +1040,17 @@ class Sequential(Module):
         self._wp_managed = bool(on)
         return self
 
+    def redirect_last_output(self, cur, buf):
+        """Let the last convolution of this net write its output into `buf` from the next forward on, if `cur` — what a consumer
+        was just handed — IS that convolution's output buffer (same storage, same shape): saves the consumer's copy per iteration
+        (the generator's image straight into the fake half of netD's [real; fake] batch).  Returns whether it took effect."""
+        last = [m for m in self.leaves() if isinstance(m, SpatialConvolution)][-1]
+        lo = getattr(last, "output", None)
+        if lo is not None and lo.data_ptr() == cur.data_ptr() and tuple(lo.shape) == tuple(buf.shape):
+            last.output = buf
+            return True
+        return False
+
     def bucket_split(self, frac=0.9):
         """(plan index k, flat offset): the shortest tail plan[k:] of the backward order's head that owns at least
         `frac` of the parameters.  After a walk over plan[k:] the flat gradient [offset, end) is final."""

@@ -28,6 +28,22 @@ DEFAULT_OPT_VID = dict(batchSize=16, fineSize=128, nBottleneck=4000, nef=64, ngf
                        nc_in=None, nc_out=None)
 
 
+# Which host drives netG / netD: "mirror" = the module-by-module nn.Sequential of nn.py (every layer call crosses the C-ABI on its
+# own), "cabi" = the library's own net object (vf_net_*, cnet.CNet: one C-ABI call per Torch7 method, the whole fast path inside
+# libvf_hip.so — what a Lua host gets through hipnn.Net).  Same kernels, same plan; nets with table modules (train.lua's option
+# branches) stay on the mirror under either setting.
+DEFAULT_HOST = os.environ.get("VF_HOST", "mirror")
+
+
+def _host_nets(host, netG, netD):
+    host = host or DEFAULT_HOST
+    assert host in ("mirror", "cabi"), host
+    if host == "cabi":
+        from .cnet import adopt_if_chain
+        return adopt_if_chain(netG), adopt_if_chain(netD), host
+    return netG, netD, host
+
+
 def opt_from_env(defaults):
     """`for k,v in pairs(opt) do opt[k] = tonumber(os.getenv(k)) or os.getenv(k) or opt[k] end` (train.lua:36)."""
     opt = dict(defaults)
@@ -198,6 +214,9 @@ class _TrainerBase:
         # beside netD's real pass.  Each side stream has its own context and workspace (backend.fork()).
         self.side_g = None
         B0 = get_backend()
+        from .cnet import CNet
+        if any(isinstance(net, CNet) for net in (self.netG, self.netD)):
+            overlap = False        # a vf_net lives on ONE context / stream; the side-stream experiments belong to the mirror
         if overlap and hasattr(B0, "fork"):
             self.netD.side = B0.fork()
             self.netG.side = self.netD.side
@@ -297,10 +316,7 @@ class _TrainerBase:
             self._cat_real = key
         if fake_in.data_ptr() != self._cat[n:].data_ptr():
             B.copy(self._cat[n:], fake_in)
-            last = [m for m in self.netG.leaves() if isinstance(m, nn.SpatialConvolution)][-1]
-            lo = getattr(last, "output", None)
-            if lo is not None and lo.data_ptr() == fake_in.data_ptr() and tuple(lo.shape) == tuple(self._cat[n:].shape):
-                last.output = self._cat[n:]
+            self.netG.redirect_last_output(fake_in, self._cat[n:])
         out = self.netD.forward(self._cat)
         if self._cat_df is None or tuple(self._cat_df.shape) != tuple(out.shape):
             self._cat_df = B.zeros(out.numel()).view(out.shape)
@@ -393,7 +409,8 @@ class _TrainerBase:
     def enable_adam_overlap(self, on=True, min_numel=4 << 20):
         assert self._graph is None and self._graphs is None, "enable_adam_overlap before capture()"
         self.adam_overlap = False
-        if not on or self._comm_on() or not hasattr(get_backend(), "fork"):
+        from .cnet import CNet
+        if not on or self._comm_on() or not hasattr(get_backend(), "fork") or isinstance(self.netG, CNet):
             return self
         plan = self.netG._plan or self.netG._build_plan()
         big = [(m, o, n) for m, name, gname, o, n in self.netG._flat[2] if name == "weight" and n >= min_numel]
@@ -608,7 +625,7 @@ class CenterTrainer(_TrainerBase):
     """train.lua: centre-square inpainting; netD judges the 64x64 centre."""
 
     def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
-                 skip_dead_grads=True, overlap=True, shard_adam=False):
+                 skip_dead_grads=True, overlap=True, shard_adam=False, host=None):
         o = dict(DEFAULT_OPT_TRAIN)
         o.update(opt or {})
         self.opt = o
@@ -618,6 +635,10 @@ class CenterTrainer(_TrainerBase):
         self.netD = build_netD(o["nc"], o["ndf"], False, fuse, lazy_zero, sm, conditionAdv=bool(o["conditionAdv"]))
         if o["conditionAdv"] and skip_dead_grads:
             self.netD.modules[0].skip_grad = (0,)     # nobody reads the gradient w.r.t. the context (train.lua:371)
+        if fuse:
+            self.netG, self.netD, self.host = _host_nets(host, self.netG, self.netD)
+        else:
+            self.host = "mirror"
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
         self._finish_init(seed, world, rank, group, sync_bn, skip_dead_grads, overlap and not (world > 1 and sync_bn), shard_adam)
         if o["conditionAdv"] and self.batch_d:
@@ -752,7 +773,7 @@ class VidTrainer(_TrainerBase):
     """train_vid_weighted.lua / train_wholeim_input.lua: full-frame output, netD judges the whole frame."""
 
     def __init__(self, opt=None, seed=1234, world=1, rank=0, group=None, sync_bn=False, fuse=True, lazy_zero=True,
-                 skip_dead_grads=True, overlap=True, shard_adam=False):
+                 skip_dead_grads=True, overlap=True, shard_adam=False, host=None):
         o = dict(DEFAULT_OPT_VID)
         o.update(opt or {})
         self.opt = o
@@ -765,6 +786,10 @@ class VidTrainer(_TrainerBase):
         self.netG = build_netG(self.nc_in, self.nc_out, o["nef"], o["ngf"], o["nBottleneck"], True, fuse, lazy_zero, sm,
                                half_last=bool(o.get("logoNet", False)), extra_bottleneck_stage=_ext256(o))
         self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero, sm, extra_last_layer=_ext256(o))
+        if fuse:
+            self.netG, self.netD, self.host = _host_nets(host, self.netG, self.netD)
+        else:
+            self.host = "mirror"
         self.netI = None                 # withInit: set_initializer(net) (train_vid_weighted.lua:260-264)
         self._ctx_filled = None
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
