@@ -47,3 +47,19 @@ def planes_gate(request, hipb):
         yield request.param
     finally:
         nn._PCONV_MIN_GFLOP = old
+
+
+HOSTS = ["mirror", "cabi"]
+
+
+@pytest.fixture(params=HOSTS)
+def host(request, hipb):
+    """who drives netG / netD in the trainers: the module-by-module Python mirror (nn.py) or the library's own net object
+    (vf_net_*, cnet.CNet) — the boundary a Lua host binds (VERDICT r2 missing #1).  Same kernels, same plan, same bars."""
+    from video_filler_amd import trainers
+    old = trainers.DEFAULT_HOST
+    trainers.DEFAULT_HOST = request.param
+    try:
+        yield request.param
+    finally:
+        trainers.DEFAULT_HOST = old

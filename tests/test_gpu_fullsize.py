@@ -236,7 +236,7 @@ def _golden_full():
 
 
 @pytest.mark.parametrize("name", ["center8", "vid16", "wholeim"])
-def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb, planes_gate):
+def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb, planes_gate, host):
     """One whole iteration (fDx + Adam + fGx + Adam) at FULL net width against the CPU oracle's result for the same seeds,
     computed in the build container and committed (tests/golden/full_<name>.npz; `center8` is BASELINE.json configs[0]: the
     train.lua recipe at batchSize 8, nBottleneck 4000).  Bars: losses 2e-5; generator output 1e-4 of its max; gradient
@@ -279,7 +279,7 @@ def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb, p
 
 
 @pytest.mark.parametrize("cfg", ["vid16", "wholeim-half"])
-def test_video_nets_against_the_oracle_at_run_time(cfg, oracle, hipb, planes_gate):
+def test_video_nets_against_the_oracle_at_run_time(cfg, oracle, hipb, planes_gate, host):
     """The oracle itself beside the HIP path, from identical weights and batches, one iteration with every (Leaky)ReLU
     kink pinned (helpers.KinkSync) so that gradients are held to 1e-4:
       vid16         configs[2] at FULL width (48 channels, nBottleneck 4000), batchSize 4 of its 16;

@@ -120,12 +120,15 @@ def _load(tr, ref):
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("fuse,lazy,skip,batch_d", [(True, True, True, False), (False, False, False, False),
                                                     (True, True, True, True), (False, False, False, True)])
-def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle, hipb, planes_gate):
+def test_center_trainer_two_iterations(fuse, lazy, skip, batch_d, smooth, oracle, hipb, planes_gate, host):
     """batch_d: netD's real and fake passes as one batch of 2B with two BatchNorm groups — same oracle, same bars."""
     from video_filler_amd.trainers import CenterTrainer
+    if host == "cabi" and not fuse:
+        pytest.skip("the un-fused container exists for the mirror's own A/B only; vf_net always runs the fused plan")
     opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4, smooth=smooth)
     ref = oracle.CenterTrainer(opt, np.random.default_rng(1))
     tr = CenterTrainer(opt, fuse=fuse, lazy_zero=lazy, skip_dead_grads=skip)
+    assert tr.host == host and (host == "mirror") == (type(tr.netG).__name__ == "Sequential")
     tr.set_batch_d(batch_d)
     _load(tr, ref)
     assert len([m for m in tr.netG.leaves() if hasattr(m, "running_mean")]) == 9
@@ -169,7 +172,7 @@ def test_center_trainer_option_branches(variant, smooth, oracle, hipb, planes_ga
 @pytest.mark.parametrize("batch_d", [False, True])
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("variant", ["weighted", "nomask0_gdl", "wholeim", "logoNet", "withInit", "ext256"])
-def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb, planes_gate):
+def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb, planes_gate, host):
     from video_filler_amd.trainers import VidTrainer, build_netG
     if variant == "weighted":          # train_vid_weighted.lua defaults, predLen = 2
         opt = dict(nBottleneck=64, predLen=2)
@@ -192,6 +195,7 @@ def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb, plan
     opt["smooth"] = smooth
     ref = oracle.VidTrainer(opt, np.random.default_rng(2))
     tr = VidTrainer(opt)
+    assert tr.host == host and (host == "mirror") == (type(tr.netD).__name__ == "Sequential")
     tr.set_batch_d(batch_d)
     _load(tr, ref)
     if variant == "withInit":
@@ -223,7 +227,7 @@ def test_vid_trainer_two_iterations(variant, smooth, batch_d, oracle, hipb, plan
         _resync(ref, tr)
 
 
-def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hipb, planes_gate):
+def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hipb, planes_gate, host):
     """Nothing is carried over from the oracle: after the common start both sides run three whole iterations on their
     own parameters, Adam moments and BatchNorm running statistics.  Adam's first steps move a weight by up to one
     learning rate whatever the size of its gradient, and the sign of a gradient that is pure rounding noise (conv biases
@@ -265,7 +269,7 @@ def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hip
     import os
     os.makedirs("gpurun_out", exist_ok=True)
     report["kink_pin"] = dict(touched=ks.touched, checked=ks.checked, frac=ks.touched / max(ks.checked, 1), worst_near=ks.worst_near)
-    with open(os.path.join("gpurun_out", "drift_report_%s.json" % planes_gate), "w") as fh:
+    with open(os.path.join("gpurun_out", "drift_report_%s_%s.json" % (planes_gate, host)), "w") as fh:
         json.dump(report, fh)
     for k in ("errD", "errG", "errG_l2"):
         assert report[k] <= 5e-3, (k, report)
@@ -275,7 +279,7 @@ def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hip
     print("drift after 3 un-synchronised iterations (units of lr):", report)
 
 
-def test_graph_replay_matches_eager(oracle, hipb, planes_gate):
+def test_graph_replay_matches_eager(oracle, hipb, planes_gate, host):
     """A captured HIP graph of the iteration must walk the same trajectory as eager launches."""
     from video_filler_amd.trainers import CenterTrainer
     opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
@@ -336,7 +340,7 @@ def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb, planes_gate)
 
 @pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("kind", ["center", "vid"])
-def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hipb, planes_gate):
+def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hipb, planes_gate, host):
     """The data-parallel iteration (4 HIP graphs with RCCL all-reduce-average between them, G's gradient in two
     buckets, the tail one in flight during the encoder's backward) on a world of ONE rank must walk exactly the
     trajectory of the plain loop body: averaging over one rank is the identity.  The exchange is the C-ABI's
@@ -375,7 +379,7 @@ def test_phased_dp_step_over_rccl_matches_plain_step(kind, pipelined, oracle, hi
 
 
 @pytest.mark.parametrize("kind", ["center", "vid"])
-def test_captured_graph_sees_new_batches(kind, oracle, hipb, planes_gate):
+def test_captured_graph_sees_new_batches(kind, oracle, hipb, planes_gate, host):
     """set_batch() after capture() writes into the buffers the graph was captured with: replaying on a new batch
     equals eager steps on that batch (a graph that kept reading the first batch would fail this)."""
     from video_filler_amd.trainers import CenterTrainer, VidTrainer

@@ -123,7 +123,7 @@ class CNet(nn.Sequential):
         self._push("groups", self._groups, lambda v: lib.vf_net_set_batch_groups(self._net, v))
         self._push("train", bool(self.train), lambda v: lib.vf_net_training(self._net, 1 if v else 0))
         self._push("managed", bool(self._wp_managed), lambda v: lib.vf_net_set_weight_planes_managed(self._net, 1 if v else 0))
-        self._push("gate", (nn._PCONV_MIN_GFLOP, nn._PCONV_MIN_ROWS), lambda v: lib.vf_net_set_planes_gate(float(v[0]), int(v[1])), shared=True)
+        _lib.check(lib.vf_net_set_planes_gate(float(nn._PCONV_MIN_GFLOP), int(nn._PCONV_MIN_ROWS)))      # (process-wide on both sides)
         sync = self._sync_state()
         self._push("sync", sync, lambda v: lib.vf_net_set_sync_bn(self._net, get_backend().comm if v[0] > 1 else None, v[0], 1 if v[1] else 0))
         hook = nn.Sequential.act_hook
@@ -136,13 +136,10 @@ class CNet(nn.Sequential):
                 self._cb = None
         return lib
 
-    _shared_pushed = {}
-
-    def _push(self, key, value, fn, shared=False):
-        store = CNet._shared_pushed if shared else self._pushed
-        if store.get(key, None) != value:
+    def _push(self, key, value, fn):
+        if self._pushed.get(key, None) != value:
             _lib.check(fn(value))
-            store[key] = value
+            self._pushed[key] = value
 
     def _sync_state(self):
         bns = [m for m in self.leaves() if isinstance(m, nn.SpatialBatchNormalization)]

@@ -32,12 +32,14 @@ DEFAULT_OPT_VID = dict(batchSize=16, fineSize=128, nBottleneck=4000, nef=64, ngf
 # own), "cabi" = the library's own net object (vf_net_*, cnet.CNet: one C-ABI call per Torch7 method, the whole fast path inside
 # libvf_hip.so — what a Lua host gets through hipnn.Net).  Same kernels, same plan; nets with table modules (train.lua's option
 # branches) stay on the mirror under either setting.
-DEFAULT_HOST = os.environ.get("VF_HOST", "mirror")
+DEFAULT_HOST = os.environ.get("VF_HOST", "cabi")
 
 
 def _host_nets(host, netG, netD):
     host = host or DEFAULT_HOST
     assert host in ("mirror", "cabi"), host
+    if getattr(get_backend(), "name", "") != "hip-gfx950":
+        host = "mirror"        # (a test backend on the CPU: host logic only — vf_net lives in libvf_hip.so)
     if host == "cabi":
         from .cnet import adopt_if_chain
         return adopt_if_chain(netG), adopt_if_chain(netD), host
