@@ -329,7 +329,8 @@ def test_net_object_cut_walk_reshape_and_bound_storage(gate, oracle, hipb):
         assert 0 < k.value < n_plan and 0 < off.value < h.count
         h.ok(h.lib.vf_zero(h.ctx, C.c_void_p(h.g), h.count * 4))
         h.ok(h.lib.vf_net_zero_grad(h.net))
-        h.forward(x)
+        # (no second forward: it would take its statistics about the MOVED running mean and round differently; the walk itself
+        #  is repeatable from the saved state of the one forward above)
         mid = C.c_void_p()
         h.ok(h.lib.vf_net_backward_range(h.net, C.c_void_p(x.data_ptr()), C.c_void_p(gy.data_ptr()), -1, k.value, 1, C.byref(mid)))
         part = h.download(h.g, h.count)
@@ -349,6 +350,7 @@ def test_net_object_cut_walk_reshape_and_bound_storage(gate, oracle, hipb):
         # host-owned storage: copy the parameters out, bind, same forward bit for bit
         own = torch.from_numpy(h.download(h.p, h.count).copy()).to(h.dev)
         owng = torch.zeros_like(own)
+        h.ok(h.lib.vf_net_training(h.net, 0))       # (evaluate mode: a training forward moves the running mean its sums are shifted by)
         before = h.download(h.forward(xsd), want.size).copy()
         h.ok(h.lib.vf_net_bind_parameters(h.net, C.c_void_p(own.data_ptr()), C.c_void_p(owng.data_ptr()), own.numel()))
         np.testing.assert_array_equal(h.download(h.forward(xsd), want.size), before)

@@ -243,6 +243,7 @@ def test_three_iterations_without_resync_stay_within_the_drift_bound(oracle, hip
     tr = CenterTrainer(opt)
     _load(tr, ref)
     ks = KinkSync(oracle, [(ref.netG, tr.netG), (ref.netD, tr.netD)])
+    ks.near_tol = 2e-2      # nothing is re-synchronised here: from the second iteration on the two sides hold different weights
     sig = {"G": None, "D": None}
     for it in range(3):
         batch = oracle.synth_center_batch(3, np.random.default_rng(10 + it))
@@ -311,11 +312,12 @@ def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb, planes_gate)
     if kind == "center":
         opt = dict(nBottleneck=512, wtl2=0.999, overlapPred=4)
         batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)
-        mk = lambda: CenterTrainer(opt, seed=3)
+        mk = lambda: CenterTrainer(opt, seed=3, host="mirror")
     else:
         opt = dict(nBottleneck=512, predLen=2)
         batch = tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(4, np.random.default_rng(5), 6))
-        mk = lambda: VidTrainer(opt, seed=3)
+        mk = lambda: VidTrainer(opt, seed=3, host="mirror")
+    # (host="mirror": the split update joins a side stream in mid-forward, an experiment of the module-by-module host)
     a, b, c = mk(), mk(), mk()
     for t in (a, b, c):
         t.set_batch(*batch)
