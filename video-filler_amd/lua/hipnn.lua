@@ -69,17 +69,33 @@ int vf_conv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, co
 int vf_deconv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 typedef struct vf_layer_desc { int kind; int nin, nout; int k, stride, pad; int act; float slope; float eps, momentum; } vf_layer_desc;
 typedef struct vf_net vf_net;
+typedef struct vf_comm vf_comm;
 int vf_net_create(vf_ctx* ctx, vf_net** out, const vf_layer_desc* layers, int nlayers, int B, int C, int H, int W);
 int vf_net_destroy(vf_net* net);
+int vf_net_reshape(vf_net* net, int B, int C, int H, int W);
 int vf_net_parameters(vf_net* net, float** params, float** grads, int64_t* count);
+int vf_net_bind_parameters(vf_net* net, float* params, float* grads, int64_t count);
 int64_t vf_net_param_offset(const vf_net* net, int layer, int which, int64_t* length);
 int vf_net_bn_running(vf_net* net, int layer, float** running_mean, float** running_var);
+int vf_net_bind_bn_running(vf_net* net, int layer, float* running_mean, float* running_var);
 int vf_net_training(vf_net* net, int train);
 int vf_net_zero_grad(vf_net* net);
+int vf_net_zero_conv_biases(vf_net* net, vf_net* other);
 int vf_net_forward(vf_net* net, const float* x, const float** y);
 int vf_net_backward(vf_net* net, const float* x, const float* gy, const float** gx);
 int vf_net_update_grad_input(vf_net* net, const float* x, const float* gy, const float** gx);
+int vf_net_set_skip_input_grad(vf_net* net, int on);
+int vf_net_set_batch_groups(vf_net* net, int G);
+int vf_net_update_grad_input_group(vf_net* net, const float* x, const float* gy, int g, int G, const float** gx);
+int vf_net_plan_size(const vf_net* net);
+int vf_net_bucket_split(const vf_net* net, double frac, int* plan_index, int64_t* flat_offset);
+int vf_net_backward_range(vf_net* net, const float* x, const float* gy, int hi, int lo, int need_input_grad, const float** gx);
+int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);
+int vf_net_set_weight_planes_managed(vf_net* net, int on);
+int vf_net_refresh_weight_planes(vf_net* net);
 int vf_net_layer_output(vf_net* net, int layer, const float** y);
+int vf_net_layer_shape(const vf_net* net, int layer, int* B, int* C, int* H, int* W, int* Co, int* Ho, int* Wo);
+int vf_net_bind_output(vf_net* net, int layer, float* y);
 int vf_bce_fwd_bwd(vf_ctx* ctx, const float* x, float label0, float label1, int n_per_group, int groups, double* loss0, double* loss1, float* gx);
 int vf_trace_available(void);
 int vf_trace_enable(int on);
@@ -90,7 +106,6 @@ int vf_range_depth(void);
 int vf_wgrad_group_begin(vf_ctx* ctx);
 int vf_wgrad_group_end(vf_ctx* ctx);
 int vf_wgrad_group_abort(vf_ctx* ctx);
-typedef struct vf_comm vf_comm;
 int vf_comm_available(void);
 int vf_comm_unique_id(void* id128);
 int vf_comm_init(vf_comm** out, const void* id128, int world, int rank);
@@ -135,38 +150,149 @@ end
 function hipnn.setMfmaMode(mode) check(C.vf_ctx_set_mfma_mode(hipnn.ctx, mode)) end
 -- every weight gradient recorded between these two runs as one grouped launch (wrap net:backward with them)
 ----------------------------------------------------------------------------------------------------------------
--- hipnn.Net: a whole nn.Sequential as ONE library object (vf_net_*).  The simple route for a driver: build the layer list from
--- the Torch7 net (kinds / planes / kernel geometry as util.cudnn reads them, util.lua:117-119), copy weight / bias into the
--- flat buffer at vf_net_param_offset, then net:forward / :backward / :updateGradInput are one C call each.
+-- hipnn.Net: the documented host path.  util.cudnn(net) is where the reference puts a net on its GPU backend
+-- (util.lua:108-131, train.lua:245-258); hipnn.hip(net, B, C, H, W) is its counterpart: the chain of modules netG:add(...) /
+-- netD:add(...) built (train.lua:87-199) becomes ONE library object (vf_net_*) that runs the whole fast path inside
+-- libvf_hip.so — activations in their producer's epilogue, BatchNorm statistics out of the neighbouring GEMMs, operand planes
+-- handed from producer to consumer, grouped weight / bias gradients, netD's real + fake passes as one 2B batch — and every
+-- method the drivers call on a net is one C call.  The object keeps Torch7's protocol: :forward / :backward / :updateGradInput
+-- return tensors, .output / .gradInput are set, :getParameters() returns the two flat tensors (host-owned storage the library
+-- is bound to, so optim.adam and the checkpoint code keep working on them), :apply visits the original modules, whose
+-- weight / bias / running_mean / running_var become views of that storage.
+-- (The module-by-module classes further down remain for nets with table modules: train.lua's conditionAdv / noiseGen branches.)
 ----------------------------------------------------------------------------------------------------------------
 local KIND = { ['nn.SpatialConvolution'] = 1, ['nn.SpatialFullConvolution'] = 2, ['nn.SpatialBatchNormalization'] = 3,
                ['nn.LeakyReLU'] = 4, ['nn.ReLU'] = 4, ['nn.Tanh'] = 4, ['nn.Sigmoid'] = 4, ['nn.View'] = 5 }
 local ACTCODE = { ['nn.LeakyReLU'] = 1, ['nn.ReLU'] = 2, ['nn.Tanh'] = 3, ['nn.Sigmoid'] = 4 }
+local fptr          -- (defined below)
+local function flatten(seq, out)      -- nested nn.Sequential -> one module list, depth first (the order of getParameters())
+   for _, m in ipairs(seq.modules) do
+      if torch.type(m) == 'nn.Sequential' then flatten(m, out) else out[#out + 1] = m end
+   end
+   return out
+end
+local Net = {}
+Net.__index = Net
 function hipnn.Net(seq, B, Cc, H, W)
-   local n = #seq.modules
+   local mods = flatten(seq, {})
+   local n = #mods
    local d = ffi.new('vf_layer_desc[?]', n)
-   for i, m in ipairs(seq.modules) do
+   for i, m in ipairs(mods) do
       local t = torch.type(m)
       local e = d[i - 1]
-      e.kind = assert(KIND[t], 'hipnn.Net: unsupported module ' .. t)
+      e.kind = assert(KIND[t], 'hipnn.Net hosts chains of convolutions, BatchNorms, activations and views; got ' .. t)
       if e.kind <= 2 then e.nin, e.nout, e.k, e.stride, e.pad = m.nInputPlane, m.nOutputPlane, m.kW, m.dW, m.padW
       elseif e.kind == 3 then e.nout, e.eps, e.momentum = m.running_mean:size(1), m.eps, m.momentum
       elseif e.kind == 4 then e.act, e.slope = ACTCODE[t], m.negval or 0 end
    end
    local out = ffi.new('vf_net*[1]')
    check(C.vf_net_create(hipnn.ctx, out, d, n, B, Cc, H, W))
-   local net = { h = ffi.gc(out[0], C.vf_net_destroy) }
-   function net:forward(x) local y = ffi.new('const float*[1]'); check(C.vf_net_forward(self.h, fptr(x), y)); return y[0] end
-   function net:backward(x, gy) local g = ffi.new('const float*[1]'); check(C.vf_net_backward(self.h, fptr(x), fptr(gy), g)); return g[0] end
-   function net:updateGradInput(x, gy) local g = ffi.new('const float*[1]'); check(C.vf_net_update_grad_input(self.h, fptr(x), fptr(gy), g)); return g[0] end
-   function net:zeroGradParameters() check(C.vf_net_zero_grad(self.h)) end
-   function net:training() check(C.vf_net_training(self.h, 1)) end
-   function net:evaluate() check(C.vf_net_training(self.h, 0)) end
-   function net:getParameters()
-      local p, g, c = ffi.new('float*[1]'), ffi.new('float*[1]'), ffi.new('int64_t[1]')
-      check(C.vf_net_parameters(self.h, p, g, c)); return p[0], g[0], tonumber(c[0])
+   local self = setmetatable({ h = ffi.gc(out[0], C.vf_net_destroy), modules = mods, seq = seq, B = B, train = true }, Net)
+   -- host-owned flat storage in the library's layout; the modules' parameters move into it (channels-last inside a 4-D weight)
+   local p, g, c = ffi.new('float*[1]'), ffi.new('float*[1]'), ffi.new('int64_t[1]')
+   check(C.vf_net_parameters(self.h, p, g, c))
+   self.count = tonumber(c[0])
+   self.flat, self.gflat = hipnn.Tensor(self.count):zero(), hipnn.Tensor(self.count):zero()
+   check(C.vf_net_bind_parameters(self.h, fptr(self.flat), fptr(self.gflat), self.count))
+   local len = ffi.new('int64_t[1]')
+   for i, m in ipairs(mods) do
+      if m.weight then
+         for which, name in ipairs({ 'weight', 'bias' }) do
+            local off = tonumber(C.vf_net_param_offset(self.h, i - 1, which - 1, len))
+            local view = hipnn.viewOf(self.flat, off, m[name])          -- same logical sizes, channels-last strides for 4-D
+            if m[name]:dim() == 4 then hipnn.copyParameterNCHW(view, m[name]) else view:copy(m[name]) end
+            m[name] = view
+            m['grad' .. name:sub(1, 1):upper() .. name:sub(2)] = hipnn.viewOf(self.gflat, off, m[name])
+         end
+      end
+      if m.running_mean then
+         local rm, rv = hipnn.Tensor(m.running_mean:size(1)):copy(m.running_mean), hipnn.Tensor(m.running_var:size(1)):copy(m.running_var)
+         check(C.vf_net_bind_bn_running(self.h, i - 1, fptr(rm), fptr(rv)))
+         m.running_mean, m.running_var = rm, rv
+      end
    end
-   return net
+   check(C.vf_net_set_weight_planes_managed(self.h, 0))     -- refreshed at every call unless the driver takes over (:manageWeightPlanes)
+   return self
+end
+-- util.cudnn's counterpart: `netD = hipnn.hip(netD, opt.batchSize, nc, opt.fineSize, opt.fineSize)` (train.lua:250-251)
+function hipnn.hip(net, B, Cc, H, W) return hipnn.Net(net, B, Cc, H, W) end
+local function wrap(self, ptr, layer, isInput)     -- a device pointer of the library as a tensor of the right logical shape
+   if ptr == nil then return nil end
+   local d = {}
+   for i = 1, 7 do d[i] = ffi.new('int[1]') end
+   check(C.vf_net_layer_shape(self.h, layer, d[1], d[2], d[3], d[4], d[5], d[6], d[7]))
+   local Bn = d[1][0]
+   if isInput then return hipnn.wrapNHWC(ptr, Bn, d[2][0], d[3][0], d[4][0]) end
+   return hipnn.wrapNHWC(ptr, Bn, d[5][0], d[6][0], d[7][0])
+end
+function Net:lastComputing()       -- index (0-based) of the last module that is not an nn.View
+   for i = #self.modules, 1, -1 do if torch.type(self.modules[i]) ~= 'nn.View' then return i - 1 end end
+   return 0
+end
+function Net:forward(x)
+   if x:size(1) ~= self.B then check(C.vf_net_reshape(self.h, x:size(1), x:size(2), x:size(3), x:size(4))); self.B = x:size(1) end
+   local y = ffi.new('const float*[1]')
+   check(C.vf_net_forward(self.h, fptr(x), y))
+   self.output = wrap(self, y[0], self:lastComputing(), false)
+   local tail = self.modules[#self.modules]
+   if torch.type(tail) == 'nn.View' then self.output = self.output:view(self.B, -1) end       -- nn.View(1):setNumInputDims(3)
+   return self.output
+end
+Net.updateOutput = Net.forward
+function Net:backward(x, gy)
+   local g = ffi.new('const float*[1]')
+   check(C.vf_net_backward(self.h, fptr(x), fptr(gy), g))
+   self.gradInput = wrap(self, g[0], 0, true)         -- nil after :skipInputGrad(true)
+   return self.gradInput
+end
+function Net:updateGradInput(x, gy)                   -- train.lua:366
+   local g = ffi.new('const float*[1]')
+   check(C.vf_net_update_grad_input(self.h, fptr(x), fptr(gy), g))
+   self.gradInput = wrap(self, g[0], 0, true)
+   return self.gradInput
+end
+-- netD's two passes of fDx as ONE batch [real; fake] (train.lua:331-349): net:setBatchGroups(2), forward / backward on the 2B
+-- tensor, and in fGx the pass over the fake half only: net:updateGradInputGroup(fake, df_do, 1, 2)  (groups count from 0)
+function Net:setBatchGroups(G) check(C.vf_net_set_batch_groups(self.h, G)); return self end
+function Net:updateGradInputGroup(x, gy, g, G)
+   local o = ffi.new('const float*[1]')
+   check(C.vf_net_update_grad_input_group(self.h, fptr(x), fptr(gy), g, G, o))
+   local t = wrap(self, o[0], 0, true)
+   return t and t:narrow(1, 1, self.B / G) or nil
+end
+function Net:skipInputGrad(on) check(C.vf_net_set_skip_input_grad(self.h, on and 1 or 0)); return self end
+function Net:zeroGradParameters() check(C.vf_net_zero_grad(self.h)) end
+function Net:training() self.train = true; check(C.vf_net_training(self.h, 1)); return self end
+function Net:evaluate() self.train = false; check(C.vf_net_training(self.h, 0)); return self end
+function Net:getParameters() return self.flat, self.gflat end            -- train.lua:262-263
+function Net:apply(fn) fn(self); for _, m in ipairs(self.modules) do fn(m) end; return self end      -- train.lua:150,201
+-- `netD:apply(function(m) if torch.type(m):find('Convolution') then m.bias:zero() end end)` of both closures (train.lua:279-280)
+-- as one launch; `other`: the second net of the sweep
+function Net:zeroConvBiases(other) check(C.vf_net_zero_conv_biases(self.h, other and other.h or nil)) end
+-- weight planes: by default refreshed at the start of every call; a driver that calls :refreshWeightPlanes() after each
+-- optim.adam (and after loading a checkpoint) switches that off with :manageWeightPlanes(true): one launch per update
+function Net:manageWeightPlanes(on) check(C.vf_net_set_weight_planes_managed(self.h, on and 1 or 0)); return self end
+function Net:refreshWeightPlanes() check(C.vf_net_refresh_weight_planes(self.h)) end
+-- data parallel: the walk cut where the big gradient bucket is complete (hipnn.allreduceAvgAsync on gflat[offset, end) meanwhile)
+function Net:bucketSplit(frac)
+   local k, off = ffi.new('int[1]'), ffi.new('int64_t[1]')
+   check(C.vf_net_bucket_split(self.h, frac or 0.9, k, off))
+   return k[0], tonumber(off[0])
+end
+function Net:backwardRange(x, gyPtr, hi, lo, needInputGrad)     -- gyPtr: a tensor, or the pointer a previous range returned
+   local g = ffi.new('const float*[1]')
+   local gp = type(gyPtr) == 'cdata' and gyPtr or fptr(gyPtr)
+   check(C.vf_net_backward_range(self.h, fptr(x), gp, hi, lo, needInputGrad and 1 or 0, g))
+   return g[0]
+end
+function Net:syncBatchNorm(world) check(C.vf_net_set_sync_bn(self.h, hipnn.comm, world, 0)); return self end
+function Net:bindOutput(layer, tensor) check(C.vf_net_bind_output(self.h, layer, tensor and fptr(tensor) or nil)) end
+function Net:layerOutput(i)          -- net.modules[i].output (1-based like Torch7)
+   local y = ffi.new('const float*[1]')
+   check(C.vf_net_layer_output(self.h, i - 1, y))
+   local j = i
+   while j > 1 and (KIND[torch.type(self.modules[j])] or 0) >= 4 do j = j - 1 end
+   return wrap(self, y[0], j - 1, false)
 end
 -- roctx ranges (rocprofv3 --marker-trace): hipnn.range('fDx', function() ... end)
 function hipnn.range(name, fn) C.vf_range_push(name); local ok, err = pcall(fn); C.vf_range_pop(); if not ok then error(err, 0) end end
@@ -174,7 +300,7 @@ function hipnn.beginBackward() check(C.vf_wgrad_group_begin(hipnn.ctx)) end
 function hipnn.endBackward() check(C.vf_wgrad_group_end(hipnn.ctx)) end
 function hipnn.abortBackward() check(C.vf_wgrad_group_abort(hipnn.ctx)) end   -- after an error inside a backward walk
 
-local function fptr(t) return ffi.cast('float*', t:data()) end
+fptr = function(t) return ffi.cast('float*', t:data()) end
 
 ----------------------------------------------------------------------------------------------------------------
 -- Data parallel (one th process per GPU; the reference itself is single-device, train.lua:42).  Rank 0 writes the
@@ -524,6 +650,33 @@ end
 function hipnn.resizeNHWC(t, B, Cc, H, W)     -- logical B x C x H x W over [B][H][W][C]
    if t and getmetatable(t) == DT and t.n == B * Cc * H * W and t.sizes[2] == Cc and t.sizes[3] == H then return t end
    return hipnn.Tensor(B, H, W, Cc):permute(1, 4, 2, 3)
+end
+-- non-owning tensors over memory that belongs to someone else (the library's net object, a flat parameter storage)
+local function aliasTensor(ptr, n, sizes, strides, keep)
+   return setmetatable({ ptr = ptr, elemSize = 4, n = n, sizes = sizes, strides = strides, base = keep }, DT)
+end
+function hipnn.wrapNHWC(ptr, B, Cc, H, W)     -- logical B x C x H x W over the library's [B][H][W][C] buffer
+   return aliasTensor(ffi.cast('void*', ptr), B * Cc * H * W, { B, Cc, H, W }, { H * W * Cc, 1, W * Cc, Cc })
+end
+function hipnn.viewOf(flat, off, like)        -- `like`'s logical sizes over flat[off ...]: channels-last strides for a 4-D weight
+   local sizes, n = {}, 1
+   for i = 1, like:dim() do sizes[i] = like:size(i); n = n * sizes[i] end
+   local strides
+   if #sizes == 4 then strides = { sizes[3] * sizes[4] * sizes[2], 1, sizes[4] * sizes[2], sizes[2] }
+   else strides = { 1 } end
+   return aliasTensor(ffi.cast('void*', ffi.cast('float*', flat.ptr) + off), n, sizes, strides, flat)
+end
+function DT:view(a, b)            -- (B, -1): the rows of a [B][...] buffer (nn.View(1):setNumInputDims(3) on B x 1 x 1 x 1)
+   local rest = self.n / a
+   assert(b == -1 or b == rest)
+   return aliasTensor(self.ptr, self.n, { a, rest }, { rest, 1 }, self)
+end
+function DT:narrow(dim, first, len)   -- leading-dimension slices only (batch groups)
+   assert(dim == 1)
+   local per = self.n / self.sizes[1]
+   local sizes = { len }
+   for i = 2, #self.sizes do sizes[i] = self.sizes[i] end
+   return aliasTensor(ffi.cast('void*', ffi.cast('float*', self.ptr) + (first - 1) * per), len * per, sizes, self.strides, self)
 end
 function hipnn.resizeLike(t, like)
    if t and getmetatable(t) == DT and t.n == like.n then t.sizes, t.strides = like.sizes, like.strides; return t end
