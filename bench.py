@@ -61,8 +61,14 @@ def main():
                     "extension opt.ext256 (the reference's nets fail at that size: one more stride-2 stage in netD and around "
                     "netG's bottleneck)")
     ap.add_argument("--force-dist", action="store_true", help="N=1: run the data-parallel path (RCCL init + all-reduce) anyway")
-    ap.add_argument("--no-pipeline", action="store_true", help="N>1: keep G's gradient exchange and Adam(G) inside the iteration "
-                    "(default: they run behind the next iteration's netD real pass)")
+    ap.add_argument("--pipeline", action="store_true", help="N>1: the pipelined data-parallel step: G's gradient exchange and Adam(G) run "
+                    "behind the NEXT iteration's netD real pass — which then has to stay a separate pass (no 2B netD batching: "
+                    "-26 %% per GPU before any communication, VERDICT r2).  Default: the un-pipelined step with the single-device "
+                    "iteration's batching; G's tail bucket travels beside the encoder backward")
+    ap.add_argument("--no-pipeline", action="store_true", help="(default now; kept so that older command lines still parse)")
+    ap.add_argument("--dp-graph", default="phased", choices=["phased", "one"], help="N>1 graph form: phased = four HIP graphs with the "
+                    "collectives launched between them from the host (default); one = the whole iteration INCLUDING the collectives "
+                    "as one HIP graph (vf_comm_* on its own stream, recorded as a fork / join) — needs --comm cabi/auto to succeed")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --share-gpu rehearses the N>1 control "
                     "flow with several ranks on ONE GPU (not a measurement)")
     ap.add_argument("--shard-adam", action="store_true", help="N > 1: reduce-scatter G's gradient, Adam on 1/N of the parameters per "
@@ -187,13 +193,20 @@ def main():
     if args.no_batch_d and tr.batch_d:
         tr.set_batch_d(False)
     use_graph = not args.no_graph and not (dp and args.sync_bn)
-    pipelined = dp and not args.no_pipeline and not args.sync_bn and not args.shard_adam
+    pipelined = dp and args.pipeline and not args.sync_bn and not args.shard_adam
+    one_graph = dp and use_graph and args.dp_graph == "one" and not pipelined and B.comm is not None
     if dp:
-        if use_graph:
-            tr.capture_phased(warmup=max(args.warmup, 2), pipelined=pipelined)
+        if pipelined and tr.batch_d:
+            tr.set_batch_d(False)
+        if one_graph:
+            tr.capture_dp(warmup=max(args.warmup, 2))
+            run = tr.replay
         else:
-            tr._pipelined = pipelined
-        run = tr.step_pipelined if pipelined else tr.step_phased
+            if use_graph:
+                tr.capture_phased(warmup=max(args.warmup, 2), pipelined=pipelined)
+            else:
+                tr._pipelined = pipelined
+            run = tr.step_pipelined if pipelined else tr.step_phased
         for _ in range(max(args.warmup, 10) if use_graph else args.warmup):
             run()
     elif use_graph:
@@ -413,7 +426,7 @@ def main():
             "dtype": {"f32": "f32", "f32_3xbf16": "f32",
                       "bf16": "bf16 MFMA operands, f32 accumulate/BN/criteria/Adam (opt-in mode)"}[args.mfma],
             "data": "synthetic",
-            "config": {"workload": wl, "global_batch": world * args.batch, "launch": (("hipGraph x4 + bucketed RCCL all-reduce between; " + ("G buckets in flight during the encoder backward and the next iteration's netD real pass" if pipelined else "G tail bucket in flight during the encoder backward")) if dp else "hipGraph") if use_graph else "eager", "streams": 3 if args.overlap else 1,
+            "config": {"workload": wl, "global_batch": world * args.batch, "launch": ((("one hipGraph with the bucketed all-reduces recorded in it; " if one_graph else "hipGraph x4 + bucketed RCCL all-reduce between; ") + ("G buckets in flight during the encoder backward and the next iteration's netD real pass" if pipelined else "G tail bucket in flight during the encoder backward")) if dp else "hipGraph") if use_graph else "eager", "streams": 3 if args.overlap else 1,
                        "mfma": {"f32_3xbf16": "fp32 operands split exactly into 3 bf16 planes, 6 cross terms on v_mfma_f32_32x32x16_bf16, "
                                               "f32 accumulate (fp32-grade: same parity tolerances as native)",
                                 "f32": "native v_mfma_f32_32x32x2_f32", "bf16": "operands rounded to bf16"}[args.mfma],

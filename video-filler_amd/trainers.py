@@ -270,8 +270,11 @@ class _TrainerBase:
         self._cat = self._cat_df = None
         self._cat_real = None        # (buffer, batch version) the real half of _cat was filled from
         self._batch_ver = 0
-        if world == 1 and os.environ.get("VF_NO_BATCH_D") != "1":
-            self.set_batch_d(True)   # single device: measured +5 % on train.lua's nets
+        if not (world > 1 and sync_bn) and os.environ.get("VF_NO_BATCH_D") != "1":
+            # measured +5 % on train.lua's nets; data parallel too, except with SyncBN (whose statistics are
+            # all-reduced per layer and pass, one group at a time) and in the pipelined step (step_pipelined switches it off:
+            # there netD's separate real pass is the window behind which G's exchange completes)
+            self.set_batch_d(True)
 
     @property
     def force_comm(self):
@@ -280,8 +283,6 @@ class _TrainerBase:
     @force_comm.setter
     def force_comm(self, v):
         self._force_comm = bool(v)
-        if v and self.batch_d:       # the data-parallel iteration keeps netD's real pass separate: it is the window
-            self.set_batch_d(False)  # behind which G's gradient exchange of the previous iteration completes
 
     def _comm_on(self):
         return self.world > 1 or self.force_comm
@@ -296,7 +297,8 @@ class _TrainerBase:
     #    BatchNorm keeps the two halves apart (nn.SpatialBatchNormalization.groups = 2: statistics, running averages
     #    and backward sums per half, real first).  Twice the rows per GEMM launch and half the launches for netD.
     def set_batch_d(self, on=True):
-        assert not (on and self._comm_on()), "batch_d is the single-device iteration"
+        assert not (on and self._pipelined), "the pipelined data-parallel step keeps netD's real pass separate"
+        assert not (on and any(getattr(m, "sync_world", 1) > 1 for m in self.netD.leaves())), "batch_d and SyncBN do not combine"
         assert self._graph is None and self._graphs is None, "set_batch_d before capture()"
         self.batch_d = bool(on)
         self.netD.setBatchGroups(2 if on else 1)
@@ -584,6 +586,8 @@ class _TrainerBase:
         """Four graphs (phases A, B, B2, C — or A1, A2, B, B2 when pipelined) with the RCCL all-reduces launched between
         them.  SyncBN puts collectives inside the phases, so it runs eagerly instead."""
         B = get_backend()
+        if pipelined and self.batch_d:
+            self.set_batch_d(False)
         self._pipelined = bool(pipelined)
         step = self.step_pipelined if pipelined else self.step_phased
         for _ in range(max(warmup, 1)):
@@ -612,6 +616,28 @@ class _TrainerBase:
             self._pending_g = True
             self._inflight = []
         return self._graphs
+
+    def capture_dp(self, warmup=3):
+        """The un-pipelined data-parallel iteration (step_phased: A | all-reduce D | B | all-reduce G tail ∥ B2 | all-reduce G
+        head | C) as ONE HIP graph, collectives included: vf_comm_* enqueues them on the communicator's stream behind an event
+        of the compute stream and joins with another, which a capture records as a fork / join of the graph — so the tail
+        bucket still travels beside the encoder's backward kernels, and nothing is launched from the host per iteration.
+        Needs the C-ABI exchange (backend.comm); replay() runs it."""
+        B = get_backend()
+        assert self._comm_on() and getattr(B, "comm", None) is not None, "capture_dp: attach a communicator first (backend.init_comm)"
+        assert not self._pipelined and not any(getattr(m, "sync_world", 1) > 1 for m in self.netD.leaves())
+        for _ in range(max(warmup, 1)):
+            self.step_phased()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            B.use_current_stream()
+            self.step_phased()
+        B.use_current_stream()
+        self._graph = g
+        self._graph_stale = False
+        self._pending_g = False
+        return g
 
     def replay(self):
         assert not self._graph_stale, "flush() was called: the captured graph would apply Adam(G) twice; capture() again"
@@ -713,13 +739,14 @@ class CenterTrainer(_TrainerBase):
                     self.netG.zeroConvBiases()
                 fake = self._netG_forward()
         if self.batch_d:
-            assert not self._comm_on() and not self._pipelined
+            assert not self._pipelined
             if fake is None:
                 fake = self._pending_then_forward(self._netG_forward)
             else:
                 self.side_g.join()
             self.input_center = fake
             self.errD = self._netD_both(self._real_center, fake)
+            self._allreduce_avg(self.gradParametersD)
             return
         # train with real (input_center:copy(real_center): the centre crop already sits in a device buffer)
         self.input_center = self._real_center
@@ -859,7 +886,7 @@ class VidTrainer(_TrainerBase):
                     self.netG.zeroConvBiases()
                 fake = self.netG.forward(self._g_in())
         if self.batch_d:
-            assert not self._comm_on() and not self._pipelined
+            assert not self._pipelined
             if fake is None:
                 fake = self._pending_then_forward(lambda **kw: self.netG.forward(self._g_in(), **kw))
             else:
@@ -870,6 +897,7 @@ class VidTrainer(_TrainerBase):
             else:
                 self.input_inpainted = fake
             self.errD = self._netD_both(self.input_real, self.input_inpainted)
+            self._allreduce_avg(self.gradParametersD)
             return
         label = self.real_label
         output = self.netD.forward(self.input_real)
