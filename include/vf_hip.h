@@ -340,6 +340,12 @@ int vf_wgrad_group_end(vf_ctx* ctx);
 /* Drop an open group without launching anything (a host-side error cut the backward walk short): the recorded GEMMs are
  * discarded and the context is back to immediate launches.  No-op when no group is open. */
 int vf_wgrad_group_abort(vf_ctx* ctx);
+/* Data parallel: a walk whose weight gradients leave in two launches, both at its END (a group launched in the middle of the
+ * data-gradient chain slowed the passes behind it by 20-40 %: DESIGN.md 8).  vf_wgrad_group_count: gradients recorded so far (the
+ * host reads it when the walk passes the bucket boundary); vf_wgrad_group_end_partial(count): launch the first `count` recorded
+ * ones — the finished bucket, whose exchange can start — and keep the group open; vf_wgrad_group_end launches the rest. */
+int vf_wgrad_group_count(vf_ctx* ctx, int* count);
+int vf_wgrad_group_end_partial(vf_ctx* ctx, int count);
 
 /* ---- every conv bias gradient of one backward walk in two launches ----------------------------------------------
  * gradBias = sum over pixels of gradOutput (THNN accGradParameters) is not needed before optim.adam, and each layer's
@@ -463,6 +469,11 @@ int vf_net_update_grad_input_group(vf_net* net, const float* x, const float* gy,
 int vf_net_plan_size(const vf_net* net);
 int vf_net_bucket_split(const vf_net* net, double frac, int* plan_index, int64_t* flat_offset);
 int vf_net_backward_range(vf_net* net, const float* x, const float* gy, int hi, int lo, int need_input_grad, const float** gx);
+/* the same cut without interrupting the data-gradient chain: vf_net_backward_split walks the WHOLE net, then launches the weight
+ * and bias gradients of plan entries >= k only (flat gradient [offset, end) final: start its exchange); vf_net_backward_finish
+ * launches the gradients of the entries below k.  Nothing else may record weight gradients on the context in between. */
+int vf_net_backward_split(vf_net* net, const float* x, const float* gy, int k, int need_input_grad, const float** gx);
+int vf_net_backward_finish(vf_net* net);
 /* SyncBN: BatchNorm sums all-reduced over `comm` (world ranks; statistics of the global batch).  force: take that path at world 1
  * too.  comm NULL / world 1 / force 0: device-local statistics. */
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);

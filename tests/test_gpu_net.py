@@ -339,6 +339,23 @@ def test_net_object_cut_walk_reshape_and_bound_storage(gate, oracle, hipb):
         h.ok(h.lib.vf_net_backward_range(h.net, C.c_void_p(x.data_ptr()), mid, k.value, 0, 1, C.byref(gxp)))
         np.testing.assert_array_equal(h.download(h.g, h.count), full)
         np.testing.assert_array_equal(h.download(gxp.value, int(np.prod(shape))), gx_full)
+        # the same cut WITHOUT interrupting the data-gradient chain: one walk, the tail bucket's gradients at its end, the rest
+        # at vf_net_backward_finish (what the data-parallel step runs)
+        h.ok(h.lib.vf_zero(h.ctx, C.c_void_p(h.g), h.count * 4))
+        h.ok(h.lib.vf_net_zero_grad(h.net))
+        h.ok(h.lib.vf_net_backward_split(h.net, C.c_void_p(x.data_ptr()), C.c_void_p(gy.data_ptr()), k.value, 1, C.byref(gxp)))
+        part = h.download(h.g, h.count)
+        np.testing.assert_array_equal(part[off.value:], full[off.value:])
+        for i, m in enumerate(h.mods):       # below the cut: BatchNorm gains / shifts are the walk's own, conv gradients still pending
+            if type(m).__name__ in ("SpatialConvolution", "SpatialFullConvolution"):
+                ln = C.c_int64()
+                o = h.lib.vf_net_param_offset(h.net, i, 0, C.byref(ln))
+                if o + ln.value <= off.value:
+                    assert np.all(part[o:o + ln.value] == 0), "a head-bucket weight gradient was launched before vf_net_backward_finish"
+        np.testing.assert_array_equal(h.download(gxp.value, int(np.prod(shape))), gx_full)
+        assert h.lib.vf_net_backward(h.net, C.c_void_p(x.data_ptr()), C.c_void_p(gy.data_ptr()), C.byref(mid)) != 0      # pending
+        h.ok(h.lib.vf_net_backward_finish(h.net))
+        np.testing.assert_array_equal(h.download(h.g, h.count), full)
         # reshape: another batch size, same parameters -> the oracle's forward on that batch
         small = (2,) + shape[1:]
         h.ok(h.lib.vf_net_reshape(h.net, *small))

@@ -133,6 +133,8 @@ SIGNATURES = {
     "vf_net_plan_size": (i32, [vp]),
     "vf_net_bucket_split": (i32, [vp, f64, C.POINTER(i32), C.POINTER(i64)]),
     "vf_net_backward_range": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]),
+    "vf_net_backward_split": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp)]),
+    "vf_net_backward_finish": (i32, [vp]),
     "vf_net_set_sync_bn": (i32, [vp, vp, i32, i32]),
     "vf_net_set_weight_planes_managed": (i32, [vp, i32]),
     "vf_net_refresh_weight_planes": (i32, [vp]),
@@ -145,6 +147,8 @@ SIGNATURES = {
     "vf_range_pop": (i32, []),
     "vf_mark": (i32, [C.c_char_p]),
     "vf_range_depth": (i32, []),
+    "vf_wgrad_group_count": (i32, [vp, C.POINTER(i32)]),
+    "vf_wgrad_group_end_partial": (i32, [vp, i32]),
     "vf_prof_begin": (i32, [vp]),
     "vf_prof_end": (i32, [vp]),
     "vf_prof_count": (i32, []),

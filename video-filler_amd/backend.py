@@ -423,6 +423,14 @@ class HipBackend:
     def wgrad_group_abort(self):
         self._c("vf_wgrad_group_abort")
 
+    def wgrad_group_count(self):
+        n = C.c_int(0)
+        self._c("vf_wgrad_group_count", C.byref(n))
+        return n.value
+
+    def wgrad_group_end_partial(self, count):
+        self._c("vf_wgrad_group_end_partial", int(count))
+
     # ---- all conv bias gradients of one backward walk in two launches (vf_bias_grad_multi)
     def bias_grad_multi(self, items):
         """items: [(gradOutput B x C x H x W channels-last, gradBias [C], beta)], C % 4 == 0.  The descriptor table is built

@@ -206,7 +206,11 @@ class CNet(nn.Sequential):
         Bn, Cc, H, W = [d.value for d in dims[:4]]
         return Bn, Cc, H, W
 
-    def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0, group=None):
+    def backward_finish(self):
+        if self._net is not None:
+            _lib.check(_lib.load().vf_net_backward_finish(self._net))
+
+    def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0, group=None, defer_cut=None):
         assert self._net is not None, "backward before forward"
         lib = _lib.load()
         x = to_nhwc(input)
@@ -218,6 +222,9 @@ class CNet(nn.Sequential):
         if group is not None:
             assert not want_gp and hi is None and lo == 0
             self._call(lib.vf_net_update_grad_input_group, self._net, xp, gp, group[0], group[1], C.byref(gxp))
+        elif want_gp and defer_cut is not None:
+            assert hi is None and lo == 0
+            self._call(lib.vf_net_backward_split, self._net, xp, gp, int(defer_cut), 1 if need_input_grad else 0, C.byref(gxp))
         elif want_gp:
             self._call(lib.vf_net_backward_range, self._net, xp, gp, -1 if hi is None else hi, lo, 1 if need_input_grad else 0, C.byref(gxp))
         else:

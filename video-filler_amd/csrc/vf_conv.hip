@@ -1912,6 +1912,34 @@ VF_API int vf_wgrad_group_end(vf_ctx* ctx) {
   return wg_flush(ctx);
 }
 
+// weight gradients recorded so far in the open group (not yet launched)
+VF_API int vf_wgrad_group_count(vf_ctx* ctx, int* count) {
+  VF_REQUIRE(count != nullptr, "vf_wgrad_group_count: NULL");
+  *count = (ctx->wg_active && ctx->wg_rec) ? (int)((WgRecorder*)ctx->wg_rec)->recs.size() : 0;
+  return 0;
+}
+// launch the FIRST `count` recorded weight gradients (record order = walk order: the layers nearest the net's output) as one
+// group and keep the group open with the rest still recorded: a data-parallel host starts the exchange of the finished bucket
+// and then ends the group — both launches sit at the END of the backward walk, none in the middle of its data-gradient chain
+VF_API int vf_wgrad_group_end_partial(vf_ctx* ctx, int count) {
+  VF_REQUIRE(ctx->wg_active, "vf_wgrad_group_end_partial: no group is open");
+  WgRecorder* R = (WgRecorder*)ctx->wg_rec;
+  if (!R || R->recs.empty() || count <= 0) return 0;
+  if (count >= (int)R->recs.size()) {
+    const size_t used = R->ws_used;
+    const int rc = wg_flush(ctx);
+    R->ws_used = used;      // (later records must not reuse slab regions a launch in flight still reads)
+    return rc;
+  }
+  std::vector<WgRec> rest(R->recs.begin() + count, R->recs.end());
+  R->recs.resize((size_t)count);
+  const size_t used = R->ws_used;
+  const int rc = wg_flush(ctx);
+  R->recs = rest;
+  R->ws_used = used;
+  return rc;
+}
+
 int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float* dW, int K, int Nu, int Ncols, float beta);  // vf_wgrad_small.hip
 static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, int Hl, int Wl, int Nu, int Hv, int Wv,
                  int Cv, int stride, int pad, float beta, int ntaps = 16, const void* Up = nullptr, const void* Vp = nullptr) {

@@ -149,6 +149,8 @@ struct vf_net {
     const float *base, *other_base;      // the flat buffers the offsets were computed between
   };
   std::map<const vf_net*, BothTable> both_tables;
+  bool split_pending = false;      // vf_net_backward_split ran: the gradients of the entries below the cut are still recorded
+  std::string pending_bias;        // (their deferred bias gradients, as a byte image of Deferred[])
   std::vector<void*> owned;        // parameter-lifetime allocations
   std::vector<void*> act_owned;    // shape-lifetime allocations (freed by vf_net_reshape)
 };
@@ -459,14 +461,19 @@ int bias_grad_flush(vf_net* n, const std::vector<Deferred>& items) {
 
 // Backward over plan entries hi-1 .. lo.  gi >= 0: the pass covers batch group gi of the G the last forward ran
 // concatenated — saved activations are sliced to that group's samples; x_in / gy hold that group only.
+// defer_cut >= 0: one uninterrupted walk; the gradients of entries >= defer_cut are launched at its end, the rest stay recorded
+// (vf_net_backward_finish)
 int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** gx_out, bool want_gp, bool need_input_grad, int hi,
-                  int lo, int gi, int G) {
+                  int lo, int gi, int G, int defer_cut = -1) {
   vf_ctx* ctx = n->ctx;
   const int np = (int)n->plan.size();
   if (hi < 0 || hi > np) hi = np;
   VF_REQUIRE(lo >= 0 && lo <= hi, "vf_net backward: bad plan range [%d, %d)", lo, hi);
   VF_REQUIRE(gi < 0 || (!want_gp && G >= 1 && gi < G && n->B % G == 0), "vf_net: bad batch group %d of %d", gi, G);
+  VF_REQUIRE(!(want_gp && n->split_pending), "vf_net: a split backward is pending — call vf_net_backward_finish first");
   const int Bn = gi >= 0 ? n->B / G : n->B;
+  int cut_wg = -1;
+  size_t cut_bias = 0;
   const float* g = gy;
   const void* g_pl = nullptr;
   std::vector<Deferred> deferred;
@@ -480,6 +487,10 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
   if (want_gp && (rc = vf_wgrad_group_begin(ctx))) return rc;
   auto slice = [&](const float* p, int64_t per_sample) { return (gi >= 0 && p) ? p + (int64_t)gi * Bn * per_sample : p; };
   for (int idx = hi - 1; idx >= lo && !rc; --idx) {
+    if (want_gp && defer_cut >= 0 && idx == defer_cut - 1) {      // everything recorded so far belongs to the finished bucket
+      if ((rc = vf_wgrad_group_count(ctx, &cut_wg))) break;
+      cut_bias = deferred.size();
+    }
     const Entry& e = n->plan[idx];
     Layer& l = n->L[e.main];
     const float* x = idx == 0 ? x_in : slice(entry_out(n, idx - 1, nullptr), (int64_t)l.H * l.W * l.C);
@@ -572,8 +583,16 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
       (void)vf_wgrad_group_abort(ctx);      // a failure in mid-walk must not leave the group open
       return rc;
     }
-    if ((rc = vf_wgrad_group_end(ctx))) return rc;
-    if ((rc = bias_grad_flush(n, deferred))) return rc;
+    if (defer_cut >= 0 && cut_wg >= 0) {
+      if ((rc = vf_wgrad_group_end_partial(ctx, cut_wg))) return rc;
+      std::vector<Deferred> first(deferred.begin(), deferred.begin() + cut_bias);
+      if ((rc = bias_grad_flush(n, first))) return rc;
+      n->pending_bias.assign((const char*)(deferred.data() + cut_bias), (deferred.size() - cut_bias) * sizeof(Deferred));
+      n->split_pending = true;
+    } else {
+      if ((rc = vf_wgrad_group_end(ctx))) return rc;
+      if ((rc = bias_grad_flush(n, deferred))) return rc;
+    }
   }
   if (rc) return rc;
   n->act_done_at = act_done ? lo : -1;      // a partial walk resumes at `lo`
@@ -1065,6 +1084,20 @@ VF_API int vf_net_backward(vf_net* n, const float* x, const float* gy, const flo
 VF_API int vf_net_backward_range(vf_net* n, const float* x, const float* gy, int hi, int lo, int need_input_grad, const float** gx) {
   VF_REQUIRE(n && x && gy, "vf_net_backward_range: NULL argument");
   return net_walk_back(n, x, gy, gx, true, need_input_grad != 0, hi, lo, -1, 1);
+}
+VF_API int vf_net_backward_split(vf_net* n, const float* x, const float* gy, int k, int need_input_grad, const float** gx) {
+  VF_REQUIRE(n && x && gy && k >= 0 && k <= (int)n->plan.size(), "vf_net_backward_split: bad arguments");
+  return net_walk_back(n, x, gy, gx, true, need_input_grad != 0, -1, 0, -1, 1, k);
+}
+VF_API int vf_net_backward_finish(vf_net* n) {
+  VF_REQUIRE(n != nullptr, "vf_net_backward_finish: NULL net");
+  if (!n->split_pending) return 0;
+  n->split_pending = false;
+  if (int rc = vf_wgrad_group_end(n->ctx)) return rc;
+  std::vector<Deferred> rest(n->pending_bias.size() / sizeof(Deferred));
+  memcpy(rest.data(), n->pending_bias.data(), n->pending_bias.size());
+  n->pending_bias.clear();
+  return bias_grad_flush(n, rest);
 }
 // net:updateGradInput(input, gradOutput): gradInput only (parameter gradients untouched; train.lua:366)
 VF_API int vf_net_update_grad_input(vf_net* n, const float* x, const float* gy, const float** gx) {

@@ -853,8 +853,10 @@ class Sequential(Module):
         if cur_pl is not None and edited is not False:
             get_backend().planes_split(cur, cur_pl)
 
-    def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0, group=None):
-        """Backward over plan entries hi-1 .. lo (default: all of them).  A partial walk lets the caller cut the
+    def _walk(self, input, gradOutput, want_gp, need_input_grad=True, hi=None, lo=0, group=None, defer_cut=None):
+        """defer_cut = k: one uninterrupted walk whose weight / bias gradients leave in two parts, both at its END: those of the
+        plan entries >= k now, the rest at backward_finish() (data parallel: the finished bucket's exchange starts in between).
+        Backward over plan entries hi-1 .. lo (default: all of them).  A partial walk lets the caller cut the
         pass where a gradient bucket is complete (data parallel: that bucket's all-reduce then overlaps the rest).
         group = (g, G): the pass covers group g of the G batches the last forward ran concatenated (BatchNorm.groups):
         the saved activations are sliced to that group's samples; `input` / `gradOutput` hold that group only."""
@@ -880,8 +882,13 @@ class Sequential(Module):
         if hi < len(plan) and self._bn_pre_at is not None and self._bn_pre_at[0] == hi:
             bn_pre = self._bn_pre_at[1]      # a walk cut between a convolution and the BatchNorm below it resumes here
         self._bn_pre_at = None
+        cut_wg, cut_bias = None, 0
+        assert not getattr(self, "_split_pending", None) or not want_gp, "a split backward is pending: call backward_finish() first"
         try:
             for idx in range(hi - 1, lo - 1, -1):
+                if defer_cut is not None and want_gp and idx == defer_cut - 1:
+                    cut_wg = B.wgrad_group_count() if grouped else 0       # everything recorded so far: the finished bucket
+                    cut_bias = len(deferred) if deferred is not None else 0
                 m, a = plan[idx]
                 x = input if idx == 0 else plan[idx - 1][0].output
                 mout = m.output
@@ -991,11 +998,20 @@ class Sequential(Module):
                 Sequential._group_open = False
                 B.wgrad_group_abort()
             raise
-        if grouped:
-            Sequential._group_open = False
-            B.wgrad_group_end()
-        if deferred:
-            B.bias_grad_multi(deferred)      # every deferred gradBias of this walk: two launches
+        if cut_wg is not None:
+            # the finished bucket's gradients now, the rest stay recorded (the group stays open) until backward_finish()
+            if grouped:
+                B.wgrad_group_end_partial(cut_wg)
+            if deferred:
+                if deferred[:cut_bias]:
+                    B.bias_grad_multi(deferred[:cut_bias])
+            self._split_pending = (grouped, deferred[cut_bias:] if deferred else [])
+        else:
+            if grouped:
+                Sequential._group_open = False
+                B.wgrad_group_end()
+            if deferred:
+                B.bias_grad_multi(deferred)      # every deferred gradBias of this walk: two launches
         if used_side:
             self.side.join()
         self._act_done_at = lo if act_done else -1       # a partial walk resumes at `lo` (backward_range)
@@ -1088,6 +1104,24 @@ class Sequential(Module):
         drivers never read it for netD's two full backward passes nor for netG (train.lua:318,348,403)."""
         assert scale == 1
         return self._walk(input, gradOutput, True, need_input_grad)
+
+    def backward_split(self, input, gradOutput, k, need_input_grad=True):
+        """backward() whose parameter gradients of the plan entries >= k are complete on return and those below k after
+        backward_finish(): the walk itself is not interrupted (see _walk)"""
+        return self._walk(input, gradOutput, True, need_input_grad, defer_cut=k)
+
+    def backward_finish(self):
+        pend = getattr(self, "_split_pending", None)
+        if not pend:
+            return
+        self._split_pending = None
+        grouped, rest = pend
+        B = get_backend()
+        if grouped:
+            Sequential._group_open = False
+            B.wgrad_group_end()
+        if rest:
+            B.bias_grad_multi(rest)
 
     def backward_range(self, input, gradOutput, hi, lo, need_input_grad=True):
         """backward() restricted to plan entries hi-1 .. lo; gradOutput is what the entry above `hi` returned."""

@@ -372,8 +372,11 @@ class _TrainerBase:
         runs the rest while that bucket is on the wire."""
         need = not self.skip_dead_grads
         if self._split_g is not None:
+            # ONE uninterrupted walk; the gradients of the tail bucket (entries >= k) leave at its end, the encoder's when
+            # _phase_b2 finishes the walk's group — both at the END of the data-gradient chain (a gradient launch in the middle of
+            # it slowed the passes behind it by 20-40 %: DESIGN.md 8)
             k, _ = self._split_g
-            self._g_mid = self.netG.backward_range(self._g_in(), df_dg, None, k, need)
+            self.netG.backward_split(self._g_in(), df_dg, k, need)
             return
         self.netG.backward(self._g_in(), df_dg, need_input_grad=need)
         self._allreduce_avg(self.gradParametersG)
@@ -487,9 +490,7 @@ class _TrainerBase:
             self._defer_comm = False
 
     def _phase_b2(self):
-        k, _ = self.netG.bucket_split()
-        if k > 0:
-            self.netG.backward_range(self._g_in(), self._g_mid, k, 0, not self.skip_dead_grads)
+        self.netG.backward_finish()      # the encoder's weight / bias gradients, while the tail bucket is on the wire
 
     def _phase_c(self):
         if self.shard_adam:
