@@ -2041,8 +2041,18 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
     }
     return 0;
   }
-  if (ctx->wg_active) {      // a launch outside the group must not overwrite recorded slabs: finish the group first
-    if (int rc = wg_flush(ctx)) return rc;
+  if (ctx->wg_active) {
+    // a launch outside the group must not overwrite recorded slabs: its own slabs go BEHIND them (the group stays recorded: a
+    // thin-channel layer at the end of a walk no longer launches the group ahead of vf_wgrad_group_end / _end_partial); only if
+    // the workspace cannot hold both is the group finished first
+    WgRecorder* R = (WgRecorder*)ctx->wg_rec;
+    const size_t need = ksplit > 1 ? (((size_t)ksplit * total * sizeof(float) + 255) & ~(size_t)255) : 0;
+    if (R && R->ws_used + need <= vf_ws_avail(ctx)) {
+      if (ksplit > 1) g.slab = (float*)(vf_ws_ptr(ctx) + R->ws_used);
+      R->ws_used += need;
+    } else if (int rc = wg_flush(ctx)) {
+      return rc;
+    }
   }
   {
     const int bf = ctx->mfma_bf16;
