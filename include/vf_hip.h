@@ -139,6 +139,13 @@ int vf_weight_planes(vf_ctx* ctx, const float* w, void* planes_native, void* pla
  * each); blocks = the total.  A net refreshes its weight planes once per parameter update (optim.adam, train.lua:421-424). */
 int vf_weight_planes_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks);
 int vf_pconv_supported(int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int transposed);
+/* The planes path in the bf16-operand mode (vf_ctx_set_mfma_mode 1): `planes` is then ONE plane, bf16 [1][n], the operand rounded
+ * to nearest-even by its producer — every producer above (vf_planes_split, vf_weight_planes[_multi], the y_planes / gx_planes
+ * of the BatchNorm entries, vf_conv2d_fwd_planes) writes that form when the context is in mode 1 — and the GEMMs issue one MFMA
+ * per product instead of six (k_pconv_dma<.., NPL = 1>, k_pwgrad_group<.., NPL = 1>).  Served shapes are narrower (whole
+ * 64-channel K steps, whole 64 x 64 tiles): vf_pconv_supported_in_mode(1, ...); mode 3 = vf_pconv_supported; mode 0: never.
+ * Results equal the in-kernel-rounding kernels' (same products, another summation order). */
+int vf_pconv_supported_in_mode(int mfma_mode, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int transposed);
 int vf_pconv_gather(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
                     int Cout, int act, float slope);
 int vf_pconv_scatter(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,

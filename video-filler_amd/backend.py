@@ -528,7 +528,9 @@ class HipBackend:
         self._c("vf_weight_planes_multi", _ptr(dev), n, blocks)
 
     def pconv_supported(self, B, H, W, Cin, Cout, k, stride, pad, transposed):
-        return bool(self.lib.vf_pconv_supported(B, H, W, Cin, Cout, k, stride, pad, 1 if transposed else 0))
+        """can the planes kernels serve this pass in the backend's CURRENT product mode (3: three exact planes; 1: one rounded
+        plane, whole 64-wide tiles only; 0: never)?"""
+        return bool(self.lib.vf_pconv_supported_in_mode(MFMA_MODES[self.mfma_mode], B, H, W, Cin, Cout, k, stride, pad, 1 if transposed else 0))
 
     def pconv_gather(self, ap, wp, bias, y, B, H, W, Cin, Cout, act="none", slope=0.0):
         self._c("vf_pconv_gather", _ptr(ap), _ptr(wp), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, ACT[act], slope)

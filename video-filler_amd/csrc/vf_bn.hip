@@ -21,7 +21,20 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // Exact three-way split of four fp32 values into bf16 planes (hi + mid + lo == x bit for bit; the arithmetic of
 // vf_pgemm.hip's pg_split4): the BatchNorm apply / backward passes write the planes of their output beside it, so the
 // convolution that consumes it (vf_pconv_*) finds its operand already split.  plane q of element i: planes[q * pstride + i].
-__device__ __forceinline__ void bn_store_planes(unsigned short* __restrict__ planes, int64_t pstride, int64_t i, f32x4 v) {
+// npl = 1 (the bf16-operand mode): ONE plane, rounded to nearest-even — the rounding vf_conv.hip's BF = 1 kernels apply inside
+// the GEMM, done once by the producer (vf_pgemm.hip pg_rne16).
+__device__ __forceinline__ unsigned bn_rne16(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bn_store_planes(unsigned short* __restrict__ planes, int64_t pstride, int64_t i, f32x4 v, int npl) {
+  if (npl == 1) {
+    u32x2 o;
+    o[0] = bn_rne16(v[0]) | (bn_rne16(v[1]) << 16);
+    o[1] = bn_rne16(v[2]) | (bn_rne16(v[3]) << 16);
+    *(u32x2*)(planes + i) = o;
+    return;
+  }
   float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, f
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
                                                   int64_t npix, int C, int cq, int rows_per_block, int act, float slope,
-                                                  unsigned short* __restrict__ planes, int64_t pstride) {
+                                                  unsigned short* __restrict__ planes, int64_t pstride, int npl) {
   x += (int64_t)blockIdx.z * npix * C;        // batch group z: its rows, its statistics
   y += (int64_t)blockIdx.z * npix * C;
   if (planes) planes += (int64_t)blockIdx.z * npix * C;
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, f
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = vf_act_apply(v[e], act, slope);
     *(f32x4*)(y + r * C + 4 * c4) = v;
-    if (planes) bn_store_planes(planes, pstride, r * C + 4 * c4, v);
+    if (planes) bn_store_planes(planes, pstride, r * C + 4 * c4, v, npl);
   }
 }
 
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const double* __restrict__ sums,
                                                       int64_t npix, double n, int C, int cq, int rows_per_block, int act,
-                                                      float slope, float pbeta, unsigned short* __restrict__ planes, int64_t pstride) {
+                                                      float slope, float pbeta, unsigned short* __restrict__ planes, int64_t pstride, int npl) {
   const int rp = 256 / cq;
   const int tx = threadIdx.x % cq, ty = threadIdx.x / cq;
   const int c4 = blockIdx.y * cq + tx;
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const f32x4 xv = *(const f32x4*)(x + o);
     const f32x4 out = (g - gm - (xv - mu) * kk) * is * ga;
     *(f32x4*)(gx + o) = out;
-    if (planes) bn_store_planes(planes, pstride, o, out);
+    if (planes) bn_store_planes(planes, pstride, o, out, npl);
   }
 }
 
@@ -555,7 +568,7 @@ VF_API int vf_bn_apply(vf_ctx* ctx, const float* x, float* y, const float* gamma
   const BnGeom g = bn_geom(npix, C);
   VfProf prof(ctx, "bn_apply", 0.0, 8.0 * (double)npix * C);
   hipLaunchKernelGGL(k_bn_apply, dim3(g.gx, g.gy), dim3(256), 0, ctx->stream, x, y, gamma, beta, mean, invstd, npix, C, g.cq,
-                     g.rows_per_block, act, slope, (unsigned short*)nullptr, (int64_t)0);
+                     g.rows_per_block, act, slope, (unsigned short*)nullptr, (int64_t)0, 3);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -566,7 +579,7 @@ static int bn_apply_groups(vf_ctx* ctx, const float* x, float* y, const float* g
   const BnGeom g = bn_geom(npix, C);
   VfProf prof(ctx, planes ? "bn_apply_planes" : "bn_apply", 0.0, (planes ? 14.0 : 8.0) * (double)npix * C * groups);
   hipLaunchKernelGGL(k_bn_apply, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, y, gamma, beta, mean, invstd, npix, C,
-                     g.cq, g.rows_per_block, act, slope, (unsigned short*)planes, npix * C * groups);
+                     g.cq, g.rows_per_block, act, slope, (unsigned short*)planes, npix * C * groups, ctx->mfma_bf16 == 1 ? 1 : 3);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -644,7 +657,7 @@ static int bn_bwd_apply_groups(vf_ctx* ctx, const float* x, const float* y_act, 
               gx ? (double)npix * C * groups * (4.0 * (act != VF_ACT_NONE ? 4 : 3) + (planes ? 6.0 : 0.0)) : 0.0);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(g.gx, g.gy, groups), dim3(256), 0, ctx->stream, x, y_act, gy, gx, ggamma, gbeta, gamma,
                      save_mean, save_invstd, sums, npix, (double)n_total, C, g.cq, g.rows_per_block, act, slope, pbeta,
-                     (unsigned short*)planes, npix * C * groups);
+                     (unsigned short*)planes, npix * C * groups, ctx->mfma_bf16 == 1 ? 1 : 3);
   VF_LAUNCH_CHECK();
   return 0;
 }

@@ -1788,7 +1788,7 @@ static int wg_flush(vf_ctx* ctx) {
     for (const WgRec& r : R->recs) any_planes |= (r.bf == 4);
     if (any_planes)
       for (WgRec& r : R->recs)
-        if (r.bf == 3 && r.plain_ok) {
+        if ((r.bf == 3 || r.bf == 1) && r.plain_ok) {
           r.bf = 4;
           r.blocks = r.pw.gx * r.pw.gy;
         }
@@ -1982,7 +1982,7 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.gx = gx; g.gy = gy; g.gz = ksplit;
   dim3 grid((unsigned)gx * gy * ksplit), block(256);
   // operands that arrive as planes (vf_*_bwd_weight_planes): the LDS-DMA kernel of vf_pgemm.hip, whole 128 x 128 x 32 tiles only
-  const bool use_pw = Up && Vp && ctx->mfma_bf16 == 3 && ntaps == 16 && stride == 2 && pad == 1 && Nu % 128 == 0 &&
+  const bool use_pw = Up && Vp && (ctx->mfma_bf16 == 3 || ctx->mfma_bf16 == 1) && ntaps == 16 && stride == 2 && pad == 1 && Nu % 128 == 0 &&
                       Cv % 64 == 0 && g.P % 32 == 0 && (int64_t)g.P * Nu * 6 < ((int64_t)1 << 31) &&
                       (int64_t)B * Hv * Wv * Cv * 6 < ((int64_t)1 << 31) && total % 4 == 0;
   const bool own_group = use_pw && !ctx->wg_active;      // a planes layer outside a group: a group of one, launched at once
@@ -2008,7 +2008,7 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
     r.total = total;
     r.flops = 2.0 * (double)g.P * Nu * (double)ntaps * Cv;
     r.plain_ok = false;
-    if (!use_pw && ctx->mfma_bf16 == 3 && BM == 128 && ksplit == 1 && Hl == 1 && Wl == 1 && Hv == 4 && Wv == 4 && stride == 1 &&
+    if (!use_pw && (ctx->mfma_bf16 == 3 || ctx->mfma_bf16 == 1) && BM == 128 && ksplit == 1 && Hl == 1 && Wl == 1 && Hv == 4 && Wv == 4 && stride == 1 &&
         pad == 0 && ntaps == 16 && Nu % 4 == 0 && (16 * Cv) % 128 == 0 && vecU && vecV) {
       r.plain_ok = true;
       VfPWGrad& w = r.pw;

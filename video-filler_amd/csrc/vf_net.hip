@@ -93,6 +93,7 @@ struct Layer {
   const void* grad_planes = nullptr;    // set by the last backward: planes of gx (or NULL)
   void *wp_nat = nullptr, *wp_tr = nullptr;      // weight planes, native and transposed
   bool wp_live = false;
+  int wp_mode = 0;               // product mode the weight planes were written in (3: three exact planes; 1: one rounded plane)
   // operands the two GEMM passes of this layer were fed with: the weight gradient takes the same planes
   const float* x_seen = nullptr;
   const void* xp_seen = nullptr;
@@ -173,11 +174,12 @@ bool pconv_layer(const Layer& l) {
   return is_conv(l) && is_s2(l) && std::min(l.d.nin, l.d.nout) >= 32 && l.d.nin % 4 == 0 && l.d.nout % 4 == 0;
 }
 bool pconv_ok(const vf_net* n, const Layer& l, int Bn, int Hg, int Wg, int Cgather, int Cout, bool transposed) {
-  if (g_no_pconv || n->ctx->mfma_bf16 != 3 || !is_s2(l)) return false;
+  const int mode = n->ctx->mfma_bf16;      // 3: three exact planes; 1: one plane rounded to bf16 by the producer
+  if (g_no_pconv || (mode != 3 && mode != 1) || !is_s2(l)) return false;
   const int64_t rows = (int64_t)Bn * Hg * Wg / (transposed ? 1 : 4);
   const double gflop = 2.0 * (double)rows * 16.0 * Cgather * Cout * 1e-9;
   if (rows < g_gate_rows || gflop < g_gate_gflop) return false;
-  return vf_pconv_supported(Bn, Hg, Wg, Cgather, Cout, 4, 2, 1, transposed ? 1 : 0) != 0;
+  return vf_pconv_supported_in_mode(mode, Bn, Hg, Wg, Cgather, Cout, 4, 2, 1, transposed ? 1 : 0) != 0;
 }
 
 int ensure_planes(vf_net* n, void** slot, int64_t numel) {
@@ -211,24 +213,25 @@ int run_observer(vf_net* n, int act_layer, float* y, int64_t numel, const void* 
 int weight_planes(vf_net* n, Layer& l, bool transposed, const void** out) {
   const float* w = n->params + l.w_off;
   const int d0 = is_full(l) ? l.d.nin : l.d.nout, d1 = is_full(l) ? l.d.nout : l.d.nin;
-  if (!l.wp_live) {
-    // first use: split now; from here on the net's one-launch refresh keeps this layer's planes current
+  if (!l.wp_live || l.wp_mode != n->ctx->mfma_bf16) {
+    // first use (or the product mode changed: another plane format): split now; from here on the net's one-launch refresh keeps this layer's planes current
     if (!l.wp_nat) {
       if (int rc = net_alloc(n->owned, &l.wp_nat, (size_t)l.w_n * 6)) return rc;
       if (int rc = net_alloc(n->owned, &l.wp_tr, (size_t)l.w_n * 6)) return rc;
     }
     if (int rc = vf_weight_planes(n->ctx, w, l.wp_nat, l.wp_tr, d0, d1)) return rc;
     l.wp_live = true;
+    l.wp_mode = n->ctx->mfma_bf16;
   }
   *out = transposed ? l.wp_tr : l.wp_nat;
   return 0;
 }
 
 int refresh_weight_planes(vf_net* n) {
-  if (g_no_pconv || n->ctx->mfma_bf16 != 3) return 0;
+  if (g_no_pconv || (n->ctx->mfma_bf16 != 3 && n->ctx->mfma_bf16 != 1)) return 0;
   std::vector<int> live;
   for (size_t i = 0; i < n->L.size(); ++i)
-    if (n->L[i].wp_live) live.push_back((int)i);
+    if (n->L[i].wp_live && n->L[i].wp_mode == n->ctx->mfma_bf16) live.push_back((int)i);
   if (live.empty()) return 0;
   if (live != n->wp_key || !n->wp_table) {
     std::vector<VfWpDescH> desc(live.size());

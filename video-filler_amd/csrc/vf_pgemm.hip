@@ -53,20 +53,38 @@ __device__ __forceinline__ void pg_split4(f32x4 v, u32x2 (&o)[3]) {
     }
   }
 }
+// The bf16-operand mode (vf_ctx_set_mfma_mode 1; BASELINE configs[4]'s "bf16"): ONE plane, the operand rounded to nearest-even —
+// bit for bit the rounding vf_conv.hip's BF = 1 kernels apply inside the GEMM ((u + 0x7FFF + lsb) >> 16), done once here.
+// 2 bytes per element instead of 6, one MFMA per product instead of six.
+__device__ __forceinline__ unsigned pg_rne16(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ u32x2 pg_round4(f32x4 v) {
+  u32x2 o;
+  o[0] = pg_rne16(v[0]) | (pg_rne16(v[1]) << 16);
+  o[1] = pg_rne16(v[2]) | (pg_rne16(v[3]) << 16);
+  return o;
+}
+template <int NPL>
 __global__ __launch_bounds__(256) void k_planes_split(const float* __restrict__ x, __bf16* __restrict__ planes, int64_t n4,
                                                       int64_t pstride) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    u32x2 o[3];
-    pg_split4(((const f32x4*)x)[i], o);
+    if constexpr (NPL == 1) {
+      *(u32x2*)(planes + 4 * i) = pg_round4(((const f32x4*)x)[i]);
+    } else {
+      u32x2 o[3];
+      pg_split4(((const f32x4*)x)[i], o);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) *(u32x2*)(planes + q * pstride + 4 * i) = o[q];
+      for (int q = 0; q < 3; ++q) *(u32x2*)(planes + q * pstride + 4 * i) = o[q];
+    }
   }
 }
 // weights: w physical [d0][16][d1] fp32 -> native planes [3][d0][16][d1] and transposed planes [3][d1][16][d0].
 // One block per (d0 tile of 32, tap, d1 tile of 32): the transpose goes through LDS so that both images are written in
 // whole 64-byte rows.
 __global__ __launch_bounds__(256) void k_weight_planes(const float* __restrict__ w, __bf16* __restrict__ nat, __bf16* __restrict__ tr,
-                                                       int d0, int d1, int64_t pstride) {
+                                                       int d0, int d1, int64_t pstride, int npl) {
   __shared__ float tile[32][33];
   const int t0 = blockIdx.x * 32, tap = blockIdx.y, u0 = blockIdx.z * 32;      // d0 tile, tap, d1 tile
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -77,11 +95,15 @@ __global__ __launch_bounds__(256) void k_weight_planes(const float* __restrict__
     tile[j][tx] = v;
     if (a < d0 && b < d1) {
       float r = v;
+      if (npl == 1) {
+        ((unsigned short*)nat)[((int64_t)a * 16 + tap) * d1 + b] = (unsigned short)pg_rne16(r);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const unsigned u = __float_as_uint(r) & 0xffff0000u;
-        ((unsigned short*)nat)[q * pstride + ((int64_t)a * 16 + tap) * d1 + b] = (unsigned short)(u >> 16);
-        r -= __uint_as_float(u);
+        for (int q = 0; q < 3; ++q) {
+          const unsigned u = __float_as_uint(r) & 0xffff0000u;
+          ((unsigned short*)nat)[q * pstride + ((int64_t)a * 16 + tap) * d1 + b] = (unsigned short)(u >> 16);
+          r -= __uint_as_float(u);
+        }
       }
     }
   }
@@ -91,11 +113,15 @@ __global__ __launch_bounds__(256) void k_weight_planes(const float* __restrict__
     const int b = u0 + j, a = t0 + tx;
     if (a < d0 && b < d1) {
       float r = tile[tx][j];
+      if (npl == 1) {
+        ((unsigned short*)tr)[((int64_t)b * 16 + tap) * d0 + a] = (unsigned short)pg_rne16(r);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const unsigned u = __float_as_uint(r) & 0xffff0000u;
-        ((unsigned short*)tr)[q * pstride + ((int64_t)b * 16 + tap) * d0 + a] = (unsigned short)(u >> 16);
-        r -= __uint_as_float(u);
+        for (int q = 0; q < 3; ++q) {
+          const unsigned u = __float_as_uint(r) & 0xffff0000u;
+          ((unsigned short*)tr)[q * pstride + ((int64_t)b * 16 + tap) * d0 + a] = (unsigned short)(u >> 16);
+          r -= __uint_as_float(u);
+        }
       }
     }
   }
@@ -113,7 +139,7 @@ struct VfWpDesc {
   int pad;
 };
 static_assert(sizeof(VfWpDesc) == 48, "descriptor layout is shared with the host mirror");
-__global__ __launch_bounds__(256) void k_weight_planes_multi(const VfWpDesc* __restrict__ d, int n) {
+__global__ __launch_bounds__(256) void k_weight_planes_multi(const VfWpDesc* __restrict__ d, int n, int npl) {
   int l = 0;
   while (l + 1 < n && (int)blockIdx.x >= d[l + 1].blk_off) ++l;
   const VfWpDesc L = d[l];
@@ -129,11 +155,15 @@ __global__ __launch_bounds__(256) void k_weight_planes_multi(const VfWpDesc* __r
   for (int j = ty; j < 32; j += 8) {
     const int a = t0 + j, b = u0 + tx;
     float r = (a < d0 && b < d1) ? L.w[((int64_t)a * 16 + tap) * d1 + b] : 0.f;
+    if (npl == 1) {
+      t[0][j][tx] = (unsigned short)pg_rne16(r);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const unsigned u = __float_as_uint(r) & 0xffff0000u;
-      t[q][j][tx] = (unsigned short)(u >> 16);
-      r -= __uint_as_float(u);
+      for (int q = 0; q < 3; ++q) {
+        const unsigned u = __float_as_uint(r) & 0xffff0000u;
+        t[q][j][tx] = (unsigned short)(u >> 16);
+        r -= __uint_as_float(u);
+      }
     }
   }
   __syncthreads();
@@ -142,8 +172,7 @@ __global__ __launch_bounds__(256) void k_weight_planes_multi(const VfWpDesc* __r
   {      // native: row = d0 index, c4 = d1 offset
     const int a = t0 + row, b = u0 + c4;
     if (a < d0 && b < d1) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < npl; ++q) {
         unsigned short* dst = (unsigned short*)L.nat + q * pstride + ((int64_t)a * 16 + tap) * d1 + b;
         if (whole) {
           u32x2 o;
@@ -159,8 +188,7 @@ __global__ __launch_bounds__(256) void k_weight_planes_multi(const VfWpDesc* __r
   {      // transposed: row = d1 index, c4 = d0 offset
     const int b = u0 + row, a = t0 + c4;
     if (a < d0 && b < d1) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < npl; ++q) {
         unsigned short* dst = (unsigned short*)L.tr + q * pstride + ((int64_t)b * 16 + tap) * d0 + a;
         if (whole) {
           u32x2 o;
@@ -556,12 +584,15 @@ __device__ __forceinline__ void pg_dma16(unsigned lds_byte, unsigned voffset, __
                : "memory");
 }
 
-template <int BM, int BN, int NTAPS, int NBUF = 2>
+// NPL = planes per operand: 3 (mode 3: the exact split, six product terms) or 1 (mode 1: operands rounded to bf16 by their
+// producer, ONE term — a stage is a third of the bytes and a sixth of the MFMAs; 128x64 with two stages: 48 KB, three blocks per CU)
+template <int BM, int BN, int NTAPS, int NBUF = 2, int NPL = 3>
 __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const PGemm p) {
   constexpr int CH = 64, WAVES_N = BN / 32, WAVES_M = BM / 32, NW = WAVES_M * WAVES_N;
   constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;                 // 8-row groups (one DMA instruction per plane) per wave
   static_assert(AG * NW * 8 == BM && BG * NW * 8 == BN, "row groups must divide over the waves");
-  constexpr int AH_SZ = BM * CH, BH_SZ = BN * CH, PL_SZ = AH_SZ + BH_SZ, BUF_SZ = 3 * PL_SZ;      // bf16 elements
+  static_assert(NPL == 1 || NPL == 3, "one rounded plane or the exact three-way split");
+  constexpr int AH_SZ = BM * CH, BH_SZ = BN * CH, PL_SZ = AH_SZ + BH_SZ, BUF_SZ = NPL * PL_SZ;      // bf16 elements
   __shared__ __attribute__((aligned(1024))) __bf16 smem[NBUF * BUF_SZ];
   auto sw_off = [](int row, int octet) { return row * 64 + ((octet ^ ((row >> 1) & 7)) << 3); };
 
@@ -625,7 +656,7 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;      // LDS byte address of the buffers
 
   // one stage = NP pieces (a DMA instruction each: 8 rows x 128 bytes of one plane); piece J of tap TAP's stage
-  constexpr int NP = 3 * (AG + BG);
+  constexpr int NP = NPL * (AG + BG);
   unsigned szero;                                   // an SGPR zero the compiler cannot fold into the asm's soffset operand
   asm volatile("s_mov_b32 %0, 0" : "=s"(szero));
   auto dma_piece = [&](int ch, auto TAP, auto PIECE, int buf, bool live) {
@@ -635,13 +666,13 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
     constexpr int t = (th << lgTW) | tw;
     const unsigned cb = (unsigned)(2 * CH) * (unsigned)ch;
     const unsigned base = lds0 + 2u * (unsigned)(buf * BUF_SZ);
-    if constexpr (J < 3 * AG) {
-      constexpr int i = J / 3, q = J % 3;
+    if constexpr (J < NPL * AG) {
+      constexpr int i = J / NPL, q = J % NPL;
       const unsigned tA = (unsigned)(th * rowA + tw * colA) + cb;
       const bool ok = live && ((a_mask[i] >> t) & 1u);
       pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + a_lds[i], ok ? a_byte[i] + tA : VF_OOB, rsA, szero + q * p.a_ps);
     } else {
-      constexpr int i = (J - 3 * AG) / 3, q = (J - 3 * AG) % 3;
+      constexpr int i = (J - NPL * AG) / NPL, q = (J - NPL * AG) % NPL;
       const unsigned tW = (unsigned)(w0 + th * rowW + tw * colW) + cb;
       pg_dma16(base + 2u * (unsigned)(q * PL_SZ) + b_lds[i], live ? w_byte[i] : VF_OOB, rsW, q * p.w_ps + tW);
     }
@@ -659,10 +690,10 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
   // slots are not what the MFMAs wait for: DMA-only 23.4 us, MFMA-only 22.7 us, both 28.8 us, neither 7.7 us on the 4.3 GFLOP pass.)
   auto compute_step = [&](int buf) {
     const __bf16* base = smem + buf * BUF_SZ;
-    bf16x8 a[2][3], b[2][3];
+    bf16x8 a[2][NPL], b[2][NPL];
     auto read_frag = [&](int g, int set) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NPL; ++q) {
         a[set][q] = *(const bf16x8*)(base + q * PL_SZ + sw_off(wm + lr, 2 * g + lh));
         b[set][q] = *(const bf16x8*)(base + q * PL_SZ + AH_SZ + sw_off(wn + lr, 2 * g + lh));
       }
@@ -673,11 +704,13 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
       const int cs = g & 1;
       if (g + 1 < CH / 16) read_frag(g + 1, cs ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1], acc[0][0], 0, 0, 0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0], acc[0][0], 0, 0, 0);
+      if constexpr (NPL == 3) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1], acc[0][0], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2], acc[0][0], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0], acc[0][0], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1], acc[0][0], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0], acc[0][0], 0, 0, 0);
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][0], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -751,7 +784,7 @@ __device__ __forceinline__ bf16x8 pg_tr_frag(const __bf16* tile, int col0, int k
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int NST>
+template <int NST, int NPL = 3>
 __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
   int l = 0;
   while (l + 1 < G.n && (int)blockIdx.x >= G.blk_off[l + 1]) ++l;
@@ -759,7 +792,7 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
   const int local = (int)blockIdx.x - G.blk_off[l];
   const int ntiles = p.gx * p.gy * p.gz;
   if (local >= ntiles) return;                       // padding blocks (uniform exit)
-  constexpr int BK = 32, TILE = BK * 128, PL_SZ = 2 * TILE, ST_SZ = 3 * PL_SZ;      // bf16 elements
+  constexpr int BK = 32, TILE = BK * 128, PL_SZ = 2 * TILE, ST_SZ = NPL * PL_SZ;      // bf16 elements
   __shared__ __attribute__((aligned(1024))) __bf16 smem[NST * ST_SZ];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -782,7 +815,7 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
   const int tap = col / p.Cv, cch = col - tap * p.Cv;
   const int dy = (tap >> 2) - 1, dx = (tap & 3) - 1;                           // stride 2, pad 1
   const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
-  const __amdgpu_buffer_rsrc_t rsU = pg_rsrc(p.Up, 3u * p.u_ps), rsV = pg_rsrc(p.Vp, 3u * p.v_ps);
+  const __amdgpu_buffer_rsrc_t rsU = pg_rsrc(p.Up, (unsigned)NPL * p.u_ps), rsV = pg_rsrc(p.Vp, (unsigned)NPL * p.v_ps);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const unsigned row_lds = 2u * (unsigned)(4 * wave * 128);                    // this wave's four rows inside a tile (bytes)
   unsigned szero;
@@ -797,7 +830,7 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
     const unsigned vo = okv ? 2u * (unsigned)(((b * p.Hv + iy) * p.Wv + ix) * p.Cv + cch) : VF_OOB;
     const unsigned base = lds0 + 2u * (unsigned)(st * ST_SZ) + row_lds;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < NPL; ++q) {
       pg_dma16(base + 2u * (unsigned)(q * PL_SZ), uo, rsU, szero + q * p.u_ps);
       pg_dma16(base + 2u * (unsigned)(q * PL_SZ + TILE), vo, rsV, szero + q * p.v_ps);
     }
@@ -818,14 +851,19 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
         if (n0 + c4 < p.Nu) u = *(const f32x4*)(p.Uf + (int64_t)pix * p.Nu + n0 + c4);      // (Nu % 4 == 0: a float4 is in or out)
         v = *(const f32x4*)(p.Vf + (int64_t)pix * Ncols + j0 + c4);
       }
-      u32x2 up[3], vp[3];
-      pg_split4(u, up);
-      pg_split4(v, vp);
       const int off = k * 128 + (((c4 >> 5) ^ (k & 3)) << 5) + (c4 & 31);      // bf16 elements inside a tile
+      if constexpr (NPL == 1) {
+        *(u32x2*)(smem + off) = pg_round4(u);
+        *(u32x2*)(smem + TILE + off) = pg_round4(v);
+      } else {
+        u32x2 up[3], vp[3];
+        pg_split4(u, up);
+        pg_split4(v, vp);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        *(u32x2*)(smem + q * PL_SZ + off) = up[q];
-        *(u32x2*)(smem + q * PL_SZ + TILE + off) = vp[q];
+        for (int q = 0; q < 3; ++q) {
+          *(u32x2*)(smem + q * PL_SZ + off) = up[q];
+          *(u32x2*)(smem + q * PL_SZ + TILE + off) = vp[q];
+        }
       }
     }
   };
@@ -837,10 +875,10 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
   auto compute_stage = [&](int st) {
     const __bf16* base = smem + st * ST_SZ;
-    bf16x8 a[2][3], b[2][3][2];
+    bf16x8 a[2][NPL], b[2][NPL][2];
     auto read_frag = [&](int g, int set) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
+      for (int q = 0; q < NPL; ++q) {
         a[set][q] = pg_tr_frag(base + q * PL_SZ, wm, 16 * g, lane);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b[set][q][nt] = pg_tr_frag(base + q * PL_SZ + TILE, wn + 32 * nt, 16 * g, lane);
@@ -854,11 +892,13 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {      // smallest terms first (the order of vf_conv.hip's mode 3)
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1][nt], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2][nt], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0][nt], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1][nt], acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0][nt], acc[nt], 0, 0, 0);
+        if constexpr (NPL == 3) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][1][nt], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][2][nt], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], b[cs][0][nt], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][1][nt], acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], b[cs][0][nt], acc[nt], 0, 0, 0);
+        }
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][0][nt], acc[nt], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -880,7 +920,8 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
     for (int kt = kt0; kt < kt1; ++kt) {
       // the 6 newest DMAs of this wave (stage kt + 1) may stay outstanding; after the barrier everybody's stage kt has landed
       // and nobody still reads the buffer stage kt + 2 goes to (it held stage kt - 1)
-      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      if constexpr (NPL == 3) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       const int st2 = st >= 1 ? st - 1 : 2;                        // (st + 2) % 3
       dma_stage(kt + 2, st2, kt + 2 < kt1);
@@ -921,6 +962,11 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
 
 int vf_internal_pwgrad_group(vf_ctx* ctx, const VfPWGradGroup& G, int blocks, const char* name, double flops) {
   static const int env_nst = getenv("VF_PWG_STAGES") ? atoi(getenv("VF_PWG_STAGES")) : 1;   // 1: 48 KB, three blocks per CU (measured 34.7 vs 42.9 us per 4.3 GFLOP layer)
+  if (ctx->mfma_bf16 == 1) {      // one rounded plane per operand: 16 KB stages
+    VF_LAUNCH_TIMED(ctx, "pwgrad_group_128x128x32_bf16", flops, 0.0, (k_pwgrad_group<1, 1>), dim3((unsigned)blocks), dim3(512), G);
+    VF_LAUNCH_CHECK();
+    return 0;
+  }
   if (env_nst == 1) VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group<1>, dim3((unsigned)blocks), dim3(512), G);
   else VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group<3>, dim3((unsigned)blocks), dim3(512), G);
   VF_LAUNCH_CHECK();
@@ -1011,6 +1057,30 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     }
     ctx->bnf.mode = 0;
   }
+  const bool one_plane = ctx->mfma_bf16 == 1;
+  VF_REQUIRE(!one_plane || use_dma, "vf_pconv: in the bf16-operand mode the planes path serves whole 64-channel / 64-row tiles only "
+             "(vf_pconv_supported_in_mode)");
+  if (use_dma && one_plane) {
+    // one rounded plane per operand: 128x64 stages of 24 KB (two stages: 48 KB, three blocks per CU), 64x64 of 16 KB
+    const unsigned nt = (unsigned)(gm * gn * zpar * ksplit);
+    char dname[64];
+    snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s_bf16", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
+    const double dfl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
+    if (t.bm == 128) {
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, 2, 1>), dim3(nt), dim3(512), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, 2, 1>), dim3(nt), dim3(512), g);
+    } else {
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, 2, 1>), dim3(nt), dim3(256), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, 2, 1>), dim3(nt), dim3(256), g);
+    }
+    VF_LAUNCH_CHECK();
+    if (ksplit > 1) {
+      VfProf prof(ctx, slab_st ? "slab_reduce_pconv_bnstats" : "slab_reduce_pconv", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+      return vf_internal_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, g.dmask, g.dact, g.dslope,
+                                     slab_st ? &g.st : nullptr, st_groups);
+    }
+    return 0;
+  }
   static const int env_dma = getenv("VF_PG_DMA") ? atoi(getenv("VF_PG_DMA")) : 1;
   if (use_dma) {
     const unsigned nt = (unsigned)(gm * gn * zpar * ksplit);
@@ -1080,14 +1150,16 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
   return 0;
 }
 
-static int pg_fill_common(PGemm& g, const void* a, int64_t a_elems, const void* w, int64_t w_elems, const float* bias, float* y) {
+static int pg_fill_common(vf_ctx* ctx, PGemm& g, const void* a, int64_t a_elems, const void* w, int64_t w_elems, const float* bias, float* y) {
   memset(&g, 0, sizeof(g));
   g.A = a; g.W = w; g.bias = bias; g.Y = y;
-  VF_REQUIRE(a_elems * 6 < ((int64_t)1 << 31) && w_elems * 6 < ((int64_t)1 << 31), "planes exceed the 2 GiB buffer-descriptor range");
+  const int npl = ctx->mfma_bf16 == 1 ? 1 : 3;
+  VF_REQUIRE(ctx->mfma_bf16 == 3 || ctx->mfma_bf16 == 1, "vf_pconv: the planes path serves product modes 3 (exact split) and 1 (bf16 operands)");
+  VF_REQUIRE(a_elems * 2 * npl < ((int64_t)1 << 31) && w_elems * 2 * npl < ((int64_t)1 << 31), "planes exceed the 2 GiB buffer-descriptor range");
   g.a_ps = (unsigned)(a_elems * 2);
   g.w_ps = (unsigned)(w_elems * 2);
-  g.a_bytes = 3 * g.a_ps;
-  g.w_bytes = 3 * g.w_ps;
+  g.a_bytes = npl * g.a_ps;
+  g.w_bytes = npl * g.w_ps;
   return 0;
 }
 
@@ -1096,7 +1168,7 @@ static int pconv_like_fwd(vf_ctx* ctx, const void* ap, const void* wp, const flo
                           int N, int act, float slope) {
   const int Ho = Hi / 2, Wo = Wi / 2;
   PGemm g;
-  if (int rc = pg_fill_common(g, ap, (int64_t)B * Hi * Wi * C, wp, (int64_t)N * 16 * C, bias, Y)) return rc;
+  if (int rc = pg_fill_common(ctx, g, ap, (int64_t)B * Hi * Wi * C, wp, (int64_t)N * 16 * C, bias, Y)) return rc;
   g.lgMh = vf_ilog2(Ho); g.lgMw = vf_ilog2(Wo);
   g.M = B * Ho * Wo;
   g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
@@ -1113,7 +1185,7 @@ static int pconv_like_fwd(vf_ctx* ctx, const void* ap, const void* wp, const flo
 static int pconv_like_tr(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* Y, int B, int Hi, int Wi, int C, int N,
                          int act, float slope, const float* dmask = nullptr, int dact = 0, float dslope = 0.f) {
   PGemm g;
-  if (int rc = pg_fill_common(g, ap, (int64_t)B * Hi * Wi * C, wp, (int64_t)N * 16 * C, bias, Y)) return rc;
+  if (int rc = pg_fill_common(ctx, g, ap, (int64_t)B * Hi * Wi * C, wp, (int64_t)N * 16 * C, bias, Y)) return rc;
   g.lgMh = vf_ilog2(Hi); g.lgMw = vf_ilog2(Wi);
   g.M = B * Hi * Wi;
   g.Hi = Hi; g.Wi = Wi; g.C = C; g.N = N;
@@ -1133,8 +1205,14 @@ VF_API int vf_planes_split(vf_ctx* ctx, const float* x, void* planes, int64_t n)
   VF_REQUIRE(n % 4 == 0 && pg_aligned16(x) && ((uintptr_t)planes & 7) == 0, "vf_planes_split: n %% 4 == 0 and aligned buffers");
   const int64_t n4 = n / 4;
   const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(vf_cdiv(n4, 256 * 2), 4096));
+  if (ctx->mfma_bf16 == 1) {
+    VfProf prof(ctx, "planes_round_bf16", 0.0, 6.0 * (double)n);
+    hipLaunchKernelGGL(k_planes_split<1>, dim3(nb), dim3(256), 0, ctx->stream, x, (__bf16*)planes, n4, n);
+    VF_LAUNCH_CHECK();
+    return 0;
+  }
   VfProf prof(ctx, "planes_split", 0.0, 10.0 * (double)n);
-  hipLaunchKernelGGL(k_planes_split, dim3(nb), dim3(256), 0, ctx->stream, x, (__bf16*)planes, n4, n);
+  hipLaunchKernelGGL(k_planes_split<3>, dim3(nb), dim3(256), 0, ctx->stream, x, (__bf16*)planes, n4, n);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -1142,14 +1220,15 @@ VF_API int vf_weight_planes(vf_ctx* ctx, const float* w, void* planes_native, vo
   VF_REQUIRE(w && planes_native && d0 > 0 && d1 > 0, "vf_weight_planes: bad arguments");
   VfProf prof(ctx, "weight_planes", 0.0, (planes_transposed ? 16.0 : 10.0) * (double)d0 * 16 * d1);
   hipLaunchKernelGGL(k_weight_planes, dim3((unsigned)vf_cdiv(d0, 32), 16, (unsigned)vf_cdiv(d1, 32)), dim3(256), 0, ctx->stream, w,
-                     (__bf16*)planes_native, (__bf16*)planes_transposed, d0, d1, (int64_t)d0 * 16 * d1);
+                     (__bf16*)planes_native, (__bf16*)planes_transposed, d0, d1, (int64_t)d0 * 16 * d1, ctx->mfma_bf16 == 1 ? 1 : 3);
   VF_LAUNCH_CHECK();
   return 0;
 }
 VF_API int vf_weight_planes_multi(vf_ctx* ctx, const void* desc_dev, int n, int blocks) {
   VF_REQUIRE(desc_dev != nullptr && n > 0 && blocks > 0, "vf_weight_planes_multi: empty table");
   VfProf prof(ctx, "weight_planes_multi", 0.0, 0.0);
-  hipLaunchKernelGGL(k_weight_planes_multi, dim3(blocks), dim3(256), 0, ctx->stream, (const VfWpDesc*)desc_dev, n);
+  hipLaunchKernelGGL(k_weight_planes_multi, dim3(blocks), dim3(256), 0, ctx->stream, (const VfWpDesc*)desc_dev, n,
+                     ctx->mfma_bf16 == 1 ? 1 : 3);
   VF_LAUNCH_CHECK();
   return 0;
 }
@@ -1158,16 +1237,24 @@ VF_API int vf_pconv_supported(int B, int H, int W, int Cin, int Cout, int k, int
   // conv-like passes gather on the H x W grid with channels Cin and produce Cout; transposed ones walk the low-res grid
   return pg_shape_ok(B, transposed ? H : H / 2, transposed ? W : W / 2, Cin, Cout) && H >= 2 && W >= 2 ? 1 : 0;
 }
+// the same question for a product mode: 3 = vf_pconv_supported; 1 (operands rounded to bf16, ONE plane [1][n]) is served by the
+// LDS-DMA kernel alone: whole 64-channel K steps and whole 64 x 64 tiles; other modes: never
+VF_API int vf_pconv_supported_in_mode(int mfma_mode, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int transposed) {
+  if (mfma_mode == 3) return vf_pconv_supported(B, H, W, Cin, Cout, k, stride, pad, transposed);
+  if (mfma_mode != 1 || !vf_pconv_supported(B, H, W, Cin, Cout, k, stride, pad, transposed)) return 0;
+  const int64_t M = (int64_t)B * (transposed ? H : H / 2) * (transposed ? W : W / 2);
+  return (Cin % 64 == 0 && Cout % 64 == 0 && M % 64 == 0) ? 1 : 0;
+}
 /* conv forward / full-conv data-gradient: gather planes `ap` [B][H][W][Cin], weight planes `wp` [Cout][16][Cin] */
 VF_API int vf_pconv_gather(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
                            int Cout, int act, float slope) {
-  VF_REQUIRE(vf_pconv_supported(B, H, W, Cin, Cout, 4, 2, 1, 0), "vf_pconv_gather: unsupported shape B=%d %dx%d %d->%d", B, H, W, Cin, Cout);
+  VF_REQUIRE(vf_pconv_supported_in_mode(ctx->mfma_bf16, B, H, W, Cin, Cout, 4, 2, 1, 0), "vf_pconv_gather: unsupported shape B=%d %dx%d %d->%d (product mode %d)", B, H, W, Cin, Cout, ctx->mfma_bf16);
   return pconv_like_fwd(ctx, ap, wp, bias, y, B, H, W, Cin, Cout, act, slope);
 }
 /* conv data-gradient / full-conv forward: low-res planes `ap` [B][H][W][Cin] -> y [B][2H][2W][Cout], weight planes [Cout][16][Cin] */
 VF_API int vf_pconv_scatter(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
                             int Cout, int act, float slope, const float* dmask, int dact, float dslope) {
-  VF_REQUIRE(vf_pconv_supported(B, H, W, Cin, Cout, 4, 2, 1, 1), "vf_pconv_scatter: unsupported shape B=%d %dx%d %d->%d", B, H, W, Cin, Cout);
+  VF_REQUIRE(vf_pconv_supported_in_mode(ctx->mfma_bf16, B, H, W, Cin, Cout, 4, 2, 1, 1), "vf_pconv_scatter: unsupported shape B=%d %dx%d %d->%d (product mode %d)", B, H, W, Cin, Cout, ctx->mfma_bf16);
   VF_REQUIRE(!(dmask && bias), "vf_pconv_scatter: the activation-backward epilogue is for data-gradient passes (no bias)");
   return pconv_like_tr(ctx, ap, wp, bias, y, B, H, W, Cin, Cout, act, slope, dmask, dact, dslope);
 }

@@ -149,7 +149,7 @@ class SpatialConvolution(Module):
         B = get_backend()
         rows = Bn * Hgrid * Wgrid // (1 if transposed else 4)
         gflop = 2.0 * rows * 16 * Cgather * Cout * 1e-9
-        return (not _NO_PCONV and getattr(B, "mfma_mode", None) == "f32_3xbf16" and hasattr(B, "pconv_supported")
+        return (not _NO_PCONV and getattr(B, "mfma_mode", None) in _PLANES_MODES and hasattr(B, "pconv_supported")
                 and self.kH == 4 and self.dH == 2 and self.padH == 1 and rows >= _PCONV_MIN_ROWS and gflop >= _PCONV_MIN_GFLOP
                 and B.pconv_supported(Bn, Hgrid, Wgrid, Cgather, Cout, 4, 2, 1, transposed))
 
@@ -162,12 +162,14 @@ class SpatialConvolution(Module):
         """(native, transposed) bf16 planes of the weight; Sequential.refresh_weight_planes() keeps them current in one
         launch per net — a module used on its own refreshes them on every call"""
         B = get_backend()
-        if getattr(self, "_wp", None) is None or self._wp_src != self.weight.data_ptr() or not getattr(self, "_wp_live", False):
+        if (getattr(self, "_wp", None) is None or self._wp_src != self.weight.data_ptr() or not getattr(self, "_wp_live", False)
+                or getattr(self, "_wp_mode", None) != B.mfma_mode):      # (planes of another product mode have another format)
             # first use (or the weight moved, e.g. getParameters): split now; from here on the net's one-launch refresh
             # (Sequential.refresh_weight_planes) keeps this layer's planes current
             self._wp = B.weight_planes(self.weight, *(self._wp if getattr(self, "_wp", None) is not None and self._wp[0].shape[1] == self.weight.numel() else (None, None)))
             self._wp_src = self.weight.data_ptr()
             self._wp_live = True
+            self._wp_mode = B.mfma_mode
         elif refresh:
             B.weight_planes(self.weight, *self._wp)
         return self._wp[1 if transposed else 0]
@@ -713,6 +715,9 @@ _PCONV_MIN_GFLOP = float(__import__("os").environ.get("VF_PCONV_MIN_GFLOP", str(
 # they did in k_wgrad_group: write-bound tiles under MFMA-bound ones.  Same-box A/B of the iteration: +0.5 .. +1.2 %
 # (DESIGN.md 4.7f).  VF_PWGRAD=0 keeps every weight gradient on the fp32-operand kernels.
 _PWGRAD = __import__("os").environ.get("VF_PWGRAD", "1") == "1"
+# product modes the planes kernels serve: three exact planes (fp32-grade) and ONE plane rounded to bf16 by the producer (the opt-in
+# bf16-operand mode; the planes buffers are allocated for three and hold one)
+_PLANES_MODES = ("f32_3xbf16", "bf16")
 
 
 class Sequential(Module):
@@ -1034,11 +1039,11 @@ class Sequential(Module):
         B = get_backend()
         if self._flat is not None:
             self._wp_version = param_version(self._flat[0])
-        if _NO_PCONV or getattr(B, "mfma_mode", None) != "f32_3xbf16" or not hasattr(B, "weight_planes_multi"):
+        if _NO_PCONV or getattr(B, "mfma_mode", None) not in _PLANES_MODES or not hasattr(B, "weight_planes_multi"):
             return
         # the layers that have taken the planes path at least once (SpatialConvolution.weight_planes marks them)
         mods = [m for m in self.leaves() if isinstance(m, SpatialConvolution) and getattr(m, "_wp_live", False)
-                and m._wp_src == m.weight.data_ptr()]
+                and m._wp_src == m.weight.data_ptr() and getattr(m, "_wp_mode", None) == B.mfma_mode]
         if not mods:
             return
         key = tuple(m.weight.data_ptr() for m in mods)
