@@ -1669,9 +1669,15 @@ static int conv_like_fwd(vf_ctx* ctx, const float* A, const float* w, const floa
 // Generic "transposed" pass: Y[b,oh,ow,n] = sum_{kh,kw,c : oh = 2i-1+kh ...} A[b,i,j,c] * Wt[c][kh][kw][n]
 // (conv data-grad: A = gy, c = Cout, n = Cin;  full-conv forward: A = x, c = Cin_full, n = Cout_full.)
 extern "C" int vf_act_bwd(vf_ctx* ctx, const float* y, const float* gy, float* gx, int64_t n, int act, float slope);
+int vf_internal_deconv_thin_out(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi, int C,
+                                int N, int act, float slope);      // vf_conv_thin.hip
 static int conv_like_bwd(vf_ctx* ctx, const float* A, const float* w, const float* bias, float* Y, int B, int Hi, int Wi,
                          int C, int N, int stride, int pad, int act, float slope, const float* dmask = nullptr, int dact = 0,
                          float dslope = 0.f) {
+  if (stride == 2 && pad == 1 && N <= 4 && !dmask && !ctx->bnf.mode) {      // the image side: direct kernel, no column matrix
+    const int rc = vf_internal_deconv_thin_out(ctx, A, w, bias, Y, B, Hi, Wi, C, N, act, slope);
+    if (rc >= 0) return rc;
+  }
   IGemm g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.Wt = w; g.bias = bias; g.Y = Y;

@@ -122,7 +122,127 @@ __global__ __launch_bounds__(256) void k_conv_thin_in(const float* __restrict__ 
   }
 }
 
+// ---- thin OUTPUT: the transposed 4x4 stride-2 pass onto <= 4 channels — netG's last full-conv forward (64 -> 3, Tanh;
+// train.lua:146) and the data-gradient of netD's first conv (train.lua:183, needed by fGx's netD:updateGradInput, :366).
+// N = 3: an MFMA tile is 13/16 padding and K = 64 is two K steps — the implicit GEMM took 40 us for 0.4 GFLOP, plus a col2im
+// pass (24 us).  Direct form: a thread owns ONE low-resolution position (b, my, mx) and produces its 2 x 2 output pixels x N
+// channels (12 accumulators): the 3 x 3 input neighbourhood meets all 16 filter taps exactly once (9 (pixel) x {1, 2, 4}
+// (parity classes) = 16 products per channel), so per input channel a thread does 9 LDS reads and 16 * N FMAs whose weight operand
+// is the SAME for every thread — 16 * N consecutive floats of w[c], read from LDS as broadcasts.  One wave per block: 8 x 8 positions,
+// the 10 x 10 x 64-channel patch staged in LDS per channel chunk (pixel pitch 68 floats: conflict-free 16-byte reads).
+// fp32 FMA chains; written once, coalesced enough (24 contiguous bytes per thread and output row).
+template <int N>
+__global__ __launch_bounds__(256) void k_deconv_thin_out(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int Hi, int Wi, int C,
+                                                         int tiles_x, int tiles_y, int act, float slope) {
+  // 8 x 8 positions per block, FOUR waves: wave k walks channels [16k, 16k + 16) of every 64-channel chunk for all 64 positions
+  // (a lone wave per SIMD sat out every LDS round trip: 28 us; four of them cover each other) and the partial sums meet in LDS,
+  // where wave k finishes parity class k (its N channels: bias, activation, store)
+  constexpr int TPO = 8, PWO = TPO + 2, CC = 64, PS = CC + 4, CW = CC / 4;
+  __shared__ __attribute__((aligned(16))) float patch[PWO * PWO * PS];      // (reused for the partial sums: 4 x 4N x 64 floats)
+  static_assert(4 * 4 * N * 64 <= PWO * PWO * PS, "the partial sums fit the patch buffer");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int tyi = t % tiles_y, b = t / tiles_y;
+  const int py = lane >> 3, px = lane & 7;
+  const int my = tyi * TPO + py, mx = tx * TPO + px;
+  float acc[4][N];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[k][n] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    __syncthreads();
+    // every load of the chunk in flight before the first LDS write (a load -> wait -> write loop cost 13 memory round trips
+    // per chunk: 36 us per launch)
+    constexpr int TOTX = PWO * PWO * (CC / 4), NX = (TOTX + 255) / 256;
+    f32x4 vx[NX];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int idx = tid + 256 * r, pix = idx / (CC / 4), q = idx % (CC / 4);
+      const int iy = tyi * TPO - 1 + pix / PWO, ix = tx * TPO - 1 + pix % PWO;
+      const bool ok = idx < TOTX && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      vx[r] = ok ? *(const f32x4*)(x + (((int64_t)b * Hi + iy) * Wi + ix) * C + c0 + 4 * q) : z;
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      const int idx = tid + 256 * r, pix = idx / (CC / 4), q = idx % (CC / 4);
+      if (idx < TOTX) *(f32x4*)(patch + pix * PS + 4 * q) = vx[r];
+    }
+    __syncthreads();
+    for (int c = wave * CW; c < wave * CW + CW; c += 4) {
+      f32x4 xv[3][3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) xv[dy][dx] = *(const f32x4*)(patch + ((py + dy) * PWO + px + dx) * PS + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // (the weights of a channel as LDS broadcasts instead made the kernel LDS-bound: 28-33 us; a lone wave per SIMD sat
+        //  out every SMEM round trip: 44 us — four waves per SIMD cover them)
+        const float* __restrict__ wc = w + (int64_t)(c0 + c + e) * 16 * N;      // wave-uniform address: scalar (SMEM) loads
+        // output row oy = 2 my + ph takes input rows i = my - 1 + dy with filter row kh = oy + 1 - 2 i:
+        //   ph = 0: (dy 1, kh 1), (dy 0, kh 3);   ph = 1: (dy 2, kh 0), (dy 1, kh 2)      (columns alike)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb) {
+                const int dy = ph == 0 ? 1 - a : 2 - a, kh = ph == 0 ? 1 + 2 * a : 2 * a;
+                const int dx = pw == 0 ? 1 - bb : 2 - bb, kw = pw == 0 ? 1 + 2 * bb : 2 * bb;
+                const float xs = xv[dy][dx][e];
+#pragma unroll
+                for (int n = 0; n < N; ++n) acc[ph * 2 + pw][n] = fmaf(xs, wc[(kh * 4 + kw) * N + n], acc[ph * 2 + pw][n]);
+              }
+      }
+    }
+  }
+  // the four channel quarters meet: red[wave][class * N + n][position]
+  __syncthreads();
+  float* red = patch;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int n = 0; n < N; ++n) red[(wave * 4 * N + k * N + n) * 64 + lane] = acc[k][n];
+  __syncthreads();
+  {
+    const int ph = wave >> 1, pw = wave & 1;      // wave k finishes parity class k
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    float* o = y + (((int64_t)b * Ho + 2 * my + ph) * Wo + 2 * mx + pw) * N;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v += red[(q * 4 * N + wave * N + n) * 64 + lane];      // fixed order: deterministic
+      o[n] = vf_act_apply(v + (bias ? bias[n] : 0.f), act, slope);
+    }
+  }
+}
+
 }  // namespace
+
+// transposed 4x4 stride-2 pad-1 pass onto N = 3 channels: x [B][Hi][Wi][C] -> y [B][2Hi][2Wi][N], w physical [C][16][N] (a
+// full-conv weight [Cin][kH][kW][Cout], or a conv weight [Cout][kH][kW][Cin] read for its data-gradient).  Returns -1 if the
+// shape is not this kernel's (the caller keeps its GEMM + col2im path), 0 when launched, > 0 on a launch error.
+int vf_internal_deconv_thin_out(vf_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int B, int Hi, int Wi, int C,
+                                int N, int act, float slope) {
+  static const bool off = getenv("VF_NO_THIN_OUT") != nullptr;
+  if (off || ctx->mfma_bf16 == 1) return -1;      // (the bf16-operand mode rounds its operands: the GEMM kernels' business)
+  if (N != 3 || C % 64 != 0 || Hi % 8 != 0 || Wi % 8 != 0 || (((uintptr_t)x) & 15) != 0 || (((uintptr_t)w) & 15) != 0) return -1;
+  const int tiles_x = Wi / 8, tiles_y = Hi / 8;
+  VfProf prof(ctx, "deconv_thin_out", 2.0 * (double)B * Hi * Wi * C * 16 * N, 0.0);
+  hipLaunchKernelGGL((k_deconv_thin_out<3>), dim3((unsigned)(B * tiles_y * tiles_x)), dim3(256), 0, ctx->stream, x, w, bias, y, Hi, Wi,
+                     C, tiles_x, tiles_y, act, slope);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
 
 // conv forward with 3 input channels, 4x4 stride 2 pad 1; act in {none, LeakyReLU, ReLU}.  Returns -1 if the shape is not this
 // kernel's (the caller keeps the implicit-GEMM path), 0 when launched, > 0 on a launch error.
