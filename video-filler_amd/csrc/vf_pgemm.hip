@@ -265,9 +265,13 @@ __device__ __forceinline__ void pg_bn_tile_partials(const VfBnSt& st, float (&s1
 // multiplier, so the 16 * MT * NT element bodies are straight-line code (with the activation as a per-element switch and
 // the statistics mode as per-element branches the epilogue was a quarter of vf_conv.hip's igemm kernels).
 // `red`: LDS the tile loop no longer needs (2 * WAVES_M * BN floats), for the statistics partials.
-template <int MT, int NT, int WAVES_M, int BN>
+// pre_d / pre_x (MT = NT = 1 only; may be NULL): the 16 derivative-mask values / BatchNorm inputs of this lane's accumulator
+// elements, fetched by the caller BEFORE its K loop — read here, at the end of the tile, they were a serialised memory phase
+// that nothing overlapped (E2's data-gradient: 62 us without the mask, 78 with it)
+template <int MT, int NT, int WAVES_M, int BN, bool PRE = false>
 __device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT], float* red, int m0, int n0, int wm, int wn, int lane,
-                                            int tid, int wave_m, int bx, int ks, int ooy0, int oox0, int ph, int pw, bool tile_ok) {
+                                            int tid, int wave_m, int bx, int ks, int ooy0, int oox0, int ph, int pw, bool tile_ok,
+                                            const float (&pre_d)[16], const float (&pre_x)[16]) {
   const int lr = lane & 31, lh = lane >> 5;
   const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
@@ -304,14 +308,14 @@ __device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT
           if (n < p.N) {
             float v = acc[mt][nt][r] + bv[nt];
             v = v * (v > 0.f ? 1.f : neg);
-            if constexpr (has_dmask) v = v * (p.dmask[pix * p.N + n] > 0.f ? 1.f : dneg);
+            if constexpr (has_dmask) v = v * ((PRE ? pre_d[r] : p.dmask[pix * p.N + n]) > 0.f ? 1.f : dneg);
             if constexpr (sm == 1) {
               const float d = v - sv[nt];
               st1[nt] += d;
               st2[nt] += d * d;
             } else if constexpr (sm == 2) {
               st1[nt] += v;
-              st2[nt] += v * (p.st.x[pix * p.N + n] - sv[nt]);
+              st2[nt] += v * ((PRE ? pre_x[r] : p.st.x[pix * p.N + n]) - sv[nt]);
             }
             out[pix * p.N + n] = v;
           }
@@ -560,7 +564,9 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void k_pconv(const PGemm p) {
   }
   if (PAIR && sub == 0) __syncthreads();              // (the barrier that pairs with the second half's last one)
 
-  pg_epilogue<MT, NT, BM / WM, BN>(p, acc, (float*)smem, m0, n0, wm, wn, lane, tid, wave / WAVES_N, bx, ks, ooy0, oox0, ph, pw, tile_ok);
+  const float none[16] = {};
+  pg_epilogue<MT, NT, BM / WM, BN>(p, acc, (float*)smem, m0, n0, wm, wn, lane, tid, wave / WAVES_N, bx, ks, ooy0, oox0, ph, pw, tile_ok,
+                                   none, none);
 }
 
 // ------------------------------------------------------------------------------------------------ the same GEMM fed by LDS-DMA
@@ -716,6 +722,29 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
     }
   };
 
+  // ---- what the epilogue reads besides the accumulators — the derivative mask of the activation below (conv -> LeakyReLU ->
+  //      conv, or the BatchNorm's activation) and, for the BatchNorm-backward sums, that BatchNorm's input — fetched NOW, 16
+  //      values each per lane, so that they travel beside the first stages instead of after the last MFMA
+  float pre_d[16], pre_x[16];
+  const bool fin_tile = p.ksplit == 1;
+  const bool want_d = fin_tile && p.dmask != nullptr, want_x = fin_tile && p.st.mode == 2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    pre_d[r] = 1.f;
+    pre_x[r] = 0.f;
+  }
+  if (want_d || want_x) {
+    const int n = n0 + wn + lr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+      const int64_t pix = ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
+      if (want_d) pre_d[r] = p.dmask[pix * p.N + n];
+      if (want_x) pre_x[r] = p.st.x[pix * p.N + n];
+    }
+  }
+
   // ---- main loop
   dma_step(ch0, VfIntC<0>{}, 0, ch0 < ch1);
   static_assert(NTAPS % 2 == 0, "the two LDS stages alternate with the tap parity");
@@ -752,7 +781,8 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
   // the last stage's prefetch (dead: out-of-range zeros) must have landed before LDS is reused, and nobody may still be
   // reading fragments when the epilogue's partial sums go there
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  pg_epilogue<1, 1, WAVES_M, BN>(p, acc, (float*)smem, m0, n0, wm, wn, lane, tid, wave / WAVES_N, bx, ks, ooy0, oox0, ph, pw, true);
+  pg_epilogue<1, 1, WAVES_M, BN, true>(p, acc, (float*)smem, m0, n0, wm, wn, lane, tid, wave / WAVES_N, bx, ks, ooy0, oox0, ph, pw, true,
+                                       pre_d, pre_x);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients from planes
