@@ -728,7 +728,8 @@ class CenterTrainer(_TrainerBase):
         else:
             self.netD.zeroConvBiases()                   # (netG's follows its deferred Adam step)
         self.netD.zeroGradParameters()
-        self.netD.refresh_weight_planes()          # netD: updated by the previous iteration's optim.adam(fDx) (and used by fGx since)
+        if self.netD._wp_stale():                  # (fGx refreshed netD's planes after optim.adam(fDx) moved its weights: stale only on
+            self.netD.refresh_weight_planes()      #  the first iteration and after a checkpoint load)
         if not self._pending_g:
             self.netG.refresh_weight_planes()      # netG: updated by the previous iteration's optim.adam(fGx)
         # netG's forward does not depend on netD's real pass: issue it on a side stream (same arithmetic)
@@ -875,7 +876,8 @@ class VidTrainer(_TrainerBase):
         else:
             self.netD.zeroConvBiases()                   # (netG's follows its deferred Adam step)
         self.netD.zeroGradParameters()
-        self.netD.refresh_weight_planes()          # netD: updated by the previous iteration's optim.adam(fDx) (and used by fGx since)
+        if self.netD._wp_stale():                  # (fGx refreshed netD's planes after optim.adam(fDx) moved its weights: stale only on
+            self.netD.refresh_weight_planes()      #  the first iteration and after a checkpoint load)
         if not self._pending_g:
             self.netG.refresh_weight_planes()      # netG: updated by the previous iteration's optim.adam(fGx)
         self._fill_from_initializer()
