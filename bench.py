@@ -343,13 +343,18 @@ def main():
         # committed under profiles/) — counters cannot be read from inside this run
         try:
             import glob
-            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic.json")))[-1]
+            # one summary per workload (scripts/pmc_bench_traffic.sh <workload>): r03_pmc_bench_traffic.json = center (configs[1]),
+            # ..._vid16.json = configs[2], ..._wholeim.json = configs[4]; taken at the workload's default batch size and product mode
+            suffix = "" if args.workload == "center" else "_" + args.workload
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic%s.json" % suffix)))[-1]
             pmc_all = json.load(open(pmc_file))
             pmc = pmc_all["kernels"].get(name)
             # the counters belong to ONE build of the kernels: the summary records the digest of csrc/ it was collected
             # with (scripts/pmc_bench_traffic.py) and a summary of any other build is refused
             fresh = pmc_all.get("csrc_sha256") == csrc_digest()
-            if pmc is not None and args.workload == "center" and args.batch == 64 and fresh:
+            default_batch = {"center": 64, "vid16": 16, "vid4": 16, "wholeim": 4}[args.workload]
+            if (pmc is not None and pmc_all.get("workload", "center") == args.workload and args.batch == default_batch
+                    and args.mfma == "f32_3xbf16" and fresh):
                 roofline["traffic"] = int(pmc["hbm_MB_per_launch"] * 1e6)
                 roofline["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)"
                 roofline["traffic_source"] = os.path.relpath(pmc_file, ROOT)

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Everything the committed profiles/ of a round are made of, in ONE GPU-box visit (run through gpurun from the repo root):
 #   bash scripts/collect_evidence.sh <tag>
-# -m gpu suite + the three un-profiled bench lines (gpu_round.sh), the two PMC passes for HBM traffic, the rocprofv3 kernel
+# -m gpu suite + the three un-profiled bench lines (gpu_round.sh), the two PMC passes for HBM traffic of each workload, the rocprofv3 kernel
 # statistics of the three workloads.  scripts/publish_profiles.py <tag> then copies the results into profiles/ (run locally).
 tag=${1:-x}
 bash scripts/gpu_round.sh $tag
-timeout -k 10 420 bash scripts/pmc_bench_traffic.sh > gpurun_out/${tag}_pmc.log 2>&1; echo "pmc rc=$?"
+for wl in center vid16 wholeim; do
+  timeout -k 10 420 bash scripts/pmc_bench_traffic.sh $wl > gpurun_out/${tag}_pmc_$wl.log 2>&1; echo "pmc $wl rc=$?"
+done
 timeout -k 10 200 bash scripts/prof_bench.sh ${tag}_center > /dev/null || exit 1
 timeout -k 10 200 bash scripts/prof_bench.sh ${tag}_vid16 --workload vid16 > /dev/null || exit 1
 timeout -k 10 200 bash scripts/prof_bench.sh ${tag}_wholeim --workload wholeim > /dev/null || exit 1

@@ -22,11 +22,17 @@ def bench_name(k):
         return "igemm_%sx%s_%s_v%s%s%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4),
                                           suf.get(m.group(5) or "0", ""), "_db" if m.group(7) == "true" else "")
     # k_pconv_dma<BM, BN, NTAPS> / k_pconv<BM, BN, WM, WN, NTAPS, CH, PAIR>
-    if re.match(r"void k_pwgrad_group<", k):
-        return "pwgrad_group_128x128x32"
-    m = re.match(r"void k_pconv_dma<(\d+), (\d+), (\d+)(?:, (\w+))?>", k)      # 4th argument: LDS stages (1: the two-blocks-per-CU form)
+    m = re.match(r"void k_pwgrad_group<(\d+)(?:, (\d+))?>", k)                      # <stages, planes per operand>
     if m:
+        return "pwgrad_group_128x128x32" + ("_bf16" if m.group(2) == "1" else "")
+    # k_pconv_dma<BM, BN, NTAPS, LDS stages (1: the two-blocks-per-CU form), planes per operand (1: the bf16-operand mode)>
+    m = re.match(r"void k_pconv_dma<(\d+), (\d+), (\d+)(?:, (\w+))?(?:, (\w+))?>", k)
+    if m:
+        if m.group(5) == "1":
+            return "pconv_dma_%sx%sx64_t%s_bf16" % (m.group(1), m.group(2), m.group(3))
         return "pconv_dma_%sx%sx64_t%s%s" % (m.group(1), m.group(2), m.group(3), "_1stage" if m.group(4) == "1" else "")
+    if "k_deconv_thin_out" in k:
+        return "deconv_thin_out"
     m = re.match(r"void k_pconv<(\d+), (\d+), \d+, \d+, (\d+), (\d+), (\w+)>", k)
     if m:
         return "pconv_%sx%sx%s_t%s%s" % (m.group(1), m.group(2), m.group(4), m.group(3), "_pair" if m.group(5) == "true" else "")
@@ -58,7 +64,7 @@ for name, e in sorted(acc.items()):
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_digest  # noqa: E402
 head = os.environ.get("VF_GIT_HEAD", "")
-json.dump(dict(csrc_sha256=csrc_digest(), git_head=head, note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graph --no-overlap --steps 2 "
+json.dump(dict(csrc_sha256=csrc_digest(), git_head=head, workload=os.environ.get("VF_PMC_WORKLOAD", "center"), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graph --no-overlap --steps 2 "
                     "--warmup 1`; averages over every launch of the kernel in that run; FETCH_SIZE x2 (gfx950 correction, "
                     "MI355X_MICROARCH.md); kernels keyed as in bench.py's kernel table",
                kernels=out), open(dst, "w"), indent=1)

@@ -305,6 +305,8 @@ class _TrainerBase:
         return self
 
     def _netD_both(self, real_in, fake_in):
+        """NOTE: the real half of the [real; fake] tensor is refreshed by set_batch() (keyed by buffer and batch version); a batch
+        edited IN PLACE without set_batch() is not seen here (nor by a captured graph) — batches change through set_batch() only."""
         B = get_backend()
         n = real_in.shape[0]
         shp = (2 * n,) + tuple(real_in.shape[1:])
@@ -389,6 +391,7 @@ class _TrainerBase:
         28 B/param HBM-bound update then overlaps MFMA-bound work.  Same arithmetic, same order on every buffer;
         `flush()` applies a pending update (call it before reading parametersG)."""
         B = get_backend()
+        assert not self.shard_adam, "shard_adam keeps its own 1 / world Adam state: use step_phased() (ADVICE r2)"
         every = self.__dict__.get("_sync_every")
         if every is None:
             every = self._sync_every = _eager_sync_every()
@@ -465,6 +468,7 @@ class _TrainerBase:
         """Apply a deferred Adam(G).  A captured graph always begins with that update, so after a flush the graph
         must not be replayed again (capture anew instead)."""
         if self._pending_g:
+            assert not self.shard_adam, "shard_adam has no deferred full-vector update to flush"
             self._wait_inflight()
             self._apply_pending_g()
             if (self._graph is not None and (self.defer_adam_g or self.adam_overlap)) or (self._graphs is not None and self._pipelined):
