@@ -44,5 +44,16 @@ for name, Cin, H, Cout in LAYERS:
     t_old = timeit(lambda: hb.conv2d_bwd_data(y, w, gx, 4, 2, 1))
     t_new = timeit(lambda: hb.pconv_scatter(yp, wt, None, gx, Bn, H // 2, H // 2, Cout, Cin))
     print("%-6s scatter B=%3d  old %7.1f us %6.1f TF   planes %7.1f us %6.1f TF   x%.2f" % (name, Bn, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new))
+    # the data-gradient as the iteration runs it: with the derivative mask of the activation below (conv -> LeakyReLU -> conv), and
+    # with the BatchNorm-backward sums + mask (conv -> BatchNorm -> LeakyReLU -> conv)
+    t_m = timeit(lambda: hb.pconv_scatter(yp, wt, None, gx, Bn, H // 2, H // 2, Cout, Cin, dmask=x, dact="lrelu", dslope=0.2))
+    sm = hb.zeros(Cin)
+    part = hb.zeros((max(Bn * H * H // 64, 512) + 8) * 2 * Cin, dtype=torch.float64)
+    def with_stats():
+        hb.bn_fuse_next_bwd(x, x, "lrelu", 0.2, sm, part, 1)
+        hb.pconv_scatter(yp, wt, None, gx, Bn, H // 2, H // 2, Cout, Cin)
+        hb.bn_fuse_result()
+    t_s = timeit(with_stats)
+    print("%-6s scatter + mask %7.1f us %6.1f TF   + BatchNorm-backward sums %7.1f us %6.1f TF" % (name, t_m, fl / t_m / 1e6, t_s, fl / t_s / 1e6))
 t = timeit(lambda: hb.planes_split(x, xp))
 print("planes_split of %d elements: %.1f us (%.0f GB/s)" % (x.numel(), t, 10.0 * x.numel() / t / 1e3))
