@@ -165,7 +165,7 @@ def _vid_batch(Bn, nc_in, nc_out, seed):
     return tuple(torch.from_numpy(a) for a in O.synth_vid_batch(Bn, np.random.default_rng(seed), nc_in, nc_out))
 
 
-@pytest.mark.parametrize("cfg", ["vid16", "wholeim", "wholeim-bf16"])
+@pytest.mark.parametrize("cfg", ["vid16", "wholeim", "wholeim-bf16", "wholeim-ext256"])
 def test_full_width_video_iterations_are_deterministic_and_finite(cfg, hipb, planes_gate):
     """configs[2] at its batch size (16 clips of 48 channels) and configs[4] at its per-GPU batch size (4, with the GDL value
     path on), three iterations, twice: finite, in range, bitwise repeatable.  `wholeim-bf16` is BASELINE.json's bf16 variant
@@ -174,7 +174,13 @@ def test_full_width_video_iterations_are_deterministic_and_finite(cfg, hipb, pla
     layers between the input and the scalar, three parameter updates)."""
     from video_filler_amd.trainers import VidTrainer
     opt, Bn, nci, nco = (VID16_OPT, 16, 48, 48) if cfg == "vid16" else (WHOLEIM_OPT, 4, 27, 12)
-    batch = _vid_batch(Bn, nci, nco, 77)
+    fs = 128
+    if cfg == "wholeim-ext256":
+        # BASELINE configs[4] as QUOTED (256x256) exists only as the labelled NON-PARITY extension (the reference's own nets fail at
+        # that size, SURVEY D5): full width, batchSize 2 — finite, in range, bitwise repeatable (VERDICT r2 missing #8)
+        opt, Bn, fs = dict(WHOLEIM_OPT, fineSize=256, ext256=True), 2, 256
+    from oracle import oracle as O
+    batch = tuple(torch.from_numpy(a) for a in O.synth_vid_batch(Bn, np.random.default_rng(77), nci, nco, fineSize=fs))
     modes = ["f32_3xbf16", "bf16"] if cfg == "wholeim-bf16" else ["f32_3xbf16", "f32_3xbf16"]
     runs = []
     try:
