@@ -511,6 +511,38 @@ def test_comm_bring_up_is_decided_by_all_ranks_together(stage, tmp_path):
         assert all(r["destroyed"] == 1 for r in res)       # everyone had one, everyone dropped it
 
 
+_AGENT_WORKER = """
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import video_filler_amd.backend as vb
+from test_host_logic import _FakeCommBackend
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+stage = os.environ.get("STAGE") or None
+b = _FakeCommBackend(stage if rank == 1 else None)
+vb.verify_comm = lambda backend, w, r, n=4096: True
+ok, store = vb.bring_up_comm(b, world, rank)
+print("RESULT", rank, int(ok), int(b.comm is not None), os.environ.get("TORCHELASTIC_USE_AGENT_STORE"), flush=True)
+"""
+
+
+@pytest.mark.parametrize("stage", ["", "init"])
+def test_comm_bring_up_under_torchrun_agent_store(stage, tmp_path):
+    """the way the driver launches bench.py for N > 1 (`python -m torch.distributed.run ... --master-addr 127.0.0.1`): the launcher's
+    agent serves the TCP store and every rank is a client of it (TORCHELASTIC_USE_AGENT_STORE) — the ranks must still agree"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w = tmp_path / "w.py"
+    w.write_text(_AGENT_WORKER % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, STAGE=stage)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_dp_port(23 + (1 if stage else 0))), str(w)], env=env, capture_output=True, text=True, timeout=300)
+    rows = sorted(l.split()[1:] for l in out.stdout.splitlines() if l.startswith("RESULT"))
+    assert len(rows) == 3, out.stdout + out.stderr
+    want = "0" if stage else "1"
+    assert all(r[1] == want and r[2] == want and r[3] == "True" for r in rows), rows
+
+
 def test_weight_planes_follow_the_parameter_version(cpu_backend):
     """with the trainers managing the weight planes, a direct netG.forward after the iteration's last optim.adam
     must not run on planes of the previous weights.  Host logic: every writer of a flat parameter vector bumps its version,
