@@ -521,7 +521,7 @@ stage = os.environ.get("STAGE") or None
 b = _FakeCommBackend(stage if rank == 1 else None)
 vb.verify_comm = lambda backend, w, r, n=4096: True
 ok, store = vb.bring_up_comm(b, world, rank)
-print("RESULT", rank, int(ok), int(b.comm is not None), os.environ.get("TORCHELASTIC_USE_AGENT_STORE"), flush=True)
+open(os.path.join(os.environ["OUT_DIR"], "r%d.txt" % rank), "w").write("%d %d %d %s" % (rank, int(ok), int(b.comm is not None), os.environ.get("TORCHELASTIC_USE_AGENT_STORE")))
 """
 
 
@@ -534,11 +534,12 @@ def test_comm_bring_up_under_torchrun_agent_store(stage, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     w = tmp_path / "w.py"
     w.write_text(_AGENT_WORKER % (root, os.path.join(root, "tests")))
-    env = dict(os.environ, STAGE=stage)
+    env = dict(os.environ, STAGE=stage, OUT_DIR=str(tmp_path))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
                           "--master-port", str(_dp_port(23 + (1 if stage else 0))), str(w)], env=env, capture_output=True, text=True, timeout=300)
-    rows = sorted(l.split()[1:] for l in out.stdout.splitlines() if l.startswith("RESULT"))
-    assert len(rows) == 3, out.stdout + out.stderr
+    files = [tmp_path / ("r%d.txt" % r) for r in range(3)]
+    assert all(f.exists() for f in files), out.stdout + out.stderr
+    rows = [f.read_text().split() for f in files]      # (one file per rank: concurrent prints interleave)
     want = "0" if stage else "1"
     assert all(r[1] == want and r[2] == want and r[3] == "True" for r in rows), rows
 

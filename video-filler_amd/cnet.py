@@ -66,7 +66,6 @@ class CNet(nn.Sequential):
         self._pushed = {}
         self._cb = None
         self._cb_error = None
-        self._out_bound = None
 
     @classmethod
     def adopt(cls, seq):
@@ -119,8 +118,7 @@ class CNet(nn.Sequential):
             Bn, Cc, H, W = shape
             _lib.check(lib.vf_net_reshape(self._net, Bn, Cc, H, W))
             self._shape = shape
-            self._out_bound = None
-        self._push("groups", self._groups, lambda v: lib.vf_net_set_batch_groups(self._net, v))
+            self._push("groups", self._groups, lambda v: lib.vf_net_set_batch_groups(self._net, v))
         self._push("train", bool(self.train), lambda v: lib.vf_net_training(self._net, 1 if v else 0))
         self._push("managed", bool(self._wp_managed), lambda v: lib.vf_net_set_weight_planes_managed(self._net, 1 if v else 0))
         _lib.check(lib.vf_net_set_planes_gate(float(nn._PCONV_MIN_GFLOP), int(nn._PCONV_MIN_ROWS)))      # (process-wide on both sides)
@@ -277,7 +275,6 @@ class CNet(nn.Sequential):
             return False
         last = max(i for i, m in enumerate(self._layers) if isinstance(m, nn.SpatialConvolution))
         _lib.check(_lib.load().vf_net_bind_output(self._net, last, C.c_void_p(buf.data_ptr())))
-        self._out_bound = buf
         return True
 
     def layer_output(self, i):

@@ -587,12 +587,6 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
       return rc;
     }
     if (defer_cut >= 0 && cut_wg >= 0) {
-      if (getenv("VF_DEBUG_SPLIT")) {
-        int total = 0;
-        (void)vf_wgrad_group_count(ctx, &total);
-        fprintf(stderr, "vf_net split: cut %d of %d plan entries, %d of %d recorded weight gradients, %zu of %zu bias gradients\n", defer_cut,
-                np, cut_wg, total, cut_bias, deferred.size());
-      }
       if ((rc = vf_wgrad_group_end_partial(ctx, cut_wg))) return rc;
       std::vector<Deferred> first(deferred.begin(), deferred.begin() + cut_bias);
       if ((rc = bias_grad_flush(n, first))) return rc;
