@@ -521,7 +521,7 @@ stage = os.environ.get("STAGE") or None
 b = _FakeCommBackend(stage if rank == 1 else None)
 vb.verify_comm = lambda backend, w, r, n=4096: True
 ok, store = vb.bring_up_comm(b, world, rank)
-open(os.path.join(os.environ["OUT_DIR"], "r%d.txt" % rank), "w").write("%d %d %d %s" % (rank, int(ok), int(b.comm is not None), os.environ.get("TORCHELASTIC_USE_AGENT_STORE")))
+open(os.path.join(os.environ["OUT_DIR"], "r" + str(rank) + ".txt"), "w").write(" ".join(str(v) for v in (rank, int(ok), int(b.comm is not None), os.environ.get("TORCHELASTIC_USE_AGENT_STORE"))))
 """
 
 
