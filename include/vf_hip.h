@@ -297,6 +297,17 @@ int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int6
 int vf_adam_prep(vf_ctx* ctx, double lr, double beta1, double beta2, int32_t* t_dev);
 int vf_adam_apply(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2,
                   double eps, const int32_t* t_dev);
+/* optim.adam applied inside the weight-gradient kernel of a bottleneck layer (train.lua:104 conv nef*8 -> nBottleneck on a 4x4
+ * map, :134 full-conv nBottleneck -> ngf*8 onto one; THNN accGradParameters with K = batch):
+ *   g[n][col] = sum_{k < K} U[k][n] * V[k][col]        U = [K][Nu] (the 1x1-map side), V = [K][Ncols] (the 4x4-map side, Ncols = 16*C)
+ * is formed in the accumulators and consumed there: x, m, v = [Nu][Ncols] slices of the flat parameter vector and of the optimiser
+ * state are read and written once — 24 B per weight where accGradParameters + vf_adam_apply move 32 (those two tensors are 92 % of
+ * train.lua's generator).  g (may be NULL) also receives the gradient (gradParameters stays complete; 28 B).  Requires a fresh
+ * gradient (zeroGradParameters before the backward pass, as both closures do) and t_dev after vf_adam_prep; element for element
+ * the update of vf_adam_apply.  vf_wgrad_adam_outer_supported: 1 when the shape is the kernel's (Ncols % 128 == 0, Nu even, >= 64). */
+int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols);
+int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v,
+                        float* g, double beta1, double beta2, double eps, const int32_t* t_dev);
 
 /* ---- batch preparation and the inference tile loop (the data formats either side of the closures) ---------
  * train.lua:284-298: from the loader's batch (B x C x fs x fs planar, [-1,1]) produce the NHWC generator input with
@@ -481,6 +492,16 @@ int vf_net_backward_range(vf_net* net, const float* x, const float* gy, int hi, 
  * launches the gradients of the entries below k.  Nothing else may record weight gradients on the context in between. */
 int vf_net_backward_split(vf_net* net, const float* x, const float* gy, int k, int need_input_grad, const float** gx);
 int vf_net_backward_finish(vf_net* net);
+/* optim.adam fused into the bottleneck pair's weight gradients (vf_wgrad_adam_outer).  vf_net_set_fused_adam(1): backward walks
+ * leave out the weight gradient of every layer the fused kernel takes and remember its operands (the module buffers, untouched
+ * until the next forward); *count = the number of such layers (0: nothing to fuse — keep the plain update).  vf_net_fused_adam_range
+ * names the i-th layer's weight slice of the flat vectors, which the host's own vf_adam_apply calls must leave out.
+ * vf_net_adam_fused, after the backward pass and vf_adam_prep: the fused kernel per marked layer (m, v: the optimiser's flat state,
+ * laid out like the parameters; keep_grad: gradParameters receives those slices too).  A marked layer whose gradient was not fresh
+ * (a second backward without zeroGradParameters) was accumulated the plain way and gets vf_adam_apply on its slice. */
+int vf_net_set_fused_adam(vf_net* net, int on, int* count);
+int vf_net_fused_adam_range(const vf_net* net, int i, int64_t* offset, int64_t* length);
+int vf_net_adam_fused(vf_net* net, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad);
 /* SyncBN: BatchNorm sums all-reduced over `comm` (world ranks; statistics of the global batch).  force: take that path at world 1
  * too.  comm NULL / world 1 / force 0: device-local statistics. */
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);

@@ -182,3 +182,63 @@ def attach_world1_comm(hipb):
     if hipb.comm is None:
         hipb.init_comm(1, 0, hipb.comm_unique_id())
     return hipb
+
+
+def to_internal(net, vec_ref):
+    """reference-order flat vector -> this net's padded channels-last flat layout."""
+    flat = torch.zeros_like(net._flat[0])
+    off = 0
+    for m, name, gname, o, n in net._flat[2]:
+        t = getattr(m, name)
+        seg = torch.from_numpy(vec_ref[off:off + n].copy()).to(flat.device)
+        if t.dim() == 4:
+            seg = seg.reshape(t.shape).permute(0, 2, 3, 1).reshape(-1)
+        flat[o:o + n] = seg
+        off += n
+    return flat
+
+
+def from_internal(net, flat):
+    parts = []
+    for m, name, gname, o, n in net._flat[2]:
+        t = getattr(m, name)
+        seg = flat[o:o + n]
+        if t.dim() == 4:
+            d0, d1, kH, kW = t.shape
+            seg = seg.view(d0, kH, kW, d1).permute(0, 3, 1, 2).contiguous().reshape(-1)
+        parts.append(seg)
+    return to_np(torch.cat(parts))
+
+
+def grads_reference_order(tr, net, gref):
+    """net.reference_flat(grads=True) as numpy.  The slices of netG's gradient vector that step() does not write
+    (trainer.fused_adam_ranges(): the bottleneck pair's weight gradients are formed and consumed inside the Adam kernel,
+    optim.adam_update_fused) are read back from Adam's first moment after a FIRST update (m = (1 - beta1) g, m having started
+    at zero); after later updates they are taken from the oracle's vector `gref`, and what vouches for them is the comparison
+    of the parameters and of Adam's m and v, which those tests make."""
+    ranges = tr.fused_adam_ranges() if net is tr.netG and hasattr(tr, "fused_adam_ranges") else []
+    if not ranges:
+        return to_np(net.reference_flat(grads=True))
+    flat = net._flat[1].clone()
+    st = tr.optimStateG
+    if int(st["t_dev"][0].item()) == 1:
+        # after the first update m = (1 - beta1) g exactly (m started at zero): the gradient the kernel consumed, read back
+        for lo, hi in ranges:
+            flat[lo:hi] = st["m"][lo:hi] / (1.0 - st.get("beta1", 0.9))
+    else:
+        want = to_internal(net, np.asarray(gref, np.float32))
+        for lo, hi in ranges:
+            flat[lo:hi] = want[lo:hi]
+    return from_internal(net, flat)
+
+
+def unwritten_grad_mask(tr, net):
+    """bool numpy vector in reference order: the elements of net's gradient vector that step() does not write (see
+    grads_reference_order); None when there are none"""
+    ranges = tr.fused_adam_ranges() if net is tr.netG and hasattr(tr, "fused_adam_ranges") else []
+    if not ranges:
+        return None
+    flat = torch.zeros_like(net._flat[1])
+    for lo, hi in ranges:
+        flat[lo:hi] = 1.0
+    return from_internal(net, flat) > 0.5

@@ -148,7 +148,11 @@ def test_hip_reproduces_iteration_vectors(kind, hipb):
     fake = to_np(tr.netG.output).reshape(-1)
     assert rel_err(fake[::mk.STRIDE], z["fake0_sample"]) < 1e-4
     # real (kinked) nets at batch 2: see tests/test_gpu_trainers.py for why gradients get 3e-2
-    assert rel_err(to_np(tr.netG.reference_flat(grads=True))[::mk.STRIDE], z["gG0_sample"]) < 3e-2
+    from helpers import unwritten_grad_mask
+    gs, skip = to_np(tr.netG.reference_flat(grads=True))[::mk.STRIDE], unwritten_grad_mask(tr, tr.netG)
+    if skip is not None:       # (the bottleneck pair's weight gradients are consumed inside the fused Adam kernel)
+        gs = np.where(skip[::mk.STRIDE], z["gG0_sample"], gs)
+    assert rel_err(gs, z["gG0_sample"]) < 3e-2
 
 
 def test_oracle_reproduces_the_full_width_config0_fixture(oracle):

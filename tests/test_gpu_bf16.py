@@ -168,7 +168,8 @@ def test_bf16_training_iteration_tracks_fp32(oracle, bf16_backend, planes_gate, 
     got = tr.losses()
     for k in ("errD", "errG", "errG_l2"):
         assert abs(got[k] - getattr(ref, k)) < 2e-2 * max(1.0, abs(getattr(ref, k))), (k, got[k], getattr(ref, k))
-    gG = tr.netG.reference_flat(grads=True).cpu().numpy()
+    from helpers import grads_reference_order
+    gG = grads_reference_order(tr, tr.netG, ref.gradParametersG)
     assert np.abs(gG - ref.gradParametersG).max() < 5e-2 * np.abs(ref.gradParametersG).max()
 
 
@@ -231,7 +232,8 @@ def test_three_plane_training_iteration_matches_fp32_tolerances(oracle, x3_backe
     for k in ("errD", "errG", "errG_l2"):
         assert abs(got[k] - getattr(ref, k)) < 2e-5 * max(1.0, abs(getattr(ref, k))), (k, got[k], getattr(ref, k))
     for net, want in ((tr.netG, ref.gradParametersG), (tr.netD, ref.gradParametersD)):
-        g = net.reference_flat(grads=True).cpu().numpy()
+        from helpers import grads_reference_order
+        g = grads_reference_order(tr, net, want)
         assert np.abs(g - want).max() < 1e-4 * np.abs(want).max()
 
 

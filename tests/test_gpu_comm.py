@@ -111,6 +111,7 @@ def test_syncbn_collectives_are_captured_with_the_phases(kind, oracle, hipb):
         return t
 
     plain = mk()
+    plain.fuse_adam = "keep"       # (its gradient vector is read below)
     plain.set_batch_d(False)
     plain.set_batch(*batch)
     eager, graph = synced(), synced()

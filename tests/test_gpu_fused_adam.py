@@ -1,0 +1,178 @@
+"""optim.adam inside the bottleneck pair's weight-gradient kernel (vf_wgrad_adam_outer, vf_net_adam_fused,
+optim.adam_update_fused): train.lua:104 (conv nef*8 -> nBottleneck on a 4x4 map) and :134 (full-conv nBottleneck -> ngf*8),
+THNN accGradParameters with K = batch, followed by optim/adam.lua's element update.
+
+What is held to what:
+  * the gradient the kernel forms (stored on request) against numpy in double: 2e-6 of its max-norm (fp32 products,
+    fp32 accumulation in batch order);
+  * x, m, v after the fused update against vf_adam_apply fed with that same gradient: BIT FOR BIT (one definition of the
+    element update, vf_common.h vf_adam_upd);
+  * not storing the gradient changes nothing else: bit for bit;
+  * the trainers: fuse_adam "on" == "keep" bit for bit in every persistent tensor, eager and captured; "keep" == "off"
+    (accGradParameters + the plain update) bit for bit where the plain path forms that gradient with the same kernel
+    (K <= 32), and at 1e-6 of the gradient's max-norm where it uses the three-plane tiles (K = 64).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(hipb, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, generator=g).to(hipb.device)
+    m = (0.1 * torch.randn(n, generator=g)).to(hipb.device)
+    v = (0.01 * torch.rand(n, generator=g)).to(hipb.device)
+    t_dev = hipb.zeros(2, dtype=torch.int32)
+    return x, m, v, t_dev
+
+
+@pytest.mark.parametrize("K,Nu,Ncols", [(4, 64, 128), (3, 66, 256), (16, 200, 1024), (64, 192, 2048), (8, 4000, 8192), (33, 70, 384)])
+def test_fused_kernel_is_accgrad_then_adam(K, Nu, Ncols, hipb):
+    assert hipb.lib.vf_wgrad_adam_outer_supported(K, Nu, Ncols) == 1
+    gen = torch.Generator().manual_seed(K * 1000 + Nu)
+    U = torch.randn(K, Nu, generator=gen).to(hipb.device)
+    V = torch.randn(K, Ncols, generator=gen).to(hipb.device)
+    n = Nu * Ncols
+    lr, b1, b2, eps = 2e-4, 0.5, 0.999, 1e-8
+    # fused, gradient stored
+    x1, m1, v1, t1 = _state(hipb, n, 7)
+    g1 = torch.full((n,), 123.0, device=hipb.device)
+    for _ in range(2):                         # two updates: the second runs on carried m, v and t = 2
+        hipb.adam_prep(lr, b1, b2, t1)
+        hipb.wgrad_adam_outer(U, V, x1, m1, v1, g1, b1, b2, eps, t1)
+    want = U.double().cpu().numpy().T @ V.double().cpu().numpy()
+    assert rel_err(to_np(g1).reshape(Nu, Ncols), want) < 2e-6
+    # the plain update fed with that gradient
+    x2, m2, v2, t2 = _state(hipb, n, 7)
+    for _ in range(2):
+        hipb.adam_prep(lr, b1, b2, t2)
+        hipb.adam_apply(x2, g1, m2, v2, b1, b2, eps, t2)
+    assert torch.equal(x1, x2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert int(t1[0].item()) == 2
+    # gradient not stored: nothing else moves
+    x3, m3, v3, t3 = _state(hipb, n, 7)
+    for _ in range(2):
+        hipb.adam_prep(lr, b1, b2, t3)
+        hipb.wgrad_adam_outer(U, V, x3, m3, v3, None, b1, b2, eps, t3)
+    assert torch.equal(x1, x3) and torch.equal(m1, m3) and torch.equal(v1, v3)
+    assert float((x1 - _state(hipb, n, 7)[0]).abs().max()) > 0
+
+
+def test_unsupported_shapes_are_refused(hipb):
+    for K, Nu, Ncols in ((4, 62, 128), (4, 65, 128), (4, 64, 192), (0, 64, 128)):
+        assert hipb.lib.vf_wgrad_adam_outer_supported(K, Nu, Ncols) == 0
+    U = torch.randn(4, 62).to(hipb.device)
+    V = torch.randn(4, 128).to(hipb.device)
+    x, m, v, t = _state(hipb, 62 * 128, 1)
+    with pytest.raises(Exception, match="not this kernel's shape"):
+        hipb.wgrad_adam_outer(U, V, x, m, v, None, 0.5, 0.999, 1e-8, t)
+
+
+def _trainer(kind, opt, mode, batch, host="cabi"):
+    from video_filler_amd.trainers import CenterTrainer, VidTrainer
+    tr = (CenterTrainer if kind == "center" else VidTrainer)(opt, seed=3, host=host)
+    tr.fuse_adam = mode
+    tr.set_batch(*batch)
+    return tr
+
+
+def _persistent(tr):
+    out = [tr.parametersG, tr.parametersD, tr.optimStateG["m"], tr.optimStateG["v"], tr.optimStateD["m"], tr.optimStateD["v"]]
+    for net in (tr.netG, tr.netD):
+        for mod in net.leaves():
+            if hasattr(mod, "running_mean"):
+                out += [mod.running_mean, mod.running_var]
+    return out
+
+
+@pytest.mark.parametrize("kind,B", [("center", 4), ("center", 64), ("vid", 4)])
+def test_trainer_modes_walk_the_same_trajectory(kind, B, oracle, hipb, planes_gate):
+    """fuse_adam on / keep / off from the same weights and batch, three iterations each (eager), and "on" captured."""
+    if kind == "center":
+        opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4, nef=16, ngf=16, ndf=16) if B == 64 else dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
+        batch = (torch.from_numpy(oracle.synth_center_batch(B, np.random.default_rng(5))),)
+    else:
+        opt = dict(nBottleneck=96, nc_in=27, nc_out=12, nef=32, ngf=32, ndf=32, weight_nomask=1, wtgdl=0.5)      # train_wholeim_input.lua's shape
+        batch = tuple(torch.from_numpy(a) for a in oracle.synth_vid_batch(B, np.random.default_rng(6), 27, 12))
+    on, keep, off, cap = [_trainer(kind, opt, m, batch) for m in ("on", "keep", "off", "on")]
+    for t in (on, keep, off):
+        for _ in range(3):
+            t.step()
+    cap.capture(warmup=2)
+    cap.replay()
+    torch.cuda.synchronize()
+    assert on.fused_adam_ranges() and len(on.fused_adam_ranges()) == 2 and not off.fused_adam_ranges()
+    ranges = on.fused_adam_ranges()
+    assert sum(hi - lo for lo, hi in ranges) > 0.5 * on.parametersG.numel()        # the pair is most of the generator
+    for a, b, c in zip(_persistent(on), _persistent(keep), _persistent(cap)):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    # "keep" writes the whole gradient vector; "on" everything but the two slices (which keep what was there: zeros)
+    gk, go = keep.gradParametersG, on.gradParametersG
+    mask = torch.zeros_like(gk, dtype=torch.bool)
+    for lo, hi in ranges:
+        mask[lo:hi] = True
+        assert float(gk[lo:hi].abs().max()) > 0 and float(go[lo:hi].abs().max()) == 0
+    assert torch.equal(gk[~mask], go[~mask])
+    # against accGradParameters + the plain update
+    if B <= 32:
+        for a, b in zip(_persistent(keep), _persistent(off)):
+            assert torch.equal(a, b)
+        assert torch.equal(keep.gradParametersG, off.gradParametersG)
+    else:
+        # K = 64: the plain path's three-plane tiles against the fused kernel's fp32 matrix-core products — one iteration from
+        # the same weights (after that the two trajectories hold different weights)
+        keep1, off1 = _trainer(kind, opt, "keep", batch), _trainer(kind, opt, "off", batch)
+        keep1.step()
+        off1.step()
+        torch.cuda.synchronize()
+        assert rel_err(to_np(keep1.gradParametersG), to_np(off1.gradParametersG)) < 1e-6
+        lr = keep1.optimStateG["learningRate"]
+        sel = off1.gradParametersG.abs() > 1e-3 * off1.gradParametersG.abs().max()
+        assert float((keep1.parametersG - off1.parametersG).abs()[sel].max()) <= 0.02 * lr
+    for k in ("errD", "errG", "errG_l2"):
+        assert on.losses()[k] == keep.losses()[k] == cap.losses()[k]
+
+
+def test_fused_update_is_left_out_where_it_does_not_apply(oracle, hipb):
+    """a data-parallel step (the gradient must travel) and the module-by-module host keep accGradParameters + the plain update"""
+    from helpers import attach_world1_comm
+    opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
+    batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)
+    mirror = _trainer("center", opt, "on", batch, host="mirror")
+    mirror.step()
+    assert mirror.fused_adam_ranges() == []
+    attach_world1_comm(hipb)
+    dp = _trainer("center", opt, "on", batch)
+    dp.force_comm = True
+    dp.step_phased()
+    assert dp.fused_adam_ranges() == []
+    plain = _trainer("center", opt, "off", batch)
+    plain.step()
+    torch.cuda.synchronize()
+    assert rel_err(to_np(dp.gradParametersG), to_np(plain.gradParametersG)) < 1e-5
+    assert float(dp.gradParametersG.abs().min()) >= 0 and float(dp.gradParametersG.abs().max()) > 0
+
+
+def test_second_backward_without_zeroing_is_refused(oracle, hipb):
+    """the fused form needs a fresh gradient: accumulating onto a gradient that was never written must fail loudly"""
+    from video_filler_amd.trainers import CenterTrainer
+    opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
+    tr = CenterTrainer(opt, seed=3, host="cabi")
+    tr.set_batch(torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))))
+    tr.step()
+    net = tr.netG
+    x = tr._g_in()
+    y = net.forward(x)
+    gy = torch.ones_like(y)
+    assert len(net.set_fused_adam(True)) == 2
+    try:
+        net.zeroGradParameters()
+        net.backward(x, gy)
+        with pytest.raises(Exception, match="one backward per zeroGradParameters"):
+            net.backward(x, gy)
+    finally:
+        net.set_fused_adam(False)

@@ -27,35 +27,9 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import KinkSync, rel_err, to_np
+from helpers import KinkSync, rel_err, to_np, grads_reference_order, to_internal as _to_internal, from_internal as _from_internal
 
 pytestmark = pytest.mark.gpu
-
-
-def _to_internal(net, vec_ref):
-    """reference-order flat vector -> this net's padded channels-last flat layout."""
-    flat = torch.zeros_like(net._flat[0])
-    off = 0
-    for m, name, gname, o, n in net._flat[2]:
-        t = getattr(m, name)
-        seg = torch.from_numpy(vec_ref[off:off + n].copy()).to(flat.device)
-        if t.dim() == 4:
-            seg = seg.reshape(t.shape).permute(0, 2, 3, 1).reshape(-1)
-        flat[o:o + n] = seg
-        off += n
-    return flat
-
-
-def _from_internal(net, flat):
-    parts = []
-    for m, name, gname, o, n in net._flat[2]:
-        t = getattr(m, name)
-        seg = flat[o:o + n]
-        if t.dim() == 4:
-            d0, d1, kH, kW = t.shape
-            seg = seg.view(d0, kH, kW, d1).permute(0, 3, 1, 2).contiguous().reshape(-1)
-        parts.append(seg)
-    return to_np(torch.cat(parts))
 
 
 def _leaves(seq):
@@ -76,7 +50,7 @@ def _check_iteration(ref, tr, it, lrG, lrD, tag, smooth, amp=1.0):
     for net, rnet, gref, pref, st, rst, lr, nm in (
             (tr.netD, ref.netD, ref.gradParametersD, ref.parametersD, tr.optimStateD, ref.optimStateD, lrD, "D"),
             (tr.netG, ref.netG, ref.gradParametersG, ref.parametersG, tr.optimStateG, ref.optimStateG, lrG, "G")):
-        g = to_np(net.reference_flat(grads=True))
+        g = grads_reference_order(tr, net, gref)
         e = rel_err(g, gref)
         assert e <= 1e-4 * amp, "%s it%d grad%s max-norm rel err %.3e" % (tag, it, nm, e)
         sel = np.abs(gref) > 1e-3 * np.abs(gref).max()

@@ -93,6 +93,8 @@ SIGNATURES = {
     "vf_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, vp]),
     "vf_adam_prep": (i32, [vp, f64, f64, f64, vp]),
     "vf_adam_apply": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, vp]),
+    "vf_wgrad_adam_outer_supported": (i32, [i32, i32, i32]),
+    "vf_wgrad_adam_outer": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, f64, f64, f64, vp]),
     "vf_conv_is_fast": (i32, [i32, i32, i32, i32, i32]),
     "vf_conv2d_bwd_weight_planes": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32]),
     "vf_deconv2d_bwd_weight_planes": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32]),
@@ -136,6 +138,9 @@ SIGNATURES = {
     "vf_net_backward_range": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]),
     "vf_net_backward_split": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp)]),
     "vf_net_backward_finish": (i32, [vp]),
+    "vf_net_set_fused_adam": (i32, [vp, i32, C.POINTER(i32)]),
+    "vf_net_fused_adam_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "vf_net_adam_fused": (i32, [vp, vp, vp, f64, f64, f64, vp, i32]),
     "vf_net_set_sync_bn": (i32, [vp, vp, i32, i32]),
     "vf_net_set_weight_planes_managed": (i32, [vp, i32]),
     "vf_net_refresh_weight_planes": (i32, [vp]),

@@ -749,6 +749,15 @@ class HipBackend:
     def adam_apply(self, x, g, m, v, beta1, beta2, eps, t_dev):
         self._c("vf_adam_apply", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), beta1, beta2, eps, _ptr(t_dev))
 
+    def wgrad_adam_outer(self, U, V, x, m, v, g, beta1, beta2, eps, t_dev):
+        """vf_wgrad_adam_outer: the bottleneck weight gradient U^T V (U [K][Nu], V [K][Ncols]) consumed by optim.adam in the
+        kernel that forms it; x, m, v (and g, or None) = [Nu][Ncols] slices, t_dev after adam_prep."""
+        K, Nu = U.shape
+        Ncols = V.shape[1]
+        assert V.shape[0] == K and x.numel() == Nu * Ncols
+        self._c("vf_wgrad_adam_outer", _ptr(U), _ptr(V), K, Nu, Ncols, _ptr(x), _ptr(m), _ptr(v), _ptr(g) if g is not None else None,
+                beta1, beta2, eps, _ptr(t_dev))
+
     # ---- per-kernel timers
     def prof_begin(self):
         self._c("vf_prof_begin")

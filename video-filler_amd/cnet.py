@@ -204,6 +204,28 @@ class CNet(nn.Sequential):
         Bn, Cc, H, W = [d.value for d in dims[:4]]
         return Bn, Cc, H, W
 
+    # ---- optim.adam inside the bottleneck pair's weight gradients (vf_net_set_fused_adam / vf_net_adam_fused)
+    def set_fused_adam(self, on=True):
+        """mark the layers whose weight gradient vf_wgrad_adam_outer takes; returns their [(lo, hi)] slices of the flat vectors
+        (empty: nothing to fuse).  Takes effect from the next backward pass; needs the library net (a forward has run)."""
+        assert self._net is not None, "set_fused_adam after the first forward"
+        lib = _lib.load()
+        cnt = C.c_int()
+        _lib.check(lib.vf_net_set_fused_adam(self._net, 1 if on else 0, C.byref(cnt)))
+        self._fused_ranges = []
+        for i in range(cnt.value):
+            o, n = C.c_int64(), C.c_int64()
+            _lib.check(lib.vf_net_fused_adam_range(self._net, i, C.byref(o), C.byref(n)))
+            self._fused_ranges.append((o.value, o.value + n.value))
+        return list(self._fused_ranges)
+
+    def fused_adam_ranges(self):
+        return list(getattr(self, "_fused_ranges", []))
+
+    def adam_fused(self, m, v, beta1, beta2, eps, t_dev, keep_grad=False):
+        _lib.check(_lib.load().vf_net_adam_fused(self._net, C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), beta1, beta2, eps,
+                                                 C.c_void_p(t_dev.data_ptr()), 1 if keep_grad else 0))
+
     def backward_finish(self):
         if self._net is not None:
             _lib.check(_lib.load().vf_net_backward_finish(self._net))

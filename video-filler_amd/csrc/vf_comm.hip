@@ -90,9 +90,15 @@ static int dtype_of(int dtype, ncclDataType_t* out) {
   return 0;
 }
 
-static int op_of(int op, ncclRedOp_t* out) {
+// The mean over ONE rank is the sum over one rank.  RCCL nevertheless answers ncclAvg on a one-rank communicator with its
+// pre-multiply pass (a kernel that reads and writes the whole bucket to scale it by 1.0: 0.14-0.19 ms per 71 M-float bucket,
+// profiles/r03_g_kernel_stats_center_force_dist_*.csv `oneRankReduce<FuncPreMulSum>`), while an in-place ncclSum there
+// enqueues nothing.  With two or more ranks the factor 1/world rides in the ring's first step and costs no pass of its own.
+static ncclRedOp_t avg_op(const vf_comm* c) { return c->world == 1 ? ncclSum : ncclAvg; }
+
+static int op_of(const vf_comm* c, int op, ncclRedOp_t* out) {
   VF_REQUIRE(op >= 0 && op <= 3, "vf_comm: op %d (0 = sum, 1 = avg, 2 = max, 3 = min)", op);
-  const ncclRedOp_t ops[4] = {ncclSum, ncclAvg, ncclMax, ncclMin};
+  const ncclRedOp_t ops[4] = {ncclSum, avg_op(c), ncclMax, ncclMin};
   *out = ops[op];
   return 0;
 }
@@ -170,7 +176,7 @@ VF_API int vf_comm_allreduce_async(vf_comm* c, vf_ctx* ctx, void* buf, int64_t c
   ncclDataType_t dt;
   ncclRedOp_t ro;
   if (int rc = dtype_of(dtype, &dt)) return rc;
-  if (int rc = op_of(op, &ro)) return rc;
+  if (int rc = op_of(c, op, &ro)) return rc;
   VF_CHECK_HIP(hipEventRecord(c->ready, ctx->stream));
   VF_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
   if (count > 0) VF_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, dt, ro, c->comm, c->stream));
@@ -197,7 +203,7 @@ VF_API int vf_comm_reduce_scatter_avg_async(vf_comm* c, vf_ctx* ctx, float* buf,
   VF_CHECK_HIP(hipEventRecord(c->ready, ctx->stream));
   VF_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
   if (shard_count > 0)
-    VF_CHECK_RCCL(g_rccl.ReduceScatter(buf, buf + (int64_t)c->rank * shard_count, (size_t)shard_count, ncclFloat32, ncclAvg, c->comm, c->stream));
+    VF_CHECK_RCCL(g_rccl.ReduceScatter(buf, buf + (int64_t)c->rank * shard_count, (size_t)shard_count, ncclFloat32, avg_op(c), c->comm, c->stream));
   const int t = (int)(c->issued++ % RING);
   VF_CHECK_HIP(hipEventRecord(c->done[t], c->stream));
   *ticket = t;
@@ -233,7 +239,7 @@ VF_API int vf_comm_allreduce_inline(vf_comm* c, vf_ctx* ctx, void* buf, int64_t 
   ncclDataType_t dt;
   ncclRedOp_t ro;
   if (int rc = dtype_of(dtype, &dt)) return rc;
-  if (int rc = op_of(op, &ro)) return rc;
+  if (int rc = op_of(c, op, &ro)) return rc;
   if (count > 0) VF_CHECK_RCCL(g_rccl.AllReduce(buf, buf, (size_t)count, dt, ro, c->comm, ctx->stream));
   return 0;
 }

@@ -155,6 +155,21 @@ static inline int vf_ilog2(int v) {  // v must be a power of two
 static inline bool vf_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int64_t vf_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// optim/adam.lua's element update, fp32 in the reference's operation order (one definition for k_adam and for the weight-gradient
+// kernel that applies it in its epilogue, vf_wgrad_small.hip): step = lr * sqrt(1 - b2^t) / (1 - b1^t)
+__device__ __forceinline__ void vf_adam_upd(float& xv, float gv, float& mv, float& vv, float b1, float omb1, float b2, float omb2,
+                                            float eps, float step) {
+  float mi = mv * b1;
+  mi = mi + omb1 * gv;
+  float vi = vv * b2;
+  vi = vi + (omb2 * gv) * gv;
+  float d = sqrtf(vi);
+  d = d + eps;
+  mv = mi;
+  vv = vi;
+  xv = xv - (step * mi) / d;
+}
+
 // fused activation
 __device__ __forceinline__ float vf_act_apply(float v, int act, float slope) {
   switch (act) {

@@ -570,17 +570,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ x, const float
                                               float eps, const int32_t* __restrict__ state) {
   const float step = __int_as_float(state[1]);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, n4 = n >> 2;
-  auto upd = [&](float& xv, float gv, float& mv, float& vv) {
-    float mi = mv * b1;
-    mi = mi + omb1 * gv;
-    float vi = vv * b2;
-    vi = vi + (omb2 * gv) * gv;
-    float d = sqrtf(vi);
-    d = d + eps;
-    mv = mi;
-    vv = vi;
-    xv = xv - (step * mi) / d;
-  };
+  auto upd = [&](float& xv, float gv, float& mv, float& vv) { vf_adam_upd(xv, gv, mv, vv, b1, omb1, b2, omb2, eps, step); };
   auto ld = [&](const float* p, int64_t i) {
     if constexpr (NT) return __builtin_nontemporal_load((const f32x4*)p + i);
     else return ((const f32x4*)p)[i];

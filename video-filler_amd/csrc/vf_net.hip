@@ -43,6 +43,8 @@
 
 #include "vf_common.h"
 
+int vf_internal_colsum(vf_ctx* ctx, const float* g, float* gb, int64_t P, int C, float beta);      // vf_bn.hip
+
 namespace {
 
 // where the planes kernels pay: from 3 GFLOP per pass and 1024 GEMM rows; process-wide, like nn.py's gate
@@ -103,6 +105,10 @@ struct Layer {
   float fused_slope = 0.f;
   bool absorbed = false;         // a VF_L_ACT that its producer applies
   bool fresh = true;             // zeroGradParameters(): the next accGradParameters overwrites (beta = 0)
+  // optim.adam in the weight-gradient kernel (vf_net_set_fused_adam): the operands of the gradient the last backward walk left out
+  bool fa = false;               // a layer the fused kernel takes
+  const float *fa_u = nullptr, *fa_v = nullptr;
+  int fa_k = 0;                  // 0: nothing pending (the gradient was accumulated the plain way, or no backward ran)
 };
 
 struct Entry {
@@ -150,6 +156,8 @@ struct vf_net {
     const float *base, *other_base;      // the flat buffers the offsets were computed between
   };
   std::map<const vf_net*, BothTable> both_tables;
+  bool fused_adam = false;         // vf_net_set_fused_adam
+  std::vector<int> fa_layers;
   bool split_pending = false;      // vf_net_backward_split ran: the gradients of the entries below the cut are still recorded
   std::string pending_bias;        // (their deferred bias gradients, as a byte image of Deferred[])
   std::vector<void*> owned;        // parameter-lifetime allocations
@@ -372,6 +380,19 @@ int conv_acc(vf_net* n, Layer& l, const float* x, const float* go, int Bn, std::
     deferred->push_back(Deferred{go, gb, (int64_t)Bn * l.Ho * l.Wo, l.Co, beta});
     gb = nullptr;
   }
+  VF_REQUIRE(!(n->fused_adam && l.fa && l.fa_k > 0 && beta != 0.f),
+             "fused Adam: a second backward pass accumulates onto a weight gradient that was never written (one backward per zeroGradParameters)");
+  if (n->fused_adam && l.fa && beta == 0.f) {
+    // the weight gradient is formed by vf_net_adam_fused, in the kernel that applies it: U = the 1x1-map side, V = the 4x4-map side
+    l.fa_u = full ? x : go;
+    l.fa_v = full ? go : x;
+    l.fa_k = Bn;
+    l.g_seen = nullptr;
+    l.gp_seen = nullptr;
+    if (!gb) return 0;
+    return vf_internal_colsum(ctx, go, gb, (int64_t)Bn * l.Ho * l.Wo, l.Co, beta);
+  }
+  l.fa_k = 0;
   const bool planes = g_pwgrad && !g_no_pconv && l.x_seen == x && l.xp_seen && l.g_seen == go && l.gp_seen;
   const void *xp = l.xp_seen, *gp = l.gp_seen;
   l.g_seen = nullptr;        // single use: only a data-gradient pass of THIS walk may hand its planes over
@@ -885,7 +906,10 @@ VF_API int vf_net_training(vf_net* n, int train) {
 }
 VF_API int vf_net_zero_grad(vf_net* n) {      // lazily: the next accGradParameters of each module overwrites
   VF_REQUIRE(n != nullptr, "vf_net_zero_grad: NULL net");
-  for (Layer& l : n->L) l.fresh = true;
+  for (Layer& l : n->L) {
+    l.fresh = true;
+    l.fa_k = 0;
+  }
   return 0;
 }
 // netX:apply(function(m) if torch.type(m):find('Convolution') then m.bias:zero() end end) (train.lua:279-280): one launch
@@ -1101,6 +1125,51 @@ VF_API int vf_net_backward_finish(vf_net* n) {
   memcpy(rest.data(), n->pending_bias.data(), n->pending_bias.size());
   n->pending_bias.clear();
   return bias_grad_flush(n, rest);
+}
+// ---- optim.adam inside the bottleneck pair's weight gradients (vf_wgrad_adam_outer, vf_wgrad_small.hip)
+static bool fused_adam_shape(const Layer& l) {
+  if (!is_conv(l) || l.d.k != 4 || l.d.stride != 1 || l.d.pad != 0 || l.w_off < 0 || (l.w_off & 3)) return false;
+  const bool full = is_full(l);
+  const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
+  const bool maps = full ? (l.H == 1 && l.W == 1 && l.Ho == 4 && l.Wo == 4) : (l.H == 4 && l.W == 4 && l.Ho == 1 && l.Wo == 1);
+  return maps && vf_wgrad_adam_outer_supported(1, Nu, 16 * Cv) && (int64_t)Nu * 16 * Cv == l.w_n;
+}
+VF_API int vf_net_set_fused_adam(vf_net* n, int on, int* count) {
+  VF_REQUIRE(n != nullptr, "vf_net_set_fused_adam: NULL net");
+  n->fa_layers.clear();
+  for (size_t i = 0; i < n->L.size(); ++i) {
+    Layer& l = n->L[i];
+    l.fa = on && fused_adam_shape(l);
+    l.fa_k = 0;
+    if (l.fa) n->fa_layers.push_back((int)i);
+  }
+  n->fused_adam = !n->fa_layers.empty();
+  if (count) *count = (int)n->fa_layers.size();
+  return 0;
+}
+VF_API int vf_net_fused_adam_range(const vf_net* n, int i, int64_t* offset, int64_t* length) {
+  VF_REQUIRE(n && offset && length && i >= 0 && i < (int)n->fa_layers.size(), "vf_net_fused_adam_range: layer %d of %d", i,
+             n ? (int)n->fa_layers.size() : 0);
+  const Layer& l = n->L[n->fa_layers[i]];
+  *offset = l.w_off;
+  *length = l.w_n;
+  return 0;
+}
+VF_API int vf_net_adam_fused(vf_net* n, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad) {
+  VF_REQUIRE(n && m && v && t_dev, "vf_net_adam_fused: NULL argument");
+  for (int i : n->fa_layers) {
+    Layer& l = n->L[i];
+    const bool full = is_full(l);
+    const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
+    float *x = n->params + l.w_off, *g = n->grads + l.w_off;
+    int rc;
+    if (l.fa_k > 0) rc = vf_wgrad_adam_outer(n->ctx, l.fa_u, l.fa_v, l.fa_k, Nu, 16 * Cv, x, m + l.w_off, v + l.w_off, keep_grad ? g : nullptr,
+                                             beta1, beta2, eps, t_dev);
+    else rc = vf_adam_apply(n->ctx, x, g, m + l.w_off, v + l.w_off, l.w_n, beta1, beta2, eps, t_dev);
+    l.fa_k = 0;
+    if (rc) return rc;
+  }
+  return 0;
 }
 // net:updateGradInput(input, gradOutput): gradInput only (parameter gradients untouched; train.lua:366)
 VF_API int vf_net_update_grad_input(vf_net* n, const float* x, const float* gy, const float** gx) {

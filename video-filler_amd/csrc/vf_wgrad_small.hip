@@ -29,9 +29,21 @@ namespace {
 // NJ = column blocks per wave (float2 / float4 of V per lane): 2 -> a 64 x 64 wave tile, 4 accumulator tiles (64 AGPRs: four or
 // five waves per SIMD cover the L2 latency of the operand loads by themselves); 4 -> 64 x 128 (one wave per SIMD: slower, kept
 // for the record)
-template <int NJ>
-__global__ __launch_bounds__(256) void k_wgrad_smallk(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ dW,
-                                                      int K, int Nu, int Ncols, int tiles_c, float beta) {
+// FUSE: optim.adam applied in the epilogue (vf_wgrad_adam_outer): the gradient never makes the round trip through memory —
+// 24 B per weight (x, m, v read and written) instead of 4 (this kernel's store) + 28 (k_adam); A.g != NULL also stores it.
+struct VfAdamFuse {
+  float *x, *m, *v, *g;
+  const int32_t* state;       // k_adam_prep's: [1] = bit pattern of the step size
+  float b1, omb1, b2, omb2, eps;
+  int round_bf16;             // operands rounded to bf16 (nearest even) on their way in: the arithmetic of matrix-core mode 1
+};
+__device__ __forceinline__ float ws_rne(float f) {
+  const unsigned u = __float_as_uint(f);
+  return __uint_as_float(((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16) << 16);
+}
+template <int NJ, bool FUSE = false>
+__global__ __launch_bounds__(256, FUSE ? 3 : 1) void k_wgrad_smallk(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ dW,
+                                                      int K, int Nu, int Ncols, int tiles_c, float beta, const VfAdamFuse A) {
   typedef float fvec __attribute__((ext_vector_type(NJ)));
   const int lane = threadIdx.x & 63;
   const int wt = blockIdx.x * 4 + (threadIdx.x >> 6);         // wave tile: column tiles fastest (the four waves share U rows)
@@ -66,10 +78,18 @@ __global__ __launch_bounds__(256) void k_wgrad_smallk(const float* __restrict__ 
     p.ma = (live && okA) ? 1.f : 0.f;
   };
   auto mm = [&](const Pair& p) {
-    const f32x2 a = p.a * p.ma;
+    f32x2 a = p.a * p.ma;
     fvec b;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) b[j] = p.b[j] * p.mb;
+    if constexpr (FUSE) {
+      if (A.round_bf16) {
+        a[0] = ws_rne(a[0]);
+        a[1] = ws_rne(a[1]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = ws_rne(b[j]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -109,8 +129,51 @@ __global__ __launch_bounds__(256) void k_wgrad_smallk(const float* __restrict__ 
         *(fvec*)o = v;
       }
   };
-  if (beta != 0.f) store_all(VfIntC<1>{});
-  else store_all(VfIntC<0>{});
+  if constexpr (FUSE) {
+    // four rows at a time: their x, m, v (12 loads of NJ floats, 256-byte runs per half wave) are in flight together, three
+    // waves per SIMD cover for one another
+    const float step = __int_as_float(A.state[1]);
+    const int cofs = c0 + NJ * lr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rb = 0; rb < 16; rb += 4) {
+        // r = rb + q: row n0 + 2 * (q + 8 * (rb >> 2) + 4 * lh) + i
+        const int nb = n0 + 2 * (8 * (rb >> 2) + 4 * lh) + i;
+        fvec xv[4], mv[4], vv[4];
+        int off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 2 * q;
+          off[q] = (n < Nu ? n : n0) * Ncols + cofs;
+          xv[q] = *(const fvec*)(A.x + off[q]);
+          mv[q] = *(const fvec*)(A.m + off[q]);
+          vv[q] = *(const fvec*)(A.v + off[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (nb + 2 * q >= Nu) continue;
+          fvec gv;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            gv[j] = acc[i][j][rb + q];
+            float xe = xv[q][j], me = mv[q][j], ve = vv[q][j];
+            vf_adam_upd(xe, gv[j], me, ve, A.b1, A.omb1, A.b2, A.omb2, A.eps, step);
+            xv[q][j] = xe;
+            mv[q][j] = me;
+            vv[q][j] = ve;
+          }
+          *(fvec*)(A.x + off[q]) = xv[q];
+          *(fvec*)(A.m + off[q]) = mv[q];
+          *(fvec*)(A.v + off[q]) = vv[q];
+          if (A.g) *(fvec*)(A.g + off[q]) = gv;
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (the next rows' loads stay behind these stores)
+      }
+  } else {
+    if (beta != 0.f) store_all(VfIntC<1>{});
+    else store_all(VfIntC<0>{});
+  }
 }
 
 }  // namespace
@@ -131,9 +194,39 @@ int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float*
   const int64_t wtiles = (int64_t)tiles_c * tiles_r;
   VfProf prof(ctx, "wgrad_smallk_f32", 2.0 * (double)K * Nu * Ncols, 4.0 * ((double)Nu * Ncols * (beta != 0.f ? 2 : 1) + (double)K * (Nu + Ncols)));
   if (nj == 4)
-    hipLaunchKernelGGL(k_wgrad_smallk<4>, dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), 0, ctx->stream, U, V, dW, K, Nu, Ncols, tiles_c, beta);
+    hipLaunchKernelGGL((k_wgrad_smallk<4, false>), dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), 0, ctx->stream, U, V, dW, K, Nu, Ncols, tiles_c, beta, VfAdamFuse{});
   else
-    hipLaunchKernelGGL(k_wgrad_smallk<2>, dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), 0, ctx->stream, U, V, dW, K, Nu, Ncols, tiles_c, beta);
+    hipLaunchKernelGGL((k_wgrad_smallk<2, false>), dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), 0, ctx->stream, U, V, dW, K, Nu, Ncols, tiles_c, beta, VfAdamFuse{});
+  VF_LAUNCH_CHECK();
+  return 0;
+}
+
+// The bottleneck pair's weight gradient with optim.adam in its epilogue:  g = sum_k U[k][:]^T V[k][:]  (K = batch) is formed in the
+// matrix-core accumulators and consumed there — x, m, v [Nu][Ncols] are read and written once (24 B per weight; + 4 when g, which
+// may be NULL, is stored too), where the two-kernel form writes g, then reads it again beside x, m, v (32 B).  t_dev is the
+// optimiser's device state AFTER vf_adam_prep (the step size of this update), as for vf_adam_apply.  Returns 2 (an error) for a
+// shape the kernel does not take: ask vf_wgrad_adam_outer_supported first.
+VF_API int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols) {
+  return K >= 1 && Ncols % 128 == 0 && Nu % 2 == 0 && Nu >= 64 && (int64_t)Nu * Ncols < ((int64_t)1 << 31);
+}
+VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v,
+                               float* g, double beta1, double beta2, double eps, const int32_t* t_dev) {
+  VF_REQUIRE(ctx && U && V && x && m && v && t_dev, "vf_wgrad_adam_outer: NULL argument");
+  VF_REQUIRE(vf_wgrad_adam_outer_supported(K, Nu, Ncols), "vf_wgrad_adam_outer: K %d, %d x %d is not this kernel's shape", K, Nu, Ncols);
+  VF_REQUIRE(!(((uintptr_t)U) & 7) && !((((uintptr_t)V) | ((uintptr_t)x) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)g)) & 15),
+             "vf_wgrad_adam_outer: operands must be 16-byte aligned");
+  VfAdamFuse A;
+  A.x = x; A.m = m; A.v = v; A.g = g;
+  A.state = t_dev;
+  A.b1 = (float)beta1; A.omb1 = (float)(1.0 - beta1);
+  A.b2 = (float)beta2; A.omb2 = (float)(1.0 - beta2);
+  A.eps = (float)eps;
+  A.round_bf16 = ctx->mfma_bf16 == 1;
+  const int tiles_c = Ncols / 64, tiles_r = (int)vf_cdiv(Nu, 64);
+  const int64_t wtiles = (int64_t)tiles_c * tiles_r;
+  const double n = (double)Nu * Ncols;
+  VF_LAUNCH_TIMED(ctx, "wgrad_adam_outer", 2.0 * K * n, (g ? 28.0 : 24.0) * n + 4.0 * K * ((double)Nu + Ncols), (k_wgrad_smallk<2, true>),
+                  dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), U, V, (float*)nullptr, K, Nu, Ncols, tiles_c, 0.f, A);
   VF_LAUNCH_CHECK();
   return 0;
 }

@@ -90,6 +90,11 @@ int vf_net_update_grad_input_group(vf_net* net, const float* x, const float* gy,
 int vf_net_plan_size(const vf_net* net);
 int vf_net_bucket_split(const vf_net* net, double frac, int* plan_index, int64_t* flat_offset);
 int vf_net_backward_range(vf_net* net, const float* x, const float* gy, int hi, int lo, int need_input_grad, const float** gx);
+int vf_net_set_fused_adam(vf_net* net, int on, int* count);
+int vf_net_fused_adam_range(const vf_net* net, int i, int64_t* offset, int64_t* length);
+int vf_net_adam_fused(vf_net* net, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad);
+int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols);
+int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v, float* g, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);
 int vf_net_set_weight_planes_managed(vf_net* net, int on);
 int vf_net_refresh_weight_planes(vf_net* net);
@@ -746,6 +751,41 @@ function hipnn.adam(opfunc, x, state)
    check(C.vf_adam_step(hipnn.ctx, fptr(x), fptr(dfdx), fptr(state.m), fptr(state.v), x:nElement(),
                         state.learningRate or 0.001, state.beta1 or 0.9, state.beta2 or 0.999, state.epsilon or 1e-8,
                         ffi.cast('int32_t*', state.t_dev:data())))
+   return x, { fx }
+end
+
+-- optim.adam(opfunc, x, state) for a hipnn.Net whose bottleneck pair (train.lua:104,134: 92 % of the generator's weights) is
+-- updated INSIDE the kernel that forms its weight gradient (vf_net_adam_fused): those two slices of dfdx are not written unless
+-- keepGrad; everything else gets the plain one-pass update.  Single device (a data-parallel step needs the gradient on the wire).
+--    hipnn.adamFused(fGx, parametersG, optimStateG, netG)
+function hipnn.adamFused(opfunc, x, state, net, keepGrad)
+   local cnt = ffi.new('int[1]')
+   check(C.vf_net_set_fused_adam(net.h, 1, cnt))
+   if cnt[0] == 0 then return hipnn.adam(opfunc, x, state) end
+   local ok, fx, dfdx = pcall(opfunc, x)
+   if not ok then C.vf_net_set_fused_adam(net.h, 0, cnt); error(fx, 0) end
+   state.m = state.m or x.new(dfdx:size()):zero()
+   state.v = state.v or x.new(dfdx:size()):zero()
+   state.t_dev = state.t_dev or hipnn.IntTensor(2):zero()
+   local b1, b2, eps = state.beta1 or 0.9, state.beta2 or 0.999, state.epsilon or 1e-8
+   local t = ffi.cast('int32_t*', state.t_dev:data())
+   check(C.vf_adam_prep(hipnn.ctx, state.learningRate or 0.001, b1, b2, t))
+   local ranges, off, len = {}, ffi.new('int64_t[1]'), ffi.new('int64_t[1]')
+   for i = 0, cnt[0] - 1 do
+      check(C.vf_net_fused_adam_range(net.h, i, off, len))
+      ranges[#ranges + 1] = { tonumber(off[0]), tonumber(off[0] + len[0]) }
+   end
+   table.sort(ranges, function(a, b) return a[1] < b[1] end)
+   ranges[#ranges + 1] = { x:nElement(), x:nElement() }
+   local pos = 0
+   for _, r in ipairs(ranges) do
+      if r[1] > pos then
+         check(C.vf_adam_apply(hipnn.ctx, fptr(x) + pos, fptr(dfdx) + pos, fptr(state.m) + pos, fptr(state.v) + pos, r[1] - pos, b1, b2, eps, t))
+      end
+      pos = r[2]
+   end
+   check(C.vf_net_adam_fused(net.h, fptr(state.m), fptr(state.v), b1, b2, eps, t, keepGrad and 1 or 0))
+   check(C.vf_net_set_fused_adam(net.h, 0, cnt))
    return x, { fx }
 end
 

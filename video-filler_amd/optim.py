@@ -63,3 +63,26 @@ def adam_update_split(x, dfdx, state, side_ranges, side):
             B.adam_apply(x[pos:lo], dfdx[pos:lo], m[pos:lo], v[pos:lo], beta1, beta2, eps, t_dev)
         pos = hi
     bump_param_version(x)
+
+
+def adam_update_fused(x, dfdx, state, net, keep_grad=False):
+    """adam_update for a net whose bottleneck weight gradients were left to the optimiser (cnet.CNet.set_fused_adam): the plain
+    one-pass update everywhere else, vf_wgrad_adam_outer on those slices — their gradient is formed in the matrix-core accumulators
+    and consumed there (24 B per weight instead of 32; dfdx receives it only with keep_grad).  Element for element the update of
+    adam_update, given the same gradient."""
+    B = get_backend()
+    lr = state.get("learningRate", 0.001)
+    beta1 = state.get("beta1", 0.9)
+    beta2 = state.get("beta2", 0.999)
+    eps = state.get("epsilon", 1e-8)
+    adam_init(x, state)
+    state["t"] += 1
+    m, v, t_dev = state["m"], state["v"], state["t_dev"]
+    B.adam_prep(lr, beta1, beta2, t_dev)
+    pos = 0
+    for lo, hi in sorted(net.fused_adam_ranges()) + [(x.numel(), x.numel())]:
+        if lo > pos:
+            B.adam_apply(x[pos:lo], dfdx[pos:lo], m[pos:lo], v[pos:lo], beta1, beta2, eps, t_dev)
+        pos = hi
+    net.adam_fused(m, v, beta1, beta2, eps, t_dev, keep_grad)
+    bump_param_version(x)

@@ -260,6 +260,11 @@ class _TrainerBase:
         self._inflight = []          # async all-reduce handles of G's gradient buckets
         self._gen = None
         self._force_comm = False     # run the exchange even at world == 1 (exercises the DP path on one GPU)
+        # optim.adam(fGx) with the bottleneck pair's weight gradients consumed inside the kernel that forms them
+        # (optim.adam_update_fused; single device, the C-ABI host): "on" (default; gradParametersG does not receive those two
+        # slices), "keep" (it does: 28 B per weight instead of 24), "off" (accGradParameters + the plain one-pass update, 32 B)
+        self.fuse_adam = os.environ.get("VF_FUSE_ADAM", "on")
+        assert self.fuse_adam in ("on", "keep", "off"), "VF_FUSE_ADAM: on | keep | off"
         self.defer_adam_g = False
         self.adam_overlap = False    # enable_adam_overlap(): Adam(G)'s two big weight tensors beside the next encoder forward
         self.side_a = None
@@ -406,8 +411,31 @@ class _TrainerBase:
             if (self.defer_adam_g and self.side_g is not None) or self.adam_overlap:
                 self.fGx(self.parametersG)
                 self._pending_g = True
+            elif self._fuse_adam_ranges():
+                try:
+                    self.fGx(self.parametersG)
+                    optim.adam_update_fused(self.parametersG, self.gradParametersG, self.optimStateG, self.netG, self.fuse_adam == "keep")
+                finally:
+                    self.netG.set_fused_adam(False)        # (closures called outside step() accumulate the plain way)
             else:
                 optim.adam(self.fGx, self.parametersG, self.optimStateG)
+
+    def _fuse_adam_ranges(self):
+        """marks netG's bottleneck pair for the fused update when this step may use it; the slices it covers (empty: plain update)"""
+        from .cnet import CNet
+        if self.fuse_adam == "off" or not isinstance(self.netG, CNet) or self.netG._net is None or self._comm_on() or self.shard_adam:
+            return []
+        return self.netG.set_fused_adam(True)
+
+    def fused_adam_ranges(self):
+        """[(lo, hi)] of gradParametersG that step() leaves unwritten (fuse_adam == "on"); for readers of the gradient vector"""
+        from .cnet import CNet
+        if self.fuse_adam != "on" or not isinstance(self.netG, CNet) or self.netG._net is None or self._comm_on() or self.shard_adam \
+                or self.defer_adam_g or self.adam_overlap:
+            return []
+        r = self.netG.set_fused_adam(True)
+        self.netG.set_fused_adam(False)
+        return r
 
     # -- Adam(G) beside the next iteration's encoder forward (single device).  92 % of the generator's parameters are
     #    the two bottleneck weight tensors (E6, D1: 32.8 M each); the first layer that reads either is E6.  The update of
