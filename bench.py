@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--no-batch-d", action="store_true", help="N=1: run netD's real and fake passes separately (default: one batch "
                     "of 2B with BatchNorm in two groups; same arithmetic per sample)")
     ap.add_argument("--batch-d", action="store_true", help="(default now at N=1; kept so that older command lines still parse)")
+    ap.add_argument("--fuse-adam", default="on", choices=["on", "keep", "off"], help="N=1: optim.adam(fGx) applied to the two bottleneck weight "
+                    "tensors inside the kernel that forms their gradient (vf_wgrad_adam_outer: 24 B per weight instead of 32). on (default): "
+                    "gradParametersG does not receive those two slices; keep: it does (28 B); off: accGradParameters + the plain update")
     ap.add_argument("--adam-overlap", action="store_true", help="N=1: update Adam(G)'s two bottleneck weight tensors on a side stream "
                     "beside the next encoder forward (measured: -4 %%: the 2048-block HBM stream slows the convolutions it shares "
                     "the chip with by more than it hides)")
@@ -190,6 +193,7 @@ def main():
 
     dp = world > 1 or args.force_dist
     tr.force_comm = args.force_dist
+    tr.fuse_adam = args.fuse_adam
     if args.no_batch_d and tr.batch_d:
         tr.set_batch_d(False)
     use_graph = not args.no_graph and not (dp and args.sync_bn)
@@ -303,7 +307,11 @@ def main():
         top_family = max(fam, key=fam.get)
         name, dom = max(((n, k) for n, k in kernels.items() if family(n) == top_family), key=lambda kv: kv[1]["ms"])
         avg_ms = dom["ms"] / dom["launches"]
-        if dom["flops"] > 0:
+        # which roofline bounds it: a kernel that reports both its algorithmic FLOPs and bytes is priced against the LONGER of the
+        # two floors (configs[4]'s batch-4 passes over a 629 MB weight tensor are matrix-core kernels bounded by the weight read)
+        t_mfma = dom["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12)
+        t_hbm = dom["bytes"] / (PEAK_HBM_GBS * 1e9)
+        if dom["flops"] > 0 and t_mfma >= t_hbm:
             ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, avg_launch_us=round(avg_ms * 1e3, 2),
@@ -435,7 +443,9 @@ def main():
                        "mfma": {"f32_3xbf16": "fp32 operands split exactly into 3 bf16 planes, 6 cross terms on v_mfma_f32_32x32x16_bf16, "
                                               "f32 accumulate (fp32-grade: same parity tolerances as native)",
                                 "f32": "native v_mfma_f32_32x32x2_f32", "bf16": "operands rounded to bf16"}[args.mfma],
-                       "adam_G": "bottleneck weight tensors on a side stream beside the next encoder forward" if tr.adam_overlap else "one launch at the end of the iteration",
+                       "adam_G": ("bottleneck weight tensors on a side stream beside the next encoder forward" if tr.adam_overlap else
+                                  ("the bottleneck pair's update inside its weight-gradient kernel (vf_wgrad_adam_outer%s), one launch for the rest"
+                                   % ("; gradient also stored" if tr.fuse_adam == "keep" else "") if tr.fuse_adam_slices() else "one launch at the end of the iteration")),
                        "netD_passes": "real+fake as one batch of 2B, BatchNorm per half" if tr.batch_d else "separate (as the reference)",
                        "host": ("vf_net_* (C-ABI net object: forward / backward / updateGradInput are one library call each)" if tr.host == "cabi"
                                 else "nn.py mirror (module by module over the C-ABI)"),

@@ -105,9 +105,10 @@ def test_trainer_modes_walk_the_same_trajectory(kind, B, oracle, hipb, planes_ga
     cap.capture(warmup=2)
     cap.replay()
     torch.cuda.synchronize()
-    assert on.fused_adam_ranges() and len(on.fused_adam_ranges()) == 2 and not off.fused_adam_ranges()
+    assert len(on.fused_adam_ranges()) == 2 and not off.fused_adam_ranges() and not keep.fused_adam_ranges()
+    assert keep.fuse_adam_slices() == on.fuse_adam_slices() == on.fused_adam_ranges() and not off.fuse_adam_slices()
     ranges = on.fused_adam_ranges()
-    assert sum(hi - lo for lo, hi in ranges) > 0.5 * on.parametersG.numel()        # the pair is most of the generator
+    assert all(hi - lo == 16 * opt["nBottleneck"] * 8 * opt.get("nef", 64) for lo, hi in ranges)      # E6 and D1 (nef == ngf here)
     for a, b, c in zip(_persistent(on), _persistent(keep), _persistent(cap)):
         assert torch.equal(a, b) and torch.equal(a, c)
     # "keep" writes the whole gradient vector; "on" everything but the two slices (which keep what was there: zeros)

@@ -1361,33 +1361,36 @@ template <int BM, int BN, int WM, int WN, int BF>
 static void launch_igemm_tile_m(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, int v, const char* name, double flops,
                                 bool db = false) {
   dim3 block(256);
+  // algorithmic bytes: both operands and the output once (small-batch passes over the bottleneck weights are bounded by these,
+  // not by the matrix pipe: bench.py prices a kernel against whichever of its two rooflines is the longer)
+  const double bytes = (double)g.a_bytes + (double)g.w_bytes + 4.0 * (double)g.out_elems;
   if constexpr (BF == 3 && BM == 64 && BN == 64) {
     if (db && v == 2) {
       if (!bkm)
-        VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, 3, false, true>), grid, block, g);
+        VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, false, 2, 3, false, true>), grid, block, g);
       else
-        VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 2, 3, false, true>), grid, block, g);
+        VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, true, 2, 3, false, true>), grid, block, g);
       return;
     }
   }
   if constexpr (BM == 64 && BN == 128) {
     if (g.klin && !bkm && v == 2) {
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, BF, true>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, false, 2, BF, true>), grid, block, g);
       return;
     }
   }
   if (!bkm) {
     if (v == 2)
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 2, BF>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, false, 2, BF>), grid, block, g);
     else
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, false, 0, BF>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, false, 0, BF>), grid, block, g);
   } else {
     if (v == 2)
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 2, BF>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, true, 2, BF>), grid, block, g);
     else if (v == 1)
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 1, BF>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, true, 1, BF>), grid, block, g);
     else
-      VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_igemm<BM, BN, WM, WN, true, 0, BF>), grid, block, g);
+      VF_LAUNCH_TIMED(ctx, name, flops, bytes, (k_igemm<BM, BN, WM, WN, true, 0, BF>), grid, block, g);
   }
 }
 template <int BM, int BN, int WM, int WN>

