@@ -134,8 +134,9 @@ def test_trainer_modes_walk_the_same_trajectory(kind, B, oracle, hipb, planes_ga
         lr = keep1.optimStateG["learningRate"]
         sel = off1.gradParametersG.abs() > 1e-3 * off1.gradParametersG.abs().max()
         assert float((keep1.parametersG - off1.parametersG).abs()[sel].max()) <= 0.02 * lr
-    for k in ("errD", "errG", "errG_l2"):
-        assert on.losses()[k] == keep.losses()[k] == cap.losses()[k]
+    for k in ("errD", "errG", "errG_l2"):       # (the criteria sum in double with atomics: equal to the last few bits, not bit for bit)
+        assert abs(on.losses()[k] - keep.losses()[k]) <= 1e-12 * abs(keep.losses()[k])
+        assert abs(on.losses()[k] - cap.losses()[k]) <= 1e-12 * abs(keep.losses()[k])
 
 
 def test_fused_update_is_left_out_where_it_does_not_apply(oracle, hipb):

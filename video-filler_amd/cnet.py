@@ -118,7 +118,7 @@ class CNet(nn.Sequential):
             Bn, Cc, H, W = shape
             _lib.check(lib.vf_net_reshape(self._net, Bn, Cc, H, W))
             self._shape = shape
-            self._push("groups", self._groups, lambda v: lib.vf_net_set_batch_groups(self._net, v))
+        self._push("groups", self._groups, lambda v: lib.vf_net_set_batch_groups(self._net, v))
         self._push("train", bool(self.train), lambda v: lib.vf_net_training(self._net, 1 if v else 0))
         self._push("managed", bool(self._wp_managed), lambda v: lib.vf_net_set_weight_planes_managed(self._net, 1 if v else 0))
         _lib.check(lib.vf_net_set_planes_gate(float(nn._PCONV_MIN_GFLOP), int(nn._PCONV_MIN_ROWS)))      # (process-wide on both sides)
