@@ -308,6 +308,12 @@ int vf_adam_apply(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int
 int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols);
 int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v,
                         float* g, double beta1, double beta2, double eps, const int32_t* t_dev);
+/* the same with the batch rows gathered from several ranks (data parallel): row k lives in segment k / rows_per_seg at row
+ * k % rows_per_seg of it, the segments seg_stride floats apart (U and V both); g = gscale * sum (1 / world: the mean over ranks).
+ * K % rows_per_seg == 0, seg_stride % 4 == 0; U, V 8-byte aligned. */
+int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu,
+                                 int Ncols, float* x, float* m, float* v, float* g, float gscale, double beta1, double beta2,
+                                 double eps, const int32_t* t_dev);
 
 /* ---- batch preparation and the inference tile loop (the data formats either side of the closures) ---------
  * train.lua:284-298: from the loader's batch (B x C x fs x fs planar, [-1,1]) produce the NHWC generator input with
@@ -502,6 +508,16 @@ int vf_net_backward_finish(vf_net* net);
 int vf_net_set_fused_adam(vf_net* net, int on, int* count);
 int vf_net_fused_adam_range(const vf_net* net, int i, int64_t* offset, int64_t* length);
 int vf_net_adam_fused(vf_net* net, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad);
+/* Data parallel with the fused update: the two weight gradients (92 % of the generator's bytes) are NOT exchanged.  Each rank packs
+ * the operands they are the product of — batch x (Nu + Ncols) floats per layer, 6 MB at batchSize 64 against 262 MB of gradient —
+ * into its segment of a gather buffer (vf_net_fused_adam_pack, after the backward pass; vf_net_fused_adam_pack_size floats, a
+ * multiple of 4), the host all-gathers the segments (vf_comm_allgather_async), and vf_net_adam_fused_gathered forms the gradient
+ * of the GLOBAL batch in the fused kernel on every rank (world * batch rows, scaled by 1 / world: the mean over ranks, the same
+ * bits on every rank) and applies the update.  The rest of the flat gradient is all-reduced as before. */
+int vf_net_fused_adam_pack_size(const vf_net* net, int64_t* floats);
+int vf_net_fused_adam_pack(vf_net* net, float* segment);
+int vf_net_adam_fused_gathered(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1,
+                               double beta2, double eps, const int32_t* t_dev, int keep_grad);
 /* SyncBN: BatchNorm sums all-reduced over `comm` (world ranks; statistics of the global batch).  force: take that path at world 1
  * too.  comm NULL / world 1 / force 0: device-local statistics. */
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);

@@ -62,6 +62,35 @@ def test_fused_kernel_is_accgrad_then_adam(K, Nu, Ncols, hipb):
     assert float((x1 - _state(hipb, n, 7)[0]).abs().max()) > 0
 
 
+@pytest.mark.parametrize("world,K,Nu,Ncols", [(2, 4, 64, 128), (4, 3, 66, 256), (8, 64, 128, 1024), (1, 5, 64, 128)])
+def test_gathered_operands_give_the_mean_gradient_of_the_ranks(world, K, Nu, Ncols, hipb):
+    """data parallel without exchanging the gradient: every rank's operands side by side (one segment per rank, as
+    vf_comm_allgather_async leaves them) -> the mean over ranks of U_r^T V_r, formed and consumed in the fused kernel"""
+    pad4 = lambda n: (n + 3) & ~3
+    u_off, v_off = 0, pad4(K * Nu)
+    seg = v_off + pad4(K * Ncols) + 8                      # (some slack: segments need not be dense)
+    gen = torch.Generator().manual_seed(world * 100 + K)
+    buf = torch.randn(world * seg, generator=gen).to(hipb.device)
+    n = Nu * Ncols
+    lr, b1, b2, eps = 2e-4, 0.5, 0.999, 1e-8
+    x1, m1, v1, t1 = _state(hipb, n, 9)
+    g1 = torch.zeros(n, device=hipb.device)
+    hipb.adam_prep(lr, b1, b2, t1)
+    hipb.wgrad_adam_outer_gathered(buf, u_off, v_off, world, K, seg, Nu, Ncols, x1, m1, v1, g1, b1, b2, eps, t1)
+    h = buf.double().cpu().numpy()
+    want = np.zeros((Nu, Ncols))
+    for r in range(world):
+        U = h[r * seg + u_off:r * seg + u_off + K * Nu].reshape(K, Nu)
+        V = h[r * seg + v_off:r * seg + v_off + K * Ncols].reshape(K, Ncols)
+        want += U.T @ V
+    want /= world
+    assert rel_err(to_np(g1).reshape(Nu, Ncols), want) < 2e-6
+    x2, m2, v2, t2 = _state(hipb, n, 9)
+    hipb.adam_prep(lr, b1, b2, t2)
+    hipb.adam_apply(x2, g1, m2, v2, b1, b2, eps, t2)
+    assert torch.equal(x1, x2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
 def test_unsupported_shapes_are_refused(hipb):
     for K, Nu, Ncols in ((4, 62, 128), (4, 65, 128), (4, 64, 192), (0, 64, 128)):
         assert hipb.lib.vf_wgrad_adam_outer_supported(K, Nu, Ncols) == 0
@@ -139,8 +168,10 @@ def test_trainer_modes_walk_the_same_trajectory(kind, B, oracle, hipb, planes_ga
         assert abs(on.losses()[k] - cap.losses()[k]) <= 1e-12 * abs(keep.losses()[k])
 
 
-def test_fused_update_is_left_out_where_it_does_not_apply(oracle, hipb):
-    """a data-parallel step (the gradient must travel) and the module-by-module host keep accGradParameters + the plain update"""
+def test_data_parallel_step_gathers_operands_instead_of_reducing_the_pair(oracle, hipb):
+    """the phased data-parallel step on one rank: the bottleneck pair's slices are not exchanged (their operands are packed,
+    all-gathered — the identity on one rank — and consumed by the fused kernel), everything else is all-reduced; the trajectory is
+    the single-device one bit for bit.  The module-by-module host keeps accGradParameters + the plain update."""
     from helpers import attach_world1_comm
     opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
     batch = (torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5))),)
@@ -148,15 +179,30 @@ def test_fused_update_is_left_out_where_it_does_not_apply(oracle, hipb):
     mirror.step()
     assert mirror.fused_adam_ranges() == []
     attach_world1_comm(hipb)
-    dp = _trainer("center", opt, "on", batch)
-    dp.force_comm = True
-    dp.step_phased()
-    assert dp.fused_adam_ranges() == []
-    plain = _trainer("center", opt, "off", batch)
-    plain.step()
+    dp, dpk, plain = _trainer("center", opt, "on", batch), _trainer("center", opt, "keep", batch), _trainer("center", opt, "on", batch)
+    dp.force_comm = dpk.force_comm = True
+    for _ in range(3):
+        dp.step_phased()
+        dpk.step_phased()
+        plain.step()
     torch.cuda.synchronize()
-    assert rel_err(to_np(dp.gradParametersG), to_np(plain.gradParametersG)) < 1e-5
-    assert float(dp.gradParametersG.abs().min()) >= 0 and float(dp.gradParametersG.abs().max()) > 0
+    ranges = dp.fused_adam_ranges()
+    assert len(ranges) == 2 and ranges == plain.fused_adam_ranges() and dpk.fused_adam_ranges() == []
+    n = dp.parametersG.numel()
+    assert dp._exchange_ranges(0, n) == [(0, ranges[0][0]), (ranges[0][1], ranges[1][0]), (ranges[1][1], n)]
+    assert dp._opbuf.numel() == 4 * (64 + 8192) * 2            # batch x (Nu + Ncols) floats per layer: what travels instead of 2 x 524288 gradients
+    for a, b, c in zip(_persistent(dp), _persistent(plain), _persistent(dpk)):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for lo, hi in ranges:
+        assert float(dp.gradParametersG[lo:hi].abs().max()) == 0 and float(dpk.gradParametersG[lo:hi].abs().max()) > 0
+    # pipelined step and sharded Adam: gradients travel whole
+    pp = _trainer("center", opt, "on", batch)
+    pp.force_comm = True
+    pp._pipelined = True
+    pp.set_batch_d(False)
+    pp.step_pipelined()
+    pp.flush()
+    assert pp.fused_adam_ranges() == [] and float(pp.gradParametersG[ranges[0][0]:ranges[0][1]].abs().max()) > 0
 
 
 def test_second_backward_without_zeroing_is_refused(oracle, hipb):

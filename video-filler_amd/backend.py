@@ -368,18 +368,23 @@ class HipBackend:
             self.scale_shift(t, 1.0 / world, 0.0)
         return t[rank * n:(rank + 1) * n]
 
-    def all_gather_shards(self, t, world, rank, group=None):
-        """every rank's shard t[r * n : (r + 1) * n] to all ranks, in place"""
+    def all_gather_shards(self, t, world, rank, group=None, async_op=False):
+        """every rank's shard t[r * n : (r + 1) * n] to all ranks, in place.  async_op: a handle whose wait() orders this backend's
+        stream after the collective (the C-ABI exchange; other backends complete here and return None)"""
         n = t.numel() // world
         assert n * world == t.numel() and t.is_contiguous() and t.dtype == torch.float32
         if self.comm is not None:
             ticket = C.c_int32(-1)
             _lib.check(self.lib.vf_comm_allgather_async(self.comm, self.ctx, _ptr(t), n, C.byref(ticket)))
-            _CommHandle(self, ticket.value).wait()
-            return
+            h = _CommHandle(self, ticket.value)
+            if async_op:
+                return h
+            h.wait()
+            return None
         import torch.distributed as dist
         parts = [t[r * n:(r + 1) * n] for r in range(world)]
         dist.all_gather(parts, parts[rank].clone(), group=group)
+        return None
 
     def _c(self, name, *args):
         _lib.check(getattr(self.lib, name)(self.ctx, *args))
@@ -757,6 +762,13 @@ class HipBackend:
         assert V.shape[0] == K and x.numel() == Nu * Ncols
         self._c("vf_wgrad_adam_outer", _ptr(U), _ptr(V), K, Nu, Ncols, _ptr(x), _ptr(m), _ptr(v), _ptr(g) if g is not None else None,
                 beta1, beta2, eps, _ptr(t_dev))
+
+    def wgrad_adam_outer_gathered(self, buf, u_off, v_off, world, K, seg, Nu, Ncols, x, m, v, g, beta1, beta2, eps, t_dev):
+        """vf_wgrad_adam_outer_gathered: `buf` holds `world` segments of `seg` floats; segment r has rank r's U [K][Nu] at u_off and
+        V [K][Ncols] at v_off.  g = the MEAN over ranks of U_r^T V_r (the data-parallel gradient), consumed by optim.adam in place."""
+        base = buf.data_ptr()
+        self._c("vf_wgrad_adam_outer_gathered", C.c_void_p(base + 4 * u_off), C.c_void_p(base + 4 * v_off), world * K, K, seg, Nu, Ncols,
+                _ptr(x), _ptr(m), _ptr(v), _ptr(g) if g is not None else None, 1.0 / world, beta1, beta2, eps, _ptr(t_dev))
 
     # ---- per-kernel timers
     def prof_begin(self):

@@ -226,6 +226,23 @@ class CNet(nn.Sequential):
         _lib.check(_lib.load().vf_net_adam_fused(self._net, C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), beta1, beta2, eps,
                                                  C.c_void_p(t_dev.data_ptr()), 1 if keep_grad else 0))
 
+    def fused_adam_pack_size(self):
+        n = C.c_int64()
+        _lib.check(_lib.load().vf_net_fused_adam_pack_size(self._net, C.byref(n)))
+        return n.value
+
+    def fused_adam_pack(self, segment):
+        """this rank's operands of the marked layers' pending weight gradients -> its segment of the gather buffer"""
+        assert segment.is_contiguous() and segment.numel() >= self.fused_adam_pack_size()
+        _lib.check(_lib.load().vf_net_fused_adam_pack(self._net, C.c_void_p(segment.data_ptr())))
+
+    def adam_fused_gathered(self, all_segments, world, m, v, beta1, beta2, eps, t_dev, keep_grad=False):
+        seg = all_segments.numel() // world
+        assert seg * world == all_segments.numel() and seg % 4 == 0
+        _lib.check(_lib.load().vf_net_adam_fused_gathered(self._net, C.c_void_p(all_segments.data_ptr()), world, seg, C.c_void_p(m.data_ptr()),
+                                                          C.c_void_p(v.data_ptr()), beta1, beta2, eps, C.c_void_p(t_dev.data_ptr()),
+                                                          1 if keep_grad else 0))
+
     def backward_finish(self):
         if self._net is not None:
             _lib.check(_lib.load().vf_net_backward_finish(self._net))

@@ -1171,6 +1171,61 @@ VF_API int vf_net_adam_fused(vf_net* n, float* m, float* v, double beta1, double
   }
   return 0;
 }
+// Data parallel: instead of all-reducing the two weight gradients (262 MB of train.lua's 284), every rank all-gathers the OPERANDS
+// they are the product of — K = batch rows of (Nu + Ncols) floats per layer, 6 MB at batchSize 64 — and forms the gradient of the
+// global batch itself, inside the fused kernel (K = world * batch rows, gscale = 1 / world: the mean over ranks, identical on every
+// rank).  vf_net_fused_adam_pack copies this rank's operands, layer after layer (U then V, each padded to 4 floats), into its
+// segment of the gather buffer; vf_net_adam_fused_gathered consumes `world` such segments, seg_stride floats apart.
+static int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+VF_API int vf_net_fused_adam_pack_size(const vf_net* n, int64_t* floats) {
+  VF_REQUIRE(n && floats, "vf_net_fused_adam_pack_size: NULL argument");
+  int64_t t = 0;
+  for (int i : n->fa_layers) {
+    const Layer& l = n->L[i];
+    const bool full = is_full(l);
+    const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
+    t += pad4((int64_t)n->B * Nu) + pad4((int64_t)n->B * 16 * Cv);
+  }
+  *floats = t;
+  return 0;
+}
+VF_API int vf_net_fused_adam_pack(vf_net* n, float* seg) {
+  VF_REQUIRE(n && seg, "vf_net_fused_adam_pack: NULL argument");
+  for (int i : n->fa_layers) {
+    const Layer& l = n->L[i];
+    const bool full = is_full(l);
+    const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
+    VF_REQUIRE(l.fa_k == n->B, "vf_net_fused_adam_pack: layer %d has no pending gradient of the net's batch (a backward pass with "
+               "vf_net_set_fused_adam on comes first)", i);
+    VF_CHECK_HIP(hipMemcpyAsync(seg, l.fa_u, (size_t)l.fa_k * Nu * sizeof(float), hipMemcpyDeviceToDevice, n->ctx->stream));
+    seg += pad4((int64_t)l.fa_k * Nu);
+    VF_CHECK_HIP(hipMemcpyAsync(seg, l.fa_v, (size_t)l.fa_k * 16 * Cv * sizeof(float), hipMemcpyDeviceToDevice, n->ctx->stream));
+    seg += pad4((int64_t)l.fa_k * 16 * Cv);
+  }
+  return 0;
+}
+VF_API int vf_net_adam_fused_gathered(vf_net* n, const float* all, int world, int64_t seg_stride, float* m, float* v, double beta1,
+                                      double beta2, double eps, const int32_t* t_dev, int keep_grad) {
+  VF_REQUIRE(n && all && m && v && t_dev && world >= 1, "vf_net_adam_fused_gathered: bad argument");
+  int64_t off = 0;
+  for (int i : n->fa_layers) {
+    Layer& l = n->L[i];
+    const bool full = is_full(l);
+    const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
+    VF_REQUIRE(l.fa_k == n->B, "vf_net_adam_fused_gathered: layer %d has no pending gradient", i);
+    const float* U = all + off;
+    off += pad4((int64_t)l.fa_k * Nu);
+    const float* V = all + off;
+    off += pad4((int64_t)l.fa_k * 16 * Cv);
+    VF_REQUIRE(off <= seg_stride || world == 1, "vf_net_adam_fused_gathered: segments of %lld floats overlap", (long long)seg_stride);
+    const int rc = vf_wgrad_adam_outer_gathered(n->ctx, U, V, world * l.fa_k, l.fa_k, seg_stride, Nu, 16 * Cv, n->params + l.w_off,
+                                                m + l.w_off, v + l.w_off, keep_grad ? n->grads + l.w_off : nullptr, 1.f / (float)world,
+                                                beta1, beta2, eps, t_dev);
+    l.fa_k = 0;
+    if (rc) return rc;
+  }
+  return 0;
+}
 // net:updateGradInput(input, gradOutput): gradInput only (parameter gradients untouched; train.lua:366)
 VF_API int vf_net_update_grad_input(vf_net* n, const float* x, const float* gy, const float** gx) {
   VF_REQUIRE(n && x && gy, "vf_net_update_grad_input: NULL argument");

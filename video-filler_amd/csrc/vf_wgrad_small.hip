@@ -36,6 +36,11 @@ struct VfAdamFuse {
   const int32_t* state;       // k_adam_prep's: [1] = bit pattern of the step size
   float b1, omb1, b2, omb2, eps;
   int round_bf16;             // operands rounded to bf16 (nearest even) on their way in: the arithmetic of matrix-core mode 1
+  // operands gathered from several ranks (data parallel): batch row k lives in segment k / kps at row k % kps, the segments
+  // seg floats apart (one rank's packed operands each); g = gscale * sum (1 / world: the mean over ranks).  One rank: kps = K.
+  int kps;
+  int64_t seg;
+  float gscale;
 };
 __device__ __forceinline__ float ws_rne(float f) {
   const unsigned u = __float_as_uint(f);
@@ -72,8 +77,14 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void k_wgrad_smallk(const float*
     const int kk = k + lh;
     const bool live = kk < K;
     const int kc = live ? kk : K - 1;
-    p.a = *(const f32x2*)(upc + (int64_t)kc * Nu);
-    p.b = *(const fvec*)(vp + (int64_t)kc * Ncols);
+    if constexpr (FUSE) {
+      const int sg = kc / A.kps, kr = kc - sg * A.kps;
+      p.a = *(const f32x2*)(upc + sg * A.seg + (int64_t)kr * Nu);
+      p.b = *(const fvec*)(vp + sg * A.seg + (int64_t)kr * Ncols);
+    } else {
+      p.a = *(const f32x2*)(upc + (int64_t)kc * Nu);
+      p.b = *(const fvec*)(vp + (int64_t)kc * Ncols);
+    }
     p.mb = live ? 1.f : 0.f;
     p.ma = (live && okA) ? 1.f : 0.f;
   };
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void k_wgrad_smallk(const float*
           fvec gv;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            gv[j] = acc[i][j][rb + q];
+            gv[j] = acc[i][j][rb + q] * A.gscale;
             float xe = xv[q][j], me = mv[q][j], ve = vv[q][j];
             vf_adam_upd(xe, gv[j], me, ve, A.b1, A.omb1, A.b2, A.omb2, A.eps, step);
             xv[q][j] = xe;
@@ -209,12 +220,15 @@ int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float*
 VF_API int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols) {
   return K >= 1 && Ncols % 128 == 0 && Nu % 2 == 0 && Nu >= 64 && (int64_t)Nu * Ncols < ((int64_t)1 << 31);
 }
-VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v,
-                               float* g, double beta1, double beta2, double eps, const int32_t* t_dev) {
+VF_API int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu,
+                                        int Ncols, float* x, float* m, float* v, float* g, float gscale, double beta1, double beta2,
+                                        double eps, const int32_t* t_dev) {
   VF_REQUIRE(ctx && U && V && x && m && v && t_dev, "vf_wgrad_adam_outer: NULL argument");
   VF_REQUIRE(vf_wgrad_adam_outer_supported(K, Nu, Ncols), "vf_wgrad_adam_outer: K %d, %d x %d is not this kernel's shape", K, Nu, Ncols);
-  VF_REQUIRE(!(((uintptr_t)U) & 7) && !((((uintptr_t)V) | ((uintptr_t)x) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)g)) & 15),
-             "vf_wgrad_adam_outer: operands must be 16-byte aligned");
+  VF_REQUIRE(rows_per_seg >= 1 && K % rows_per_seg == 0 && (K == rows_per_seg || seg_stride % 4 == 0),
+             "vf_wgrad_adam_outer: %d batch rows in segments of %d (stride %lld floats)", K, rows_per_seg, (long long)seg_stride);
+  VF_REQUIRE(!((((uintptr_t)U) | ((uintptr_t)V)) & 7) && !((((uintptr_t)x) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)g)) & 15),
+             "vf_wgrad_adam_outer: U, V must be 8-byte aligned, x, m, v, g 16-byte aligned");
   VfAdamFuse A;
   A.x = x; A.m = m; A.v = v; A.g = g;
   A.state = t_dev;
@@ -222,6 +236,9 @@ VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int 
   A.b2 = (float)beta2; A.omb2 = (float)(1.0 - beta2);
   A.eps = (float)eps;
   A.round_bf16 = ctx->mfma_bf16 == 1;
+  A.kps = rows_per_seg;
+  A.seg = seg_stride;
+  A.gscale = gscale;
   const int tiles_c = Ncols / 64, tiles_r = (int)vf_cdiv(Nu, 64);
   const int64_t wtiles = (int64_t)tiles_c * tiles_r;
   const double n = (double)Nu * Ncols;
@@ -230,4 +247,8 @@ VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int 
                   dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), U, V, (float*)nullptr, K, Nu, Ncols, tiles_c, 0.f, A);
   VF_LAUNCH_CHECK();
   return 0;
+}
+VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v,
+                               float* g, double beta1, double beta2, double eps, const int32_t* t_dev) {
+  return vf_wgrad_adam_outer_gathered(ctx, U, V, K, K, 0, Nu, Ncols, x, m, v, g, 1.f, beta1, beta2, eps, t_dev);
 }

@@ -94,6 +94,10 @@ int vf_net_set_fused_adam(vf_net* net, int on, int* count);
 int vf_net_fused_adam_range(const vf_net* net, int i, int64_t* offset, int64_t* length);
 int vf_net_adam_fused(vf_net* net, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad);
 int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols);
+int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu, int Ncols, float* x, float* m, float* v, float* g, float gscale, double beta1, double beta2, double eps, const int32_t* t_dev);
+int vf_net_fused_adam_pack_size(const vf_net* net, int64_t* floats);
+int vf_net_fused_adam_pack(vf_net* net, float* segment);
+int vf_net_adam_fused_gathered(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad);
 int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v, float* g, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);
 int vf_net_set_weight_planes_managed(vf_net* net, int on);

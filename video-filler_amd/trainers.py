@@ -265,6 +265,8 @@ class _TrainerBase:
         # slices), "keep" (it does: 28 B per weight instead of 24), "off" (accGradParameters + the plain one-pass update, 32 B)
         self.fuse_adam = os.environ.get("VF_FUSE_ADAM", "on")
         assert self.fuse_adam in ("on", "keep", "off"), "VF_FUSE_ADAM: on | keep | off"
+        self._dpf = []               # phased data-parallel step: the fused slices of this iteration (set in phase B)
+        self._opbuf = None           # ... and the gather buffer of their operands: world segments
         self.defer_adam_g = False
         self.adam_overlap = False    # enable_adam_overlap(): Adam(G)'s two big weight tensors beside the next encoder forward
         self.side_a = None
@@ -420,21 +422,27 @@ class _TrainerBase:
             else:
                 optim.adam(self.fGx, self.parametersG, self.optimStateG)
 
-    def _fuse_adam_possible(self):
+    def _fuse_adam_possible(self, dp=None):
+        """dp False: the single-device step(); True: the phased data-parallel step (operands gathered instead of gradients
+        reduced); None: whichever of the two this trainer is set up for"""
         from .cnet import CNet
-        return (self.fuse_adam != "off" and isinstance(self.netG, CNet) and self.netG._net is not None and not self._comm_on()
-                and not self.shard_adam and not self.defer_adam_g and not self.adam_overlap)
+        if dp is None:
+            dp = self._comm_on()
+        ok = (self.fuse_adam != "off" and isinstance(self.netG, CNet) and self.netG._net is not None and not self.shard_adam
+              and not self.defer_adam_g and not self.adam_overlap)
+        return ok and (self._comm_on() and not self._pipelined if dp else not self._comm_on())
 
     def _fuse_adam_ranges(self):
-        """marks netG's bottleneck pair for the fused update when this step may use it; the slices it covers (empty: plain update)"""
-        return self.netG.set_fused_adam(True) if self._fuse_adam_possible() else []
+        """marks netG's bottleneck pair for the fused update when step() may use it; the slices it covers (empty: plain update)"""
+        return self.netG.set_fused_adam(True) if self._fuse_adam_possible(dp=False) else []
 
     def fuse_adam_slices(self):
-        """[(lo, hi)] of the flat generator vectors that step() updates inside the weight-gradient kernel (empty: none)"""
+        """[(lo, hi)] of the flat generator vectors that this trainer's step updates inside the weight-gradient kernel (empty: none)"""
         if not self._fuse_adam_possible():
             return []
         r = self.netG.set_fused_adam(True)
-        self.netG.set_fused_adam(False)
+        if not (self._comm_on() and self._dpf):        # (a phased data-parallel step keeps its marks from phase B to phase C)
+            self.netG.set_fused_adam(False)
         return r
 
     def fused_adam_ranges(self):
@@ -519,11 +527,34 @@ class _TrainerBase:
         optim.adam_update(self.parametersD, self.gradParametersD, self.optimStateD)
         self._defer_comm = True
         self._split_g = self.netG.bucket_split()
+        # the bottleneck pair (92 % of G's gradient bytes) does not go on the wire: its weight gradients are left to phase C, which
+        # forms them from every rank's OPERANDS — packed here into this rank's segment of the gather buffer (6 MB at batchSize 64
+        # against 262 MB of gradient) and all-gathered by the step
+        self._dpf = self.netG.set_fused_adam(True) if self._fuse_adam_possible(dp=True) else []
         try:
             self.fGx(self.parametersG)
+            if self._dpf:
+                seg = self.netG.fused_adam_pack_size()
+                if self._opbuf is None or self._opbuf.numel() != seg * self.world:
+                    self._opbuf = get_backend().zeros(seg * self.world)
+                self.netG.fused_adam_pack(self._opbuf[self.rank * seg:(self.rank + 1) * seg])
         finally:
             self._split_g = None
             self._defer_comm = False
+
+    def _exchange_ranges(self, lo, hi):
+        """[(a, b)] of the flat generator gradient inside [lo, hi) that still travel as gradients (everything but the fused slices)"""
+        out, pos = [], lo
+        for a, b in sorted(self._dpf or []):
+            a, b = max(a, lo), min(b, hi)
+            if a >= b:
+                continue
+            if a > pos:
+                out.append((pos, a))
+            pos = max(pos, b)
+        if hi > pos:
+            out.append((pos, hi))
+        return out
 
     def _phase_b2(self):
         self.netG.backward_finish()      # the encoder's weight / bias gradients, while the tail bucket is on the wire
@@ -532,6 +563,13 @@ class _TrainerBase:
         if self.shard_adam:
             lo, hi = self._shard
             optim.adam_update(self.parametersG[lo:hi], self.gradParametersG[lo:hi], self.optimStateG_shard)
+            return
+        if self._dpf:
+            try:
+                optim.adam_update_fused(self.parametersG, self.gradParametersG, self.optimStateG, self.netG, self.fuse_adam == "keep",
+                                        gathered=(self._opbuf, self.world))
+            finally:
+                self.netG.set_fused_adam(False)
             return
         optim.adam_update(self.parametersG, self.gradParametersG, self.optimStateG)
 
@@ -550,10 +588,13 @@ class _TrainerBase:
             pc()                                                             # Adam on that shard
             B.all_gather_shards(self.parametersG, self.world, self.rank, self.group)
             return
-        h_tail = B.all_reduce_avg(gG[off:], self.world, self.group, async_op=True)
+        hs = []
+        if self._dpf:
+            hs.append(B.all_gather_shards(self._opbuf, self.world, self.rank, self.group, async_op=True))
+        hs += [B.all_reduce_avg(gG[a:b], self.world, self.group, async_op=True) for a, b in self._exchange_ranges(off, gG.numel())]
         pb2()
-        h_head = B.all_reduce_avg(gG[:off], self.world, self.group, async_op=True) if off > 0 else None
-        for h in (h_tail, h_head):
+        hs += [B.all_reduce_avg(gG[a:b], self.world, self.group, async_op=True) for a, b in self._exchange_ranges(0, off)]
+        for h in hs:
             if h is not None:
                 h.wait()
         pc()
