@@ -98,6 +98,7 @@ def test_syncbn_collectives_are_captured_with_the_phases(kind, oracle, hipb):
 
     def synced():
         t = mk(overlap=False)                  # what the trainers do for world > 1 with sync_bn (one stream)
+        t.fuse_adam = "keep"                   # (its gradient vector is read below)
         t.set_batch_d(False)                   # (SyncBN all-reduces one group's sums per layer and pass: no 2B netD batching)
         t.set_batch(*batch)
         t.force_comm = True
