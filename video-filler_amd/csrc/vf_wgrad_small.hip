@@ -38,7 +38,7 @@ struct VfAdamFuse {
   int round_bf16;             // operands rounded to bf16 (nearest even) on their way in: the arithmetic of matrix-core mode 1
   // operands gathered from several ranks (data parallel): batch row k lives in segment k / kps at row k % kps, the segments
   // seg floats apart (one rank's packed operands each); g = gscale * sum (1 / world: the mean over ranks).  One rank: kps = K.
-  int kps;
+  int kps, kshift;            // kshift: log2(kps) when it is a power of two, else -1
   int64_t seg;
   float gscale;
 };
@@ -46,8 +46,10 @@ __device__ __forceinline__ float ws_rne(float f) {
   const unsigned u = __float_as_uint(f);
   return __uint_as_float(((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16) << 16);
 }
-template <int NJ, bool FUSE = false>
-__global__ __launch_bounds__(256, FUSE ? 3 : 1) void k_wgrad_smallk(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ dW,
+// RB: rows of x, m, v in flight per epilogue batch; OCC: waves per SIMD the register budget is held to; PF: the first batch is
+// loaded BEFORE the K loop, so it travels under the matrix-core phase
+template <int NJ, bool FUSE = false, int RB = 4, int OCC = 3, bool PF = false>
+__global__ __launch_bounds__(256, FUSE ? OCC : 1) void k_wgrad_smallk(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ dW,
                                                       int K, int Nu, int Ncols, int tiles_c, float beta, const VfAdamFuse A) {
   typedef float fvec __attribute__((ext_vector_type(NJ)));
   const int lane = threadIdx.x & 63;
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void k_wgrad_smallk(const float*
     const int kk = k + lh;
     const bool live = kk < K;
     const int kc = live ? kk : K - 1;
-    if constexpr (FUSE) {
-      const int sg = kc / A.kps, kr = kc - sg * A.kps;
+    if (FUSE && A.seg != 0) {       // (wave-uniform: gathered operands only)
+      const int sg = A.kshift >= 0 ? kc >> A.kshift : kc / A.kps, kr = kc - sg * A.kps;
       p.a = *(const f32x2*)(upc + sg * A.seg + (int64_t)kr * Nu);
       p.b = *(const fvec*)(vp + sg * A.seg + (int64_t)kr * Ncols);
     } else {
@@ -106,6 +108,22 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void k_wgrad_smallk(const float*
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
   };
+  // ---- FUSE: the epilogue's batches (rows r = rb .. rb + RB of accumulator row block i)
+  struct Bat { fvec x[RB], m[RB], v[RB]; int off[RB]; };
+  const int cofs = c0 + NJ * lr;
+  auto bat_load = [&](int i, int rb, Bat& b) {
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int r = rb + q;
+      const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + i;
+      b.off[q] = (n < Nu ? n : n0) * Ncols + cofs;
+      b.x[q] = *(const fvec*)(A.x + b.off[q]);
+      b.m[q] = *(const fvec*)(A.m + b.off[q]);
+      b.v[q] = *(const fvec*)(A.v + b.off[q]);
+    }
+  };
+  Bat pre;
+  if constexpr (FUSE && PF) bat_load(0, 0, pre);
   Pair p0, p1, p2;
   ld(0, p0);
   ld(2, p1);
@@ -141,46 +159,44 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 1) void k_wgrad_smallk(const float*
       }
   };
   if constexpr (FUSE) {
-    // four rows at a time: their x, m, v (12 loads of NJ floats, 256-byte runs per half wave) are in flight together, three
-    // waves per SIMD cover for one another
+    // RB rows at a time: their x, m, v (3 RB loads of NJ floats, 256-byte runs per half wave) are in flight together, OCC waves
+    // per SIMD cover for one another
     const float step = __int_as_float(A.state[1]);
-    const int cofs = c0 + NJ * lr;
+    auto bat_apply = [&](auto IC, auto RBC, Bat& b) {
+      constexpr int i = decltype(IC)::value, rb = decltype(RBC)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int q = 0; q < RB; ++q) {
+        const int r = rb + q;
+        if (n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lh) + i >= Nu) continue;
+        fvec gv;
 #pragma unroll
-      for (int rb = 0; rb < 16; rb += 4) {
-        // r = rb + q: row n0 + 2 * (q + 8 * (rb >> 2) + 4 * lh) + i
-        const int nb = n0 + 2 * (8 * (rb >> 2) + 4 * lh) + i;
-        fvec xv[4], mv[4], vv[4];
-        int off[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nb + 2 * q;
-          off[q] = (n < Nu ? n : n0) * Ncols + cofs;
-          xv[q] = *(const fvec*)(A.x + off[q]);
-          mv[q] = *(const fvec*)(A.m + off[q]);
-          vv[q] = *(const fvec*)(A.v + off[q]);
+        for (int j = 0; j < NJ; ++j) {
+          gv[j] = acc[i][j][r] * A.gscale;
+          float xe = b.x[q][j], me = b.m[q][j], ve = b.v[q][j];
+          vf_adam_upd(xe, gv[j], me, ve, A.b1, A.omb1, A.b2, A.omb2, A.eps, step);
+          b.x[q][j] = xe;
+          b.m[q][j] = me;
+          b.v[q][j] = ve;
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (nb + 2 * q >= Nu) continue;
-          fvec gv;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            gv[j] = acc[i][j][rb + q] * A.gscale;
-            float xe = xv[q][j], me = mv[q][j], ve = vv[q][j];
-            vf_adam_upd(xe, gv[j], me, ve, A.b1, A.omb1, A.b2, A.omb2, A.eps, step);
-            xv[q][j] = xe;
-            mv[q][j] = me;
-            vv[q][j] = ve;
-          }
-          *(fvec*)(A.x + off[q]) = xv[q];
-          *(fvec*)(A.m + off[q]) = mv[q];
-          *(fvec*)(A.v + off[q]) = vv[q];
-          if (A.g) *(fvec*)(A.g + off[q]) = gv;
+        *(fvec*)(A.x + b.off[q]) = b.x[q];
+        *(fvec*)(A.m + b.off[q]) = b.m[q];
+        *(fvec*)(A.v + b.off[q]) = b.v[q];
+        if (A.g) *(fvec*)(A.g + b.off[q]) = gv;
+      }
+    };
+    vf_static_for<2>([&](auto IC) {
+      vf_static_for<16 / RB>([&](auto BC) {
+        constexpr int i = decltype(IC)::value, rb = decltype(BC)::value * RB;
+        if constexpr (PF && i == 0 && rb == 0) {
+          bat_apply(IC, VfIntC<rb>{}, pre);
+        } else {
+          Bat b;
+          bat_load(i, rb, b);
+          bat_apply(IC, VfIntC<rb>{}, b);
         }
         __builtin_amdgcn_sched_barrier(0);      // (the next rows' loads stay behind these stores)
-      }
+      });
+    });
   } else {
     if (beta != 0.f) store_all(VfIntC<1>{});
     else store_all(VfIntC<0>{});
@@ -237,14 +253,20 @@ VF_API int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float
   A.eps = (float)eps;
   A.round_bf16 = ctx->mfma_bf16 == 1;
   A.kps = rows_per_seg;
-  A.seg = seg_stride;
+  A.kshift = vf_is_pow2(rows_per_seg) ? vf_ilog2(rows_per_seg) : -1;
+  A.seg = K == rows_per_seg ? 0 : seg_stride;       // (one segment: plain row addressing)
   A.gscale = gscale;
   const int tiles_c = Ncols / 64, tiles_r = (int)vf_cdiv(Nu, 64);
   const int64_t wtiles = (int64_t)tiles_c * tiles_r;
   const double n = (double)Nu * Ncols;
   // (2 K flops per 24 bytes is far below the matrix pipe's ridge: bench.py prices it by its bytes)
-  VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", 2.0 * K * n, (g ? 28.0 : 24.0) * n + 4.0 * K * ((double)Nu + Ncols), (k_wgrad_smallk<2, true>),
-                  dim3((unsigned)vf_cdiv(wtiles, 4)), dim3(256), U, V, (float*)nullptr, K, Nu, Ncols, tiles_c, 0.f, A);
+  // measured (scripts/bench_fused_adam.py; K = 64, 4000 x 8192): RB 4 / three waves per SIMD 180 us; RB 8 / two waves 181; RB 16 / two
+  // waves 233 (spills); first batch loaded ahead of the K loop 174-180 — the epilogue is bandwidth-, not latency-bound.  What the
+  // kernel leaves on the table is that a CU's waves run their matrix-core phase and their memory phase in step (K = 64: 150 us of
+  // traffic + 30 us of MFMAs = 180; K = 512, eight gathered ranks: 150 + 280 = 430): DESIGN.md 4.8(f).
+  const double bytes = (g ? 28.0 : 24.0) * n + 4.0 * K * ((double)Nu + Ncols);
+  VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", 2.0 * K * n, bytes, (k_wgrad_smallk<2, true, 4, 3, false>), dim3((unsigned)vf_cdiv(wtiles, 4)),
+                  dim3(256), U, V, (float*)nullptr, K, Nu, Ncols, tiles_c, 0.f, A);
   VF_LAUNCH_CHECK();
   return 0;
 }
