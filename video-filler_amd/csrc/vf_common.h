@@ -170,6 +170,21 @@ __device__ __forceinline__ void vf_adam_upd(float& xv, float gv, float& mv, floa
   xv = xv - (step * mi) / d;
 }
 
+// One layer of the fused bottleneck update (vf_wgrad_small.hip k_adam_fused_wgrad; built by vf_wgrad_adam_outer* and by vf_net.hip):
+//   g = gscale * sum_k U[k][:]^T V[k][:]  consumed by optim.adam on x, m, v [Nu][Ncols]; g_out (may be NULL) also receives it.
+// Batch row k lives in segment k / kps at row k % kps, the segments `seg` floats apart (seg == 0: one segment, plain rows).
+struct VfFusedLayer {
+  const float *U, *V;
+  float *x, *m, *v, *g_out;
+  int K, Nu, Ncols;
+  int kps;
+  int64_t seg;
+  float gscale;
+};
+#define VF_FUSED_MAX 4
+int vf_internal_adam_fused_multi(vf_ctx* ctx, const VfFusedLayer* layers, int nl, double beta1, double beta2, double eps,
+                                 const int32_t* t_dev);
+
 // fused activation
 __device__ __forceinline__ float vf_act_apply(float v, int act, float slope) {
   switch (act) {

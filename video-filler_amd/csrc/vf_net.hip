@@ -1155,28 +1155,53 @@ VF_API int vf_net_fused_adam_range(const vf_net* n, int i, int64_t* offset, int6
   *length = l.w_n;
   return 0;
 }
-VF_API int vf_net_adam_fused(vf_net* n, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad) {
-  VF_REQUIRE(n && m && v && t_dev, "vf_net_adam_fused: NULL argument");
+static int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+static int fused_layers_launch(vf_net* n, const float* all, int world, int64_t seg_stride, float* m, float* v, double beta1, double beta2,
+                               double eps, const int32_t* t_dev, int keep_grad) {
+  VfFusedLayer F[VF_FUSED_MAX];
+  int nf = 0;
+  int64_t off = 0;
   for (int i : n->fa_layers) {
     Layer& l = n->L[i];
     const bool full = is_full(l);
     const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
     float *x = n->params + l.w_off, *g = n->grads + l.w_off;
-    int rc;
-    if (l.fa_k > 0) rc = vf_wgrad_adam_outer(n->ctx, l.fa_u, l.fa_v, l.fa_k, Nu, 16 * Cv, x, m + l.w_off, v + l.w_off, keep_grad ? g : nullptr,
-                                             beta1, beta2, eps, t_dev);
-    else rc = vf_adam_apply(n->ctx, x, g, m + l.w_off, v + l.w_off, l.w_n, beta1, beta2, eps, t_dev);
+    if (all) VF_REQUIRE(l.fa_k == n->B, "vf_net_adam_fused_gathered: layer %d has no pending gradient", i);
+    if (l.fa_k <= 0) {       // accumulated the plain way (a backward pass onto a gradient that was not fresh): the plain update
+      if (int rc = vf_adam_apply(n->ctx, x, g, m + l.w_off, v + l.w_off, l.w_n, beta1, beta2, eps, t_dev)) return rc;
+      continue;
+    }
+    if (nf == VF_FUSED_MAX) {
+      if (int rc = vf_internal_adam_fused_multi(n->ctx, F, nf, beta1, beta2, eps, t_dev)) return rc;
+      nf = 0;
+    }
+    VfFusedLayer& L = F[nf++];
+    if (all) {
+      L.U = all + off;
+      off += pad4((int64_t)l.fa_k * Nu);
+      L.V = all + off;
+      off += pad4((int64_t)l.fa_k * 16 * Cv);
+      VF_REQUIRE(off <= seg_stride || world == 1, "vf_net_adam_fused_gathered: segments of %lld floats overlap", (long long)seg_stride);
+    } else {
+      L.U = l.fa_u;
+      L.V = l.fa_v;
+    }
+    L.x = x; L.m = m + l.w_off; L.v = v + l.w_off; L.g_out = keep_grad ? g : nullptr;
+    L.K = world * l.fa_k; L.Nu = Nu; L.Ncols = 16 * Cv;
+    L.kps = l.fa_k; L.seg = all ? seg_stride : 0; L.gscale = 1.f / (float)world;
     l.fa_k = 0;
-    if (rc) return rc;
   }
-  return 0;
+  return nf ? vf_internal_adam_fused_multi(n->ctx, F, nf, beta1, beta2, eps, t_dev) : 0;
+}
+VF_API int vf_net_adam_fused(vf_net* n, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad) {
+  VF_REQUIRE(n && m && v && t_dev, "vf_net_adam_fused: NULL argument");
+  return fused_layers_launch(n, nullptr, 1, 0, m, v, beta1, beta2, eps, t_dev, keep_grad);
 }
 // Data parallel: instead of all-reducing the two weight gradients (262 MB of train.lua's 284), every rank all-gathers the OPERANDS
 // they are the product of — K = batch rows of (Nu + Ncols) floats per layer, 6 MB at batchSize 64 — and forms the gradient of the
 // global batch itself, inside the fused kernel (K = world * batch rows, gscale = 1 / world: the mean over ranks, identical on every
 // rank).  vf_net_fused_adam_pack copies this rank's operands, layer after layer (U then V, each padded to 4 floats), into its
 // segment of the gather buffer; vf_net_adam_fused_gathered consumes `world` such segments, seg_stride floats apart.
-static int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
 VF_API int vf_net_fused_adam_pack_size(const vf_net* n, int64_t* floats) {
   VF_REQUIRE(n && floats, "vf_net_fused_adam_pack_size: NULL argument");
   int64_t t = 0;
@@ -1207,24 +1232,7 @@ VF_API int vf_net_fused_adam_pack(vf_net* n, float* seg) {
 VF_API int vf_net_adam_fused_gathered(vf_net* n, const float* all, int world, int64_t seg_stride, float* m, float* v, double beta1,
                                       double beta2, double eps, const int32_t* t_dev, int keep_grad) {
   VF_REQUIRE(n && all && m && v && t_dev && world >= 1, "vf_net_adam_fused_gathered: bad argument");
-  int64_t off = 0;
-  for (int i : n->fa_layers) {
-    Layer& l = n->L[i];
-    const bool full = is_full(l);
-    const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
-    VF_REQUIRE(l.fa_k == n->B, "vf_net_adam_fused_gathered: layer %d has no pending gradient", i);
-    const float* U = all + off;
-    off += pad4((int64_t)l.fa_k * Nu);
-    const float* V = all + off;
-    off += pad4((int64_t)l.fa_k * 16 * Cv);
-    VF_REQUIRE(off <= seg_stride || world == 1, "vf_net_adam_fused_gathered: segments of %lld floats overlap", (long long)seg_stride);
-    const int rc = vf_wgrad_adam_outer_gathered(n->ctx, U, V, world * l.fa_k, l.fa_k, seg_stride, Nu, 16 * Cv, n->params + l.w_off,
-                                                m + l.w_off, v + l.w_off, keep_grad ? n->grads + l.w_off : nullptr, 1.f / (float)world,
-                                                beta1, beta2, eps, t_dev);
-    l.fa_k = 0;
-    if (rc) return rc;
-  }
-  return 0;
+  return fused_layers_launch(n, all, world, seg_stride, m, v, beta1, beta2, eps, t_dev, keep_grad);
 }
 // net:updateGradInput(input, gradOutput): gradInput only (parameter gradients untouched; train.lua:366)
 VF_API int vf_net_update_grad_input(vf_net* n, const float* x, const float* gy, const float** gx) {

@@ -228,6 +228,21 @@ int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float*
   return 0;
 }
 
+// Measured and rejected (round 3): a persistent producer / consumer form — blocks of three wave PAIRS, the producer of a pair walks the
+// K loop and hands the 64 x 64 accumulator tile through 16 KB of LDS to its consumer, which streams x, m, v; bounded flag waits in
+// LDS; one launch for all layers.  Correct (the bit-for-bit tests passed on it) and slower everywhere: K = 64 301 us against 180,
+// K = 4 (configs[4], no matrix-core phase to hide) 1287 against 735, K = 512 965 against 436 — half the waves of a CU issue
+// loads, so half the bytes are in flight, and the other half's MFMAs have one or two waves per SIMD to hide their operand latency
+// with instead of three.  Start-up phase offsets between the waves of the plain form (so that one wave's MFMAs fall into the
+// others' memory phase) only added their own delay: 178 -> 188 / 201 / 256 us for offsets of 1 / 3 / 8 x 4096 cycles.
+struct VfFusedArgs {
+  int nl;
+  int tile_off[VF_FUSED_MAX + 1];
+  int tiles_c[VF_FUSED_MAX];
+  int kshift[VF_FUSED_MAX];       // log2(kps) when it is a power of two, else -1
+  VfFusedLayer L[VF_FUSED_MAX];
+};
+
 // The bottleneck pair's weight gradient with optim.adam in its epilogue:  g = sum_k U[k][:]^T V[k][:]  (K = batch) is formed in the
 // matrix-core accumulators and consumed there — x, m, v [Nu][Ncols] are read and written once (24 B per weight; + 4 when g, which
 // may be NULL, is stored too), where the two-kernel form writes g, then reads it again beside x, m, v (32 B).  t_dev is the
@@ -236,39 +251,58 @@ int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float*
 VF_API int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols) {
   return K >= 1 && Ncols % 128 == 0 && Nu % 2 == 0 && Nu >= 64 && (int64_t)Nu * Ncols < ((int64_t)1 << 31);
 }
+int vf_internal_adam_fused_multi(vf_ctx* ctx, const VfFusedLayer* layers, int nl, double beta1, double beta2, double eps,
+                                 const int32_t* t_dev) {
+  VF_REQUIRE(ctx && layers && t_dev && nl >= 1 && nl <= VF_FUSED_MAX, "fused update: %d layers (at most %d per launch)", nl, VF_FUSED_MAX);
+  VfFusedArgs A;
+  memset(&A, 0, sizeof(A));
+  A.nl = nl;
+  for (int i = 0; i < nl; ++i) {
+    const VfFusedLayer& L = layers[i];
+    VF_REQUIRE(L.U && L.V && L.x && L.m && L.v, "vf_wgrad_adam_outer: NULL argument");
+    VF_REQUIRE(vf_wgrad_adam_outer_supported(L.K, L.Nu, L.Ncols), "vf_wgrad_adam_outer: K %d, %d x %d is not this kernel's shape", L.K, L.Nu,
+               L.Ncols);
+    VF_REQUIRE(L.kps >= 1 && L.K % L.kps == 0 && (L.K == L.kps || L.seg % 4 == 0),
+               "vf_wgrad_adam_outer: %d batch rows in segments of %d (stride %lld floats)", L.K, L.kps, (long long)L.seg);
+    VF_REQUIRE(!((((uintptr_t)L.U) | ((uintptr_t)L.V)) & 7) &&
+                   !((((uintptr_t)L.x) | ((uintptr_t)L.m) | ((uintptr_t)L.v) | ((uintptr_t)L.g_out)) & 15),
+               "vf_wgrad_adam_outer: U, V must be 8-byte aligned, x, m, v, g 16-byte aligned");
+    A.L[i] = L;
+    if (L.K == L.kps) A.L[i].seg = 0;       // (one segment: plain row addressing)
+    A.kshift[i] = vf_is_pow2(L.kps) ? vf_ilog2(L.kps) : -1;
+    A.tiles_c[i] = L.Ncols / 64;
+    A.tile_off[i + 1] = A.tile_off[i] + A.tiles_c[i] * (int)vf_cdiv(L.Nu, 64);
+  }
+  for (int i = 0; i < nl; ++i) {      // one launch per layer
+    const VfFusedLayer& L = A.L[i];
+    VfAdamFuse F;
+    F.x = L.x; F.m = L.m; F.v = L.v; F.g = L.g_out;
+    F.state = t_dev;
+    F.b1 = (float)beta1; F.omb1 = (float)(1.0 - beta1);
+    F.b2 = (float)beta2; F.omb2 = (float)(1.0 - beta2);
+    F.eps = (float)eps;
+    F.round_bf16 = ctx->mfma_bf16 == 1;
+    F.kps = L.kps; F.kshift = A.kshift[i]; F.seg = L.seg; F.gscale = L.gscale;
+    const double n = (double)L.Nu * L.Ncols;
+    // (2 K flops per 24 bytes is far below the matrix pipe's ridge: bench.py prices it by its bytes)
+    // measured (scripts/bench_fused_adam.py; K = 64, 4000 x 8192): RB 4 / three waves per SIMD 180 us; RB 8 / two waves 181; RB 16 / two
+    // waves 233 (spills); first batch loaded ahead of the K loop 174-180
+    VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", 2.0 * L.K * n, (L.g_out ? 28.0 : 24.0) * n + 4.0 * L.K * ((double)L.Nu + L.Ncols),
+                    (k_wgrad_smallk<2, true, 4, 3, false>), dim3((unsigned)vf_cdiv(A.tile_off[i + 1] - A.tile_off[i], 4)), dim3(256), L.U,
+                    L.V, (float*)nullptr, L.K, L.Nu, L.Ncols, A.tiles_c[i], 0.f, F);
+    VF_LAUNCH_CHECK();
+  }
+  return 0;
+}
 VF_API int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu,
                                         int Ncols, float* x, float* m, float* v, float* g, float gscale, double beta1, double beta2,
                                         double eps, const int32_t* t_dev) {
   VF_REQUIRE(ctx && U && V && x && m && v && t_dev, "vf_wgrad_adam_outer: NULL argument");
-  VF_REQUIRE(vf_wgrad_adam_outer_supported(K, Nu, Ncols), "vf_wgrad_adam_outer: K %d, %d x %d is not this kernel's shape", K, Nu, Ncols);
-  VF_REQUIRE(rows_per_seg >= 1 && K % rows_per_seg == 0 && (K == rows_per_seg || seg_stride % 4 == 0),
-             "vf_wgrad_adam_outer: %d batch rows in segments of %d (stride %lld floats)", K, rows_per_seg, (long long)seg_stride);
-  VF_REQUIRE(!((((uintptr_t)U) | ((uintptr_t)V)) & 7) && !((((uintptr_t)x) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)g)) & 15),
-             "vf_wgrad_adam_outer: U, V must be 8-byte aligned, x, m, v, g 16-byte aligned");
-  VfAdamFuse A;
-  A.x = x; A.m = m; A.v = v; A.g = g;
-  A.state = t_dev;
-  A.b1 = (float)beta1; A.omb1 = (float)(1.0 - beta1);
-  A.b2 = (float)beta2; A.omb2 = (float)(1.0 - beta2);
-  A.eps = (float)eps;
-  A.round_bf16 = ctx->mfma_bf16 == 1;
-  A.kps = rows_per_seg;
-  A.kshift = vf_is_pow2(rows_per_seg) ? vf_ilog2(rows_per_seg) : -1;
-  A.seg = K == rows_per_seg ? 0 : seg_stride;       // (one segment: plain row addressing)
-  A.gscale = gscale;
-  const int tiles_c = Ncols / 64, tiles_r = (int)vf_cdiv(Nu, 64);
-  const int64_t wtiles = (int64_t)tiles_c * tiles_r;
-  const double n = (double)Nu * Ncols;
-  // (2 K flops per 24 bytes is far below the matrix pipe's ridge: bench.py prices it by its bytes)
-  // measured (scripts/bench_fused_adam.py; K = 64, 4000 x 8192): RB 4 / three waves per SIMD 180 us; RB 8 / two waves 181; RB 16 / two
-  // waves 233 (spills); first batch loaded ahead of the K loop 174-180 — the epilogue is bandwidth-, not latency-bound.  What the
-  // kernel leaves on the table is that a CU's waves run their matrix-core phase and their memory phase in step (K = 64: 150 us of
-  // traffic + 30 us of MFMAs = 180; K = 512, eight gathered ranks: 150 + 280 = 430): DESIGN.md 4.8(f).
-  const double bytes = (g ? 28.0 : 24.0) * n + 4.0 * K * ((double)Nu + Ncols);
-  VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", 2.0 * K * n, bytes, (k_wgrad_smallk<2, true, 4, 3, false>), dim3((unsigned)vf_cdiv(wtiles, 4)),
-                  dim3(256), U, V, (float*)nullptr, K, Nu, Ncols, tiles_c, 0.f, A);
-  VF_LAUNCH_CHECK();
-  return 0;
+  VfFusedLayer L;
+  L.U = U; L.V = V; L.x = x; L.m = m; L.v = v; L.g_out = g;
+  L.K = K; L.Nu = Nu; L.Ncols = Ncols;
+  L.kps = rows_per_seg; L.seg = seg_stride; L.gscale = gscale;
+  return vf_internal_adam_fused_multi(ctx, &L, 1, beta1, beta2, eps, t_dev);
 }
 VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v,
                                float* g, double beta1, double beta2, double eps, const int32_t* t_dev) {
