@@ -1,0 +1,82 @@
+"""Several data-parallel ranks on ONE GPU, exchanging over gloo (RCCL refuses two ranks on a device): what a one-GPU box can say
+about the N > 1 iteration.  Every rank runs the train.lua nets through the C-ABI host on cuda:0 on its own shard of a batch:
+
+  * `on`  : the phased step with the bottleneck pair's OPERANDS all-gathered and the global-batch gradient formed inside the fused
+            Adam kernel on every rank (trainers._phase_b / _phase_c, vf_net_fused_adam_pack / vf_net_adam_fused_gathered);
+  * `off` : the same step with that pair's gradients all-reduced like the rest.
+
+Checked on every rank: the two walk the same trajectory to fp32 rounding (gradients of everything that is still exchanged,
+parameters where the gradient is significant), the fused slices were really left out of the exchange, and the replicas hold the
+SAME BITS on every rank after three iterations (parameters, Adam moments).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 scripts/dp_rehearsal.py
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+from video_filler_amd.backend import get_backend
+from video_filler_amd.trainers import CenterTrainer
+
+B = get_backend()
+b = int(os.environ.get("VF_REHEARSAL_BATCH", "4"))
+opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4, nef=32, ngf=32, ndf=32, batchSize=b)
+gen = torch.Generator().manual_seed(7)
+full = torch.rand((world * b, 3, 128, 128), generator=gen) * 2 - 1          # the same draw on every rank; rank r takes shard r
+shard = full[rank * b:(rank + 1) * b].contiguous()
+
+
+def make(mode):
+    tr = CenterTrainer(opt, seed=11, world=world, rank=rank, group=None, host="cabi")
+    tr.fuse_adam = mode
+    tr.set_batch(shard)
+    return tr
+
+
+on, off = make("on"), make("off")
+assert torch.equal(on.parametersG, off.parametersG)
+for _ in range(3):
+    on.step_phased()
+    off.step_phased()
+torch.cuda.synchronize()
+ranges = on.fused_adam_ranges()
+assert len(ranges) == 2 and off.fused_adam_ranges() == [], (ranges, off.fused_adam_ranges())
+assert on._opbuf is not None and on._opbuf.numel() == world * on._opbuf.numel() // world
+n = on.parametersG.numel()
+mask = torch.zeros(n, dtype=torch.bool, device=on.parametersG.device)
+for lo, hi in ranges:
+    mask[lo:hi] = True
+    assert float(on.gradParametersG[lo:hi].abs().max()) == 0.0, "the fused slices must not have been written / exchanged"
+g_on, g_off = on.gradParametersG, off.gradParametersG
+err_g = float((g_on - g_off)[~mask].abs().max() / g_off.abs().max())
+lr = on.optimStateG["learningRate"]
+sel = g_off.abs() > 1e-3 * g_off.abs().max()
+err_p = float((on.parametersG - off.parametersG).abs()[sel].max() / lr)
+err_m = float((on.optimStateG["m"] - off.optimStateG["m"]).abs().max() / off.optimStateG["m"].abs().max())
+err_d = float((on.parametersD - off.parametersD).abs().max() / on.optimStateD["learningRate"])
+
+
+def bits(t):
+    return int(t.view(torch.int32).to(torch.int64).sum().item())
+
+
+sig = torch.tensor([bits(on.parametersG), bits(on.optimStateG["m"]), bits(on.optimStateG["v"]), bits(on.parametersD)], dtype=torch.int64)
+every = [torch.zeros_like(sig) for _ in range(world)]
+dist.all_gather(every, sig)
+same = all(torch.equal(e, every[0]) for e in every)
+line = ("rank %d/%d  batch %d/rank  fused slices %s  gather buffer %d floats  |  on vs off: grad(exchanged part) %.2e  param %.3f lr  "
+        "adam m %.2e  netD %.3f lr  |  replicas bit-identical: %s" % (rank, world, b, ranges, on._opbuf.numel(), err_g, err_p, err_m, err_d, same))
+print(line, flush=True)
+ok = err_g < 1e-4 and err_p < 0.05 and err_m < 1e-3 and same
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
