@@ -1,0 +1,34 @@
+"""Two and three data-parallel ranks on the one GPU of the box, exchanging over gloo (scripts/dp_rehearsal.py): the N > 1 form of the
+phased step with the bottleneck pair's operands gathered (vf_net_fused_adam_pack -> all-gather -> vf_net_adam_fused_gathered) against
+the same step with that pair's gradients all-reduced; replicas must hold the same bits.  (RCCL itself refuses two ranks on one
+device; its entries are exercised on a one-rank communicator in tests/test_gpu_comm.py.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gathered_operand_exchange_with_real_ranks(world):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "dp_rehearsal.py")]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.replace("rank ", "\nrank ").splitlines() if l.startswith("rank ")]
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert len(lines) == world and all("replicas bit-identical: True" in l for l in lines), lines
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dp_rehearsal_%d.log" % world), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
