@@ -3,7 +3,6 @@ phased step with the bottleneck pair's operands gathered (vf_net_fused_adam_pack
 the same step with that pair's gradients all-reduced; replicas must hold the same bits.  (RCCL itself refuses two ranks on one
 device; its entries are exercised on a one-rank communicator in tests/test_gpu_comm.py.)"""
 import os
-import re
 import socket
 import subprocess
 import sys
@@ -27,9 +26,10 @@ def test_gathered_operand_exchange_with_real_ranks(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "dp_rehearsal.py")]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    lines = re.findall(r"rank \d+/\d+  batch.*?replicas bit-identical: \w+", r.stdout, re.S)      # (ranks may share a line)
+    # (every rank exits non-zero on a failed check and torchrun passes that on; the ranks' lines may interleave on the shared stdout)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    assert len(lines) == world and all("replicas bit-identical: True" in l for l in lines), lines
+    assert r.stdout.count("replicas bit-identical: True") == world, r.stdout[-2000:]
+    lines = [r.stdout]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "dp_rehearsal_%d.log" % world), "w") as fh:
         fh.write("\n".join(lines) + "\n")
