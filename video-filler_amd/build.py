@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["vf_core.hip", "vf_bn.hip", "vf_conv.hip", "vf_conv_generic.hip", "vf_pipeline.hip", "vf_pgemm.hip", "vf_conv_thin.hip", "vf_comm.hip", "vf_wgrad_small.hip", "vf_trace.hip", "vf_net.hip"]
+SRC = ["vf_core.hip", "vf_bn.hip", "vf_conv.hip", "vf_conv_generic.hip", "vf_pipeline.hip", "vf_pgemm.hip", "vf_conv_thin.hip", "vf_comm.hip", "vf_wgrad_small.hip", "vf_smallm.hip", "vf_trace.hip", "vf_net.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]

@@ -1406,6 +1406,8 @@ static void launch_igemm_tile(vf_ctx* ctx, const IGemm& g, dim3 grid, bool bkm, 
 
 // vecA / vecB: 16-byte loads legal for the A / B operand.  top: this launch writes the pass's output tensor itself (an inner
 // GEMM into a column buffer does not), so a pending BatchNorm-statistics attachment (vf_bn_fuse_next_*) applies to it.
+int vf_internal_smallm_plan(int form, int M, int N, int K, size_t ws_bytes);                                                   // vf_smallm.hip
+int vf_internal_smallm_launch(vf_ctx* ctx, int form, const float* A, const float* W, float* slab, int M, int N, int K, int ksplit);
 static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB, bool top = true) {
   const int zpar = g.parity ? 4 : 1;
   const bool bkm = g.wsN == 1 && g.wsC != 1;
@@ -1459,6 +1461,21 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB, bool top = 
     if (ksplit < 1) ksplit = 1;
     const int steps = (int)vf_cdiv(g.nk, ksplit);  // avoid empty trailing splits
     ksplit = (int)vf_cdiv(g.nk, steps);
+  }
+  // ---- the bottleneck GEMMs at a small batch (M <= 8 rows against hundreds of MB of weights): a weight-streaming kernel instead
+  // of a tile (vf_smallm.hip); it leaves split-K slabs, which the combine below takes like the tiled kernel's
+  int sm_form = -1;
+  if (!g.parity && g.lgMh == 0 && g.lgMw == 0 && g.M <= 8 && v == 2) {
+    if (!bkm && g.Hi == g.TH && g.Wi == g.TW && g.oy0 == 0 && g.ox0 == 0 && g.sy == 1 && g.sx == 1 && g.ty == 1 && g.tx == 1 && g.wsC == 1 &&
+        g.wsTap == g.C && g.wsN == Ktot && g.kh0 == 0 && g.kw0 == 0 && g.khs == 1 && g.kws == 1)
+      sm_form = 0;        // A rows and weight rows are K = taps * C contiguous floats
+    else if (bkm && g.TH * g.TW == 1 && g.Hi == 1 && g.Wi == 1 && g.wsC == g.N)
+      sm_form = 1;        // weights [C][N], N contiguous
+    if (sm_form >= 0) {
+      const int s = vf_internal_smallm_plan(sm_form, g.M, g.N, Ktot, vf_ws_avail(ctx));
+      if (s >= 2) ksplit = s;
+      else sm_form = -1;
+    }
   }
   g.ksplit = ksplit;
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
@@ -1524,7 +1541,9 @@ static int launch_igemm(vf_ctx* ctx, IGemm& g, bool vecA, bool vecB, bool top = 
                   (tune_db == 2 || (tune_db == 1 && (int64_t)grid.x <= 2 * 256));
   snprintf(pname, sizeof(pname), "igemm_%dx%d_%s_v%d%s%s", t.bm, t.bn, bkm ? "kmajorB" : "rowB", v,
            ctx->mfma_bf16 == 3 ? "_bf16x3" : (ctx->mfma_bf16 ? "_bf16" : ""), db ? "_db" : "");
-  {
+  if (sm_form >= 0) {
+    if (int rc = vf_internal_smallm_launch(ctx, sm_form, g.A, g.Wt, g.slab, g.M, g.N, Ktot, ksplit)) return rc;
+  } else {
     const double fl = 2.0 * (double)g.M * g.N * Ktot * zpar;
     if (t.bm == 256)
       launch_igemm_tile<256, 32, 64, 32>(ctx, g, grid, bkm, v, pname, fl);

@@ -1,0 +1,206 @@
+// vf_smallm.hip — the bottleneck GEMMs at a small batch: M = batchSize <= 8 rows against a weight matrix of hundreds of MB
+// (train_wholeim_input.lua at batchSize 4: conv nef*8 -> 6400 on a 4x4 map, 24576 x 6400 weights = 629 MB, and the full-conv back;
+// forward and data-gradient of each: four passes per iteration).
+//
+// 2 M flops per weight: the job is reading the weights once.  The tiled matrix-core kernel of vf_conv.hip (64 x 128 tiles,
+// LDS stages, a barrier per K step, split-K) ran these passes at 3.4-3.8 TB/s; here a wave streams weight rows with 16-byte
+// loads straight into fp32 FMAs — no LDS, no barrier, no matrix core (its tile would be 4 live rows of 32) — and leaves split-K
+// slabs in the layout vf_conv.hip's combine kernels already take (bias, activation, derivative mask, BatchNorm statistics):
+//
+//   row-dot  (weights [N][K], K contiguous: conv forward on the 4x4 map, full-conv data-gradient)
+//            y[b][n] = sum_k A[b][k] W[n][k]: a wave owns 8 weight rows and one K range; per step of 256 floats every lane
+//            holds a float4 of each of the 8 rows and of the M activation rows (L2 hits, shared by the 8 rows), 32 M FMAs;
+//            one cross-lane reduction at the end.
+//   axpy     (weights [K][N], N contiguous: full-conv forward from the 1x1 map, conv data-gradient)
+//            y[b][col] += A[b][c] W[c][col]: a wave owns 256 columns (a float4 per lane) and one range of c; the M
+//            activation values of a c are wave-uniform (scalar loads), the weight row segment is one coalesced 1 KB load.
+//
+// fp32 products and sums (at least as accurate as the three-plane matrix-core mode these passes otherwise use); in the
+// bf16-operand mode both operands are rounded to bf16 on their way in, as everywhere.  Deterministic: fixed summation order.
+#include <algorithm>
+#include <cstdlib>
+
+#include "vf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float sm_rne(float f) {
+  const unsigned u = __float_as_uint(f);
+  return __uint_as_float(((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16) << 16);
+}
+__device__ __forceinline__ f32x4 sm_rne4(f32x4 v) {
+  f32x4 o = {sm_rne(v[0]), sm_rne(v[1]), sm_rne(v[2]), sm_rne(v[3])};
+  return o;
+}
+
+// ---- row-dot: slab[ks][b][n] = sum_{k in range ks} A[b][k] W[n][k]
+// grid: (N / 8 row groups) x ksplit waves, four waves per block (consecutive row groups of the same K range)
+template <int MT>
+__global__ __launch_bounds__(256) void k_smallm_rowdot(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ slab,
+                                                       int M, int N, int K, int steps_per_split, int ngroups, int rb) {
+  constexpr int R = 8;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // (wave-uniform, and known to be)
+  const int ks = wv / ngroups, grp = wv - ks * ngroups;
+  const int n0 = grp * R;
+  const int64_t k0 = (int64_t)ks * steps_per_split * 256 + 4 * lane;
+  const float* wp = W + (int64_t)n0 * K + k0;
+  const float* ap = A + k0;
+  float acc[R][MT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[r][b] = 0.f;
+  struct Stage { f32x4 w[R], x[MT]; };
+  auto load = [&](int s, Stage& st) {
+    const int64_t o = (int64_t)s * 256;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) st.x[b] = b < M ? *(const f32x4*)(ap + (int64_t)b * K + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < R; ++r) st.w[r] = __builtin_nontemporal_load((const f32x4*)(wp + (int64_t)r * K + o));
+  };
+  auto fma = [&](Stage& st) {
+    if (rb) {
+#pragma unroll
+      for (int b = 0; b < MT; ++b) st.x[b] = sm_rne4(st.x[b]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) st.w[r] = sm_rne4(st.w[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[r][b] = fmaf(st.w[r][e], st.x[b][e], acc[r][b]);
+  };
+  Stage s0, s1;
+  load(0, s0);
+  for (int s = 0; s < steps_per_split; s += 2) {
+    if (s + 1 < steps_per_split) load(s + 1, s1);
+    fma(s0);
+    if (s + 2 < steps_per_split) load(s + 2, s0);
+    if (s + 1 < steps_per_split) fma(s1);
+  }
+  // the 64 lanes' partial sums meet in a fixed butterfly
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      float v = acc[r][b];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      acc[r][b] = v;
+    }
+  if (lane == 0) {
+    float* o = slab + (int64_t)ks * M * N + n0;
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+      if (b < M) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) o[(int64_t)b * N + r] = acc[r][b];
+      }
+  }
+}
+
+// ---- axpy: slab[ks][b][col] = sum_{c in range ks} A[b][c] W[c][col]
+// grid: (N / 256 column groups) x ksplit waves, four waves per block (consecutive column groups of the same c range)
+template <int MT>
+__global__ __launch_bounds__(256) void k_smallm_axpy(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ slab,
+                                                     int M, int N, int C, int c_per_split, int ngroups, int rb) {
+  constexpr int CH = 8;                       // weight rows in flight per stage
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // (so that A[b][c] below is a scalar load)
+  const int ks = wv / ngroups, grp = wv - ks * ngroups;
+  const int col = grp * 256 + 4 * lane;
+  const int c0 = ks * c_per_split;
+  const float* wp = W + (int64_t)c0 * N + col;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int b = 0; b < MT; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  struct Stage { f32x4 w[CH]; };
+  auto load = [&](int c, Stage& st) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) st.w[j] = __builtin_nontemporal_load((const f32x4*)(wp + (int64_t)(c + j) * N));
+  };
+  auto fma = [&](int c, Stage& st) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      f32x4 w = st.w[j];
+      if (rb) w = sm_rne4(w);
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        if (b < M) {
+          float a = A[(int64_t)b * C + c0 + c + j];       // wave-uniform: a scalar load
+          if (rb) a = sm_rne(a);
+          acc[b] += a * w;
+        }
+      }
+    }
+  };
+  Stage s0, s1;
+  load(0, s0);
+  for (int c = 0; c < c_per_split; c += 2 * CH) {
+    if (c + CH < c_per_split) load(c + CH, s1);
+    fma(c, s0);
+    if (c + 2 * CH < c_per_split) load(c + 2 * CH, s0);
+    if (c + CH < c_per_split) fma(c + CH, s1);
+  }
+  float* o = slab + (int64_t)ks * M * N + col;
+#pragma unroll
+  for (int b = 0; b < MT; ++b)
+    if (b < M) *(f32x4*)(o + (int64_t)b * N) = acc[b];
+}
+
+}  // namespace
+
+// Plans a small-M pass.  form 0: row-dot (W = [N][K]); form 1: axpy (W = [K][N]).  Returns the split count (>= 2), or 0 when the
+// shape is not these kernels' (the caller keeps its tiled path).
+int vf_internal_smallm_plan(int form, int M, int N, int K, size_t ws_bytes) {
+  static const bool off = getenv("VF_NO_SMALLM") && atoi(getenv("VF_NO_SMALLM"));
+  if (off || M < 1 || M > 8) return 0;
+  static const int want_waves = getenv("VF_SMALLM_WAVES") ? atoi(getenv("VF_SMALLM_WAVES")) : 4096;      // ~4 per SIMD
+  int ksplit = 0;
+  if (form == 0) {
+    if (K % 256 != 0 || N % 32 != 0) return 0;          // (four 8-row groups per block)
+    const int steps = K / 256, groups = N / 8;
+    for (int s = 2; s <= steps; ++s)
+      if (steps % s == 0 && (steps / s) % 2 == 0) {      // whole double steps per split
+        ksplit = s;
+        if ((int64_t)groups * s >= want_waves) break;
+      }
+  } else {
+    if (N % 1024 != 0 || K % 16 != 0) return 0;          // (four 256-column groups per block)
+    const int chunks = K / 16, groups = N / 256;
+    for (int s = 2; s <= chunks; ++s)
+      if (chunks % s == 0) {
+        ksplit = s;
+        if ((int64_t)groups * s >= want_waves) break;
+      }
+  }
+  if (ksplit < 2 || (size_t)ksplit * M * N * sizeof(float) > ws_bytes) return 0;
+  return ksplit;
+}
+
+int vf_internal_smallm_launch(vf_ctx* ctx, int form, const float* A, const float* W, float* slab, int M, int N, int K, int ksplit) {
+  const int rb = ctx->mfma_bf16 == 1;
+  const double flops = 2.0 * M * (double)N * K, bytes = 4.0 * ((double)N * K + (double)M * K + (double)ksplit * M * N);
+  if (form == 0) {
+    const int groups = N / 8, steps = K / 256 / ksplit;
+    const dim3 grid((unsigned)((int64_t)groups * ksplit / 4));
+    if (M <= 4)
+      VF_LAUNCH_TIMED(ctx, "smallm_rowdot", flops, bytes, k_smallm_rowdot<4>, grid, dim3(256), A, W, slab, M, N, K, steps, groups, rb);
+    else
+      VF_LAUNCH_TIMED(ctx, "smallm_rowdot", flops, bytes, k_smallm_rowdot<8>, grid, dim3(256), A, W, slab, M, N, K, steps, groups, rb);
+  } else {
+    const int groups = N / 256, cps = K / ksplit;
+    const dim3 grid((unsigned)((int64_t)groups * ksplit / 4));
+    if (M <= 4)
+      VF_LAUNCH_TIMED(ctx, "smallm_axpy", flops, bytes, k_smallm_axpy<4>, grid, dim3(256), A, W, slab, M, N, K, cps, groups, rb);
+    else
+      VF_LAUNCH_TIMED(ctx, "smallm_axpy", flops, bytes, k_smallm_axpy<8>, grid, dim3(256), A, W, slab, M, N, K, cps, groups, rb);
+  }
+  VF_LAUNCH_CHECK();
+  return 0;
+}
