@@ -34,7 +34,10 @@ def bench_name(k):
     if "k_deconv_thin_out" in k:
         return "deconv_thin_out"
     if "k_wgrad_smallk" in k:      # <NJ, FUSE>: FUSE = optim.adam in the epilogue (vf_wgrad_adam_outer)
-        return "adam_fused_wgrad" if re.search(r"k_wgrad_smallk<\d+, true>", k) else "wgrad_smallk_f32"
+        return "adam_fused_wgrad" if re.search(r"k_wgrad_smallk<\d+, true", k) else "wgrad_smallk_f32"
+    m = re.search(r"k_smallm_(rowdot|axpy)", k)
+    if m:
+        return "smallm_" + m.group(1)
     m = re.match(r"void k_pconv<(\d+), (\d+), \d+, \d+, (\d+), (\d+), (\w+)>", k)
     if m:
         return "pconv_%sx%sx%s_t%s%s" % (m.group(1), m.group(2), m.group(4), m.group(3), "_pair" if m.group(5) == "true" else "")
