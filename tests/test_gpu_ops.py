@@ -565,6 +565,45 @@ def test_bottleneck_weight_gradients_small_batch(Bn, nB, C8, hipb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Bn,nB,C8", [(4, 640, 64), (3, 128, 128), (8, 96, 64), (1, 64, 64), (5, 3200, 192), (4, 200, 32), (9, 128, 64)])
+def test_bottleneck_forward_and_data_gradient_small_batch(Bn, nB, C8, hipb):
+    """vf_smallm.hip: the four bottleneck passes (train.lua:104 conv on the 4x4 map, :134 full-conv from the 1x1 map; forward and
+    data-gradient of each) at batchSize <= 8 — weight-streaming row-dot / axpy kernels + the split-K combine (bias, activation) —
+    against fp64; odd batch sizes, and shapes / batch sizes the kernels do not take (those stay on the tiled kernel: same bars)."""
+    g = torch.Generator().manual_seed(Bn * 100 + C8)
+    r = lambda *s: torch.randn(*s, generator=g).to(hipb.device)
+    tol = 2e-5
+    rel = lambda got, want: float((got.double().cpu() - want).abs().max() / want.abs().max())
+    # conv C8 -> nB on a 4x4 map (weights physical [nB][4][4][C8])
+    x = r(Bn, 4, 4, C8).permute(0, 3, 1, 2)
+    w = (r(nB, 4, 4, C8) * 0.05).permute(0, 3, 1, 2)
+    bias = r(nB)
+    y = hipb.empty_act(Bn, nB, 1, 1)
+    hipb.conv2d_fwd(x, w, bias, y, 4, 1, 0, "lrelu", 0.2)
+    want = torch.einsum("bchw,nchw->bn", x.double().cpu(), w.double().cpu()) + bias.double().cpu()
+    want = torch.where(want > 0, want, 0.2 * want)
+    assert rel(y.reshape(Bn, nB), want) < tol
+    gy = r(Bn, 1, 1, nB).permute(0, 3, 1, 2)
+    gx = hipb.empty_act(Bn, C8, 4, 4)
+    hipb.conv2d_bwd_data(gy, w, gx, 4, 1, 0)
+    want = torch.einsum("bn,nchw->bchw", gy.double().cpu().reshape(Bn, nB), w.double().cpu())
+    assert rel(gx, want) < tol
+    # full-conv nB -> C8 from the 1x1 map (weights physical [nB][4][4][C8])
+    x2 = r(Bn, 1, 1, nB).permute(0, 3, 1, 2)
+    w2 = (r(nB, 4, 4, C8) * 0.05).permute(0, 3, 1, 2)
+    b2 = r(C8)
+    y2 = hipb.empty_act(Bn, C8, 4, 4)
+    hipb.deconv2d_fwd(x2, w2, b2, y2, 4, 1, 0, "relu", 0.0)
+    want = torch.einsum("bi,iohw->bohw", x2.double().cpu().reshape(Bn, nB), w2.double().cpu()) + b2.double().cpu().view(1, C8, 1, 1)
+    assert rel(y2, want.clamp(min=0)) < tol
+    gy2 = r(Bn, 4, 4, C8).permute(0, 3, 1, 2)
+    gx2 = hipb.empty_act(Bn, nB, 1, 1)
+    hipb.deconv2d_bwd_data(gy2, w2, gx2, 4, 1, 0)
+    want = torch.einsum("bohw,iohw->bi", gy2.double().cpu(), w2.double().cpu())
+    assert rel(gx2.reshape(Bn, nB), want) < tol
+
+
+@pytest.mark.gpu
 def test_bce_forward_and_backward_in_one_launch(hipb):
     """vf_bce_fwd_bwd against vf_bce_fwd + vf_bce_bwd: one group, and two groups with their own labels (netD's real and fake
     halves) — element for element the same arithmetic, so bitwise."""
