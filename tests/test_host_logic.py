@@ -110,6 +110,21 @@ def test_lazy_zero_equals_memset(cpu_backend):
     assert rel_err(out[0][0], out[1][0]) < 1e-6 and rel_err(out[0][1], out[1][1]) < 1e-6
 
 
+def test_exchange_ranges_leave_out_the_fused_slices(cpu_backend):
+    """the data-parallel step all-reduces everything BUT the slices whose operands are gathered (trainers._exchange_ranges); on
+    this backend (the mirror host) nothing is fused and the whole bucket travels"""
+    from video_filler_amd.trainers import CenterTrainer
+    tr = CenterTrainer(dict(SMALL, wtl2=0.999, overlapPred=4), seed=5)
+    assert tr.fuse_adam == "on" and tr.fuse_adam_slices() == [] and tr.fused_adam_ranges() == []
+    assert tr._exchange_ranges(0, 50) == [(0, 50)]
+    tr._dpf = [(30, 40), (10, 20)]
+    assert tr._exchange_ranges(0, 50) == [(0, 10), (20, 30), (40, 50)]
+    assert tr._exchange_ranges(15, 35) == [(20, 30)]
+    assert tr._exchange_ranges(10, 20) == [] and tr._exchange_ranges(40, 50) == [(40, 50)]
+    assert tr._exchange_ranges(0, 10) == [(0, 10)] and tr._exchange_ranges(12, 18) == []
+    tr._dpf = []
+
+
 def test_gradient_buckets_and_split_backward(cpu_backend):
     """Data-parallel bucketing: the tail bucket (bottleneck conv + decoder) owns > 90 % of netG's gradient bytes and is
     final after the upper part of the backward walk; the cut walk equals the uncut one."""
