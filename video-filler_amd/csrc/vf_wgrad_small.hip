@@ -235,7 +235,7 @@ int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float*
 // loads, so half the bytes are in flight, and the other half's MFMAs have one or two waves per SIMD to hide their operand latency
 // with instead of three.  Start-up phase offsets between the waves of the plain form (so that one wave's MFMAs fall into the
 // others' memory phase) only added their own delay: 178 -> 188 / 201 / 256 us for offsets of 1 / 3 / 8 x 4096 cycles.
-struct VfFusedArgs {          // host-side plan of a multi-layer update (validated layers, tile counts, segment shifts)
+struct VfFusedArgs {
   int nl;
   int tile_off[VF_FUSED_MAX + 1];
   int tiles_c[VF_FUSED_MAX];
