@@ -77,6 +77,8 @@ line = ("rank %d/%d  batch %d/rank  fused slices %s  gather buffer %d floats  | 
         "adam m %.2e  netD %.3f lr  |  replicas bit-identical: %s" % (rank, world, b, ranges, on._opbuf.numel(), err_g, err_p, err_m, err_d, same))
 print(line, flush=True)
 ok = err_g < 1e-4 and err_p < 0.05 and err_m < 1e-3 and same
+if not ok:
+    sys.stderr.write("dp_rehearsal FAILED on " + line + "\n")
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)

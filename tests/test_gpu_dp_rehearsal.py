@@ -27,7 +27,7 @@ def test_gathered_operand_exchange_with_real_ranks(world):
            "--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "dp_rehearsal.py")]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     # (every rank exits non-zero on a failed check and torchrun passes that on; the ranks' lines may interleave on the shared stdout)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-6000:])
     assert r.stdout.count("replicas bit-identical: True") == world, r.stdout[-2000:]
     lines = [r.stdout]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
