@@ -29,7 +29,9 @@ from video_filler_amd.trainers import CenterTrainer
 
 B = get_backend()
 b = int(os.environ.get("VF_REHEARSAL_BATCH", "4"))
-opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4, nef=32, ngf=32, ndf=32, batchSize=b)
+# (smooth nets — every (Leaky)ReLU replaced by LeakyReLU(1.0), same graph and kernels: two trajectories that differ by fp32
+#  rounding must not be told apart by an activation that sits at its kink, tests/test_gpu_trainers.py)
+opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4, nef=32, ngf=32, ndf=32, batchSize=b, smooth=True)
 gen = torch.Generator().manual_seed(7)
 full = torch.rand((world * b, 3, 128, 128), generator=gen) * 2 - 1          # the same draw on every rank; rank r takes shard r
 shard = full[rank * b:(rank + 1) * b].contiguous()
