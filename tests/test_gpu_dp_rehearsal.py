@@ -26,6 +26,10 @@ def test_gathered_operand_exchange_with_real_ranks(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "dp_rehearsal.py")]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    if r.returncode != 0:
+        with open(os.path.join(ROOT, "gpurun_out", "dp_rehearsal_%d_failed.log" % world), "a") as fh:
+            fh.write("==== stdout\n" + r.stdout + "\n==== stderr\n" + r.stderr + "\n")
     # (every rank exits non-zero on a failed check and torchrun passes that on; the ranks' lines may interleave on the shared stdout)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-6000:])
     assert r.stdout.count("replicas bit-identical: True") == world, r.stdout[-2000:]

@@ -330,7 +330,12 @@ class HipBackend:
                                                          _COMM_OP[op]))
             return
         import torch.distributed as dist
+        host = dist.get_backend(group) != "nccl"
+        if host:
+            self._host_sync()
         dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=group)
+        if host:
+            self._host_sync()
 
     def all_reduce_avg(self, t, world, group=None, async_op=False):
         """Mean over ranks of a flat gradient bucket.  RCCL averages inside the collective (no extra pass over the
@@ -349,9 +354,17 @@ class HipBackend:
         if dist.get_backend(group) == "nccl":
             h = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
             return h if async_op else None
+        self._host_sync()
         dist.all_reduce(t, group=group)
+        self._host_sync()
         self.scale_shift(t, 1.0 / world, 0.0)
         return None
+
+    def _host_sync(self):
+        """around a host-side (gloo) collective on device tensors: the producers of its input have finished and its result has
+        landed before anything else is launched — this path is the CPU tests' and the one-GPU rehearsal's, never a timed one"""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def reduce_scatter_avg(self, t, world, rank, group=None):
         """mean over ranks of shard `rank` of the flat vector t (numel % world == 0), in place at t[rank * n : (rank + 1) * n];
@@ -364,7 +377,9 @@ class HipBackend:
             _CommHandle(self, ticket.value).wait()
         else:       # (gloo has no reduce-scatter: the whole vector is averaged, the shard read out of it)
             import torch.distributed as dist
+            self._host_sync()
             dist.all_reduce(t, group=group)
+            self._host_sync()
             self.scale_shift(t, 1.0 / world, 0.0)
         return t[rank * n:(rank + 1) * n]
 
@@ -383,7 +398,9 @@ class HipBackend:
             return None
         import torch.distributed as dist
         parts = [t[r * n:(r + 1) * n] for r in range(world)]
+        self._host_sync()
         dist.all_gather(parts, parts[rank].clone(), group=group)
+        self._host_sync()
         return None
 
     def _c(self, name, *args):
