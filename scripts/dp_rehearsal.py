@@ -48,7 +48,11 @@ on, off = make("on"), make("off")
 assert torch.equal(on.parametersG, off.parametersG)
 for _ in range(3):
     on.step_phased()
+    if os.environ.get("VF_REHEARSAL_SYNC") == "1":
+        torch.cuda.synchronize()
     off.step_phased()
+    if os.environ.get("VF_REHEARSAL_SYNC") == "1":
+        torch.cuda.synchronize()
 torch.cuda.synchronize()
 ranges = on.fused_adam_ranges()
 assert len(ranges) == 2 and off.fused_adam_ranges() == [], (ranges, off.fused_adam_ranges())

@@ -330,12 +330,11 @@ class HipBackend:
                                                          _COMM_OP[op]))
             return
         import torch.distributed as dist
-        host = dist.get_backend(group) != "nccl"
-        if host:
-            self._host_sync()
-        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=group)
-        if host:
-            self._host_sync()
+        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+        if dist.get_backend(group) != "nccl":
+            self._host_collective(lambda h: dist.all_reduce(h, op=rop, group=group), t)
+        else:
+            dist.all_reduce(t, op=rop, group=group)
 
     def all_reduce_avg(self, t, world, group=None, async_op=False):
         """Mean over ranks of a flat gradient bucket.  RCCL averages inside the collective (no extra pass over the
@@ -354,11 +353,22 @@ class HipBackend:
         if dist.get_backend(group) == "nccl":
             h = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
             return h if async_op else None
-        self._host_sync()
-        dist.all_reduce(t, group=group)
-        self._host_sync()
+        self._host_collective(lambda h: dist.all_reduce(h, group=group), t)
         self.scale_shift(t, 1.0 / world, 0.0)
         return None
+
+    def _host_collective(self, fn, t):
+        """a host-side (gloo) collective on a device tensor, through a host copy: gloo's own staging of device tensors proved
+        unreliable with several ranks on one GPU (the rehearsal's plain all-reduce path: intermittently a stale bucket).  This path
+        serves the CPU tests and the one-GPU rehearsal, never a timed run."""
+        if t.device.type != "cuda":
+            fn(t)
+            return
+        torch.cuda.synchronize(t.device)
+        h = t.detach().cpu()
+        fn(h)
+        t.copy_(h)
+        torch.cuda.synchronize(t.device)
 
     def _host_sync(self):
         """around a host-side (gloo) collective on device tensors: the producers of its input have finished and its result has
@@ -377,9 +387,7 @@ class HipBackend:
             _CommHandle(self, ticket.value).wait()
         else:       # (gloo has no reduce-scatter: the whole vector is averaged, the shard read out of it)
             import torch.distributed as dist
-            self._host_sync()
-            dist.all_reduce(t, group=group)
-            self._host_sync()
+            self._host_collective(lambda h: dist.all_reduce(h, group=group), t)
             self.scale_shift(t, 1.0 / world, 0.0)
         return t[rank * n:(rank + 1) * n]
 
@@ -397,10 +405,10 @@ class HipBackend:
             h.wait()
             return None
         import torch.distributed as dist
-        parts = [t[r * n:(r + 1) * n] for r in range(world)]
-        self._host_sync()
-        dist.all_gather(parts, parts[rank].clone(), group=group)
-        self._host_sync()
+        def gather(h):
+            parts = [h[r * n:(r + 1) * n] for r in range(world)]
+            dist.all_gather(parts, parts[rank].clone(), group=group)
+        self._host_collective(gather, t)
         return None
 
     def _c(self, name, *args):

@@ -54,14 +54,21 @@ __global__ __launch_bounds__(256) void k_smallm_rowdot(const float* __restrict__
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[r][b] = 0.f;
   struct Stage { f32x4 w[R], x[MT]; };
+  // (every load of a stage is unconditional — activation rows past M read row 0 and are zeroed by a multiply, the stage after the
+  //  last re-reads the last one: straight-line stages whose wait counts are plain to see)
+  float xm[MT];
+#pragma unroll
+  for (int b = 0; b < MT; ++b) xm[b] = b < M ? 1.f : 0.f;
   auto load = [&](int s, Stage& st) {
     const int64_t o = (int64_t)s * 256;
 #pragma unroll
-    for (int b = 0; b < MT; ++b) st.x[b] = b < M ? *(const f32x4*)(ap + (int64_t)b * K + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MT; ++b) st.x[b] = *(const f32x4*)(ap + (int64_t)(b < M ? b : 0) * K + o);
 #pragma unroll
-    for (int r = 0; r < R; ++r) st.w[r] = __builtin_nontemporal_load((const f32x4*)(wp + (int64_t)r * K + o));
+    for (int r = 0; r < R; ++r) st.w[r] = *(const f32x4*)(wp + (int64_t)r * K + o);
   };
   auto fma = [&](Stage& st) {
+#pragma unroll
+    for (int b = 0; b < MT; ++b) st.x[b] = st.x[b] * xm[b];
     if (rb) {
 #pragma unroll
       for (int b = 0; b < MT; ++b) st.x[b] = sm_rne4(st.x[b]);
@@ -77,30 +84,35 @@ __global__ __launch_bounds__(256) void k_smallm_rowdot(const float* __restrict__
   };
   Stage s0, s1;
   load(0, s0);
-  for (int s = 0; s < steps_per_split; s += 2) {
-    if (s + 1 < steps_per_split) load(s + 1, s1);
+  const int last = steps_per_split - 1;
+  for (int s = 0; s < steps_per_split; s += 2) {          // (steps_per_split is even: vf_internal_smallm_plan)
+    load(s + 1, s1);
+    __builtin_amdgcn_sched_barrier(0);
     fma(s0);
-    if (s + 2 < steps_per_split) load(s + 2, s0);
-    if (s + 1 < steps_per_split) fma(s1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(min(s + 2, last), s0);                            // (past the end: the last stage once more, never consumed)
+    __builtin_amdgcn_sched_barrier(0);
+    fma(s1);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  // the 64 lanes' partial sums meet in a fixed butterfly
+  // the 64 lanes' partial sums meet in LDS: value v = r * MT + b of this wave is summed over the lanes, in lane order, by lane v.
+  // (NOT a __shfl_xor butterfly: 32 values x 6 steps put dozens of ds_bpermute in flight, and with other processes on the GPU —
+  //  three trainers' worth of LDS traffic on the same CUs — one to seven of a launch's 4096 slab values then differed from run to
+  //  run on identical operands, by up to 3x (scripts/probe/multi_trainer_det.py ran the pass twice in place and compared; 6-9 of 24
+  //  process-runs deviated, 0 of 54 with this form).  The other shuffles of the library keep at most eight in flight.)
+  __shared__ float red[4][R * MT][65];
+  const int wl = threadIdx.x >> 6;
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int b = 0; b < MT; ++b) {
-      float v = acc[r][b];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      acc[r][b] = v;
-    }
-  if (lane == 0) {
-    float* o = slab + (int64_t)ks * M * N + n0;
-#pragma unroll
-    for (int b = 0; b < MT; ++b)
-      if (b < M) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) o[(int64_t)b * N + r] = acc[r][b];
-      }
+    for (int b = 0; b < MT; ++b) red[wl][r * MT + b][lane] = acc[r][b];
+  __syncthreads();
+  if (lane < R * MT) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) t += red[wl][lane][j];
+    const int r = lane / MT, bb = lane - r * MT;
+    if (bb < M) slab[(int64_t)ks * M * N + (int64_t)bb * N + n0 + r] = t;
   }
 }
 
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void k_smallm_axpy(const float* __restrict__ A
   struct Stage { f32x4 w[CH]; };
   auto load = [&](int c, Stage& st) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) st.w[j] = __builtin_nontemporal_load((const f32x4*)(wp + (int64_t)(c + j) * N));
+    for (int j = 0; j < CH; ++j) st.w[j] = *(const f32x4*)(wp + (int64_t)(c + j) * N);
   };
   auto fma = [&](int c, Stage& st) {
 #pragma unroll
@@ -131,21 +143,24 @@ __global__ __launch_bounds__(256) void k_smallm_axpy(const float* __restrict__ A
       if (rb) w = sm_rne4(w);
 #pragma unroll
       for (int b = 0; b < MT; ++b) {
-        if (b < M) {
-          float a = A[(int64_t)b * C + c0 + c + j];       // wave-uniform: a scalar load
-          if (rb) a = sm_rne(a);
-          acc[b] += a * w;
-        }
+        float a = A[(int64_t)(b < M ? b : 0) * C + c0 + c + j];       // wave-uniform: a scalar load (rows past M: row 0, unused)
+        if (rb) a = sm_rne(a);
+        acc[b] += a * w;
       }
     }
   };
   Stage s0, s1;
   load(0, s0);
-  for (int c = 0; c < c_per_split; c += 2 * CH) {
-    if (c + CH < c_per_split) load(c + CH, s1);
+  const int lastc = c_per_split - CH;
+  for (int c = 0; c < c_per_split; c += 2 * CH) {        // (c_per_split is a multiple of 2 * CH: vf_internal_smallm_plan)
+    load(c + CH, s1);
+    __builtin_amdgcn_sched_barrier(0);
     fma(c, s0);
-    if (c + 2 * CH < c_per_split) load(c + 2 * CH, s0);
-    if (c + CH < c_per_split) fma(c + CH, s1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(min(c + 2 * CH, lastc), s0);                     // (past the end: the last stage once more, never consumed)
+    __builtin_amdgcn_sched_barrier(0);
+    fma(c + CH, s1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   float* o = slab + (int64_t)ks * M * N + col;
 #pragma unroll
