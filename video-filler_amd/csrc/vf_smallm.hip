@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_smallm_rowdot(const float* __restrict__
 #pragma unroll
     for (int b = 0; b < MT; ++b) st.x[b] = *(const f32x4*)(ap + (int64_t)(b < M ? b : 0) * K + o);
 #pragma unroll
-    for (int r = 0; r < R; ++r) st.w[r] = *(const f32x4*)(wp + (int64_t)r * K + o);
+    for (int r = 0; r < R; ++r) st.w[r] = __builtin_nontemporal_load((const f32x4*)(wp + (int64_t)r * K + o));      // (read once)
   };
   auto fma = [&](Stage& st) {
 #pragma unroll
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_smallm_axpy(const float* __restrict__ A
   struct Stage { f32x4 w[CH]; };
   auto load = [&](int c, Stage& st) {
 #pragma unroll
-    for (int j = 0; j < CH; ++j) st.w[j] = *(const f32x4*)(wp + (int64_t)(c + j) * N);
+    for (int j = 0; j < CH; ++j) st.w[j] = __builtin_nontemporal_load((const f32x4*)(wp + (int64_t)(c + j) * N));      // (read once)
   };
   auto fma = [&](int c, Stage& st) {
 #pragma unroll
