@@ -5,17 +5,35 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
-from video_filler_amd.trainers import CenterTrainer
-b = 4
-opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4, nef=32, ngf=32, ndf=32, batchSize=b, smooth=True)
+from video_filler_amd.trainers import CenterTrainer, VidTrainer
+# VF_PROBE_NET: small (default: train.lua's nets at nef 32, batch 4) | center (BASELINE configs[1], full width, batch 64) |
+#               vid16 (configs[2], batch 16) | wholeim (configs[4], batch 4)
+NET = os.environ.get("VF_PROBE_NET", "small")
 gen = torch.Generator().manual_seed(7)
-shard = (torch.rand((b, 3, 128, 128), generator=gen) * 2 - 1).contiguous()
+if NET in ("small", "center"):
+    b = 4 if NET == "small" else 64
+    opt = (dict(nBottleneck=128, wtl2=0.999, overlapPred=4, nef=32, ngf=32, ndf=32, batchSize=b, smooth=True) if NET == "small"
+           else dict(nBottleneck=4000, wtl2=0.999, overlapPred=4, batchSize=b))
+    batch = ((torch.rand((b, 3, 128, 128), generator=gen) * 2 - 1).contiguous(),)
+    cls = CenterTrainer
+else:
+    b, nci, nco = (16, 48, 48) if NET == "vid16" else (4, 27, 12)
+    opt = (dict(batchSize=b, nBottleneck=4000, predLen=16) if NET == "vid16"
+           else dict(batchSize=b, nc_in=27, nc_out=12, nef=192, ngf=192, ndf=128, nBottleneck=6400, weight_nomask=1, wtgdl=0.5))
+    full = torch.rand((b, nco, 128, 128), generator=gen) * 2 - 1
+    mask = torch.zeros((b, nco, 128, 128), dtype=torch.uint8)
+    mask[:, :, 32:96, 32:96] = 1
+    ctx = (torch.rand((b, nci, 128, 128), generator=gen) * 2 - 1) if nci != nco else full.clone()
+    if nci == nco:
+        ctx[mask != 0] = 2 * (110.0 / 255.0) - 1
+    batch = (ctx.contiguous(), full.contiguous(), mask)
+    cls = VidTrainer
 def make():
-    tr = CenterTrainer(opt, seed=11, host=os.environ.get("VF_PROBE_HOST", "cabi"))
+    tr = cls(opt, seed=11, host=os.environ.get("VF_PROBE_HOST", "cabi"))
     tr.fuse_adam = os.environ.get("VF_PROBE_FUSE", "off")
-    tr.set_batch(shard)
+    tr.set_batch(*batch)
     return tr
-trs = [make() for _ in range(4)]
+trs = [make() for _ in range(int(os.environ.get("VF_PROBE_TRAINERS", "4")))]
 bad = 0
 # taps: what fGx feeds into netG:backward, and what netD:updateGradInput returned before the reconstruction gradient was mixed in
 taps = {id(t): {} for t in trs}
@@ -40,7 +58,7 @@ def segs(net, flat_a, flat_b):
         if d > 0:
             out.append("%d:%s.%s %.2e" % (i, type(m).__name__[:8], name, d))
     return out
-for it in range(6):
+for it in range(int(os.environ.get("VF_PROBE_ITERS", "6"))):
     snaps = []
     for t in trs:
         t.step()
