@@ -519,7 +519,7 @@ int vf_net_fused_adam_pack(vf_net* net, float* segment);
 int vf_net_adam_fused_gathered(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1,
                                double beta2, double eps, const int32_t* t_dev, int keep_grad);
 /* SyncBN: BatchNorm sums all-reduced over `comm` (world ranks; statistics of the global batch).  force: take that path at world 1
- * too.  comm NULL / world 1 / force 0: device-local statistics. */
+ * too.  comm NULL / world 1 / force 0: device-local statistics.  world > 1 with comm NULL is refused (it would silently be local). */
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);
 /* Weight planes (bf16 shadows of the conv weights the planes kernels read).  Unmanaged (default): refreshed at the start of every
  * forward / backward call.  Managed: the host calls vf_net_refresh_weight_planes once after each parameter update (optim.adam, a

@@ -87,3 +87,8 @@ for it in range(int(os.environ.get("VF_PROBE_ITERS", "6"))):
         sg = segs(trs[k].netG, snaps[k][1], snaps[ref][1]); print("   gradG segments (%d of %d differ), the last ones: %s" % (len(sg), len(trs[k].netG._flat[2]), sg[-14:]))
         break
 print("pid %d done, %d mismatching iterations" % (os.getpid(), bad), flush=True)
+try:                                    # a CHECK build of scripts/probe/rowdot_variants.hip: what its per-launch checker logged
+    from video_filler_amd import _lib
+    _lib.load().vf_probe_rowdot_report()
+except AttributeError:
+    pass

@@ -10,7 +10,7 @@ box):
            wtgdl = 0.5 so that the GDL value path runs (batchSize 4)
 
 Stored: the four loss scalars, every STRIDE-th entry (+ double-precision sum and sum of squares) of both gradient
-vectors and both parameter vectors after the Adam steps, and of the generator's output; plus a strided sample of the
+vectors, both parameter vectors and Adam's first and second moments (m, v) after the Adam steps, and of the generator's output; plus a strided sample of the
 INITIAL parameters so that a reader can check it rebuilt the same weights.  Inputs are regenerated from seeds
 (`tests/helpers.py`: FastRng / fast_init_flat; oracle.synth_*_batch), so the files hold results only.
 """
@@ -59,7 +59,8 @@ def make(name):
     r = tr.step()
     out["losses"] = np.array([r["errD"], r["errG"], r["errG_l2"], r.get("errG_gdl") or 0.0], np.float64)
     for nm, vec in (("gG", tr.gradParametersG), ("gD", tr.gradParametersD), ("pG", tr.parametersG), ("pD", tr.parametersD),
-                    ("fake", tr.netG.output)):
+                    ("fake", tr.netG.output), ("mG", tr.optimStateG["m"]), ("vG", tr.optimStateG["v"]), ("mD", tr.optimStateD["m"]),
+                    ("vD", tr.optimStateD["v"])):
         out[nm + "_sample"], out[nm + "_sums"] = summarize(vec)
     out["n_params"] = np.array([tr.parametersG.size, tr.parametersD.size], np.int64)
     path = os.path.join(HERE, "full_%s.npz" % name)

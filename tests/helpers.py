@@ -230,15 +230,3 @@ def grads_reference_order(tr, net, gref):
         for lo, hi in ranges:
             flat[lo:hi] = want[lo:hi]
     return from_internal(net, flat)
-
-
-def unwritten_grad_mask(tr, net):
-    """bool numpy vector in reference order: the elements of net's gradient vector that step() does not write (see
-    grads_reference_order); None when there are none"""
-    ranges = tr.fused_adam_ranges() if net is tr.netG and hasattr(tr, "fused_adam_ranges") else []
-    if not ranges:
-        return None
-    flat = torch.zeros_like(net._flat[1])
-    for lo, hi in ranges:
-        flat[lo:hi] = 1.0
-    return from_internal(net, flat) > 0.5

@@ -128,3 +128,21 @@ def test_range_helpers_balance_without_a_gpu():
     assert lib.vf_range_depth() == d0
     if d0 == 0:
         assert lib.vf_range_pop() != 0 and b"no range" in lib.vf_last_error()
+
+
+def test_shipped_code_objects_hold_no_packed_fma_with_a_high_dword_src1_select():
+    """scripts/check_pk_opsel.py over the built library: `v_pk_fma_f32 ... op_sel:[0,1,0]` (and its mul / add / src2 relatives) gives
+    wrong low results in lanes 48-63 on gfx950 when other processes share the CU — the cause of round 3's run-to-run differences
+    (DESIGN.md 4.9).  The compiler chooses the form by itself, so the guard is on the binary: a kernel that acquires it after a
+    source change fails HERE, before it reaches a GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_pk_opsel", os.path.join(ROOT, "scripts", "check_pk_opsel.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    flagged, kernels = chk.scan(os.path.join(ROOT, "video-filler_amd", "lib", "libvf_hip.so"))
+    assert kernels >= 150, "the scan did not find the library's kernels (%d)" % kernels
+    assert not flagged, "packed FP32 instructions selecting the high dword of src1/src2: %s" % flagged[:5]
+    # the detector itself: the instruction text of the round-3 kernel is flagged, the shipped form is not
+    assert chk.PK.search("v_pk_fma_f32 v[12:13], v[22:23], v[18:19], v[12:13] op_sel:[0,1,0]")
+    m = chk.PK.search("v_pk_fma_f32 v[4:5], v[26:27], v[6:7], v[4:5] op_sel:[1,0,0]")
+    assert m and not any(int(b) for b in m.group(2).split(",")[1:])

@@ -148,10 +148,10 @@ def test_hip_reproduces_iteration_vectors(kind, hipb):
     fake = to_np(tr.netG.output).reshape(-1)
     assert rel_err(fake[::mk.STRIDE], z["fake0_sample"]) < 1e-4
     # real (kinked) nets at batch 2: see tests/test_gpu_trainers.py for why gradients get 3e-2
-    from helpers import unwritten_grad_mask
-    gs, skip = to_np(tr.netG.reference_flat(grads=True))[::mk.STRIDE], unwritten_grad_mask(tr, tr.netG)
-    if skip is not None:       # (the bottleneck pair's weight gradients are consumed inside the fused Adam kernel)
-        gs = np.where(skip[::mk.STRIDE], z["gG0_sample"], gs)
+    # (the bottleneck pair's weight gradients are consumed inside the fused Adam kernel: after this FIRST update they are read
+    #  back from Adam's first moment, g = m / (1 - beta1) exactly — helpers.grads_reference_order — never substituted)
+    from helpers import grads_reference_order
+    gs = grads_reference_order(tr, tr.netG, None)[::mk.STRIDE]
     assert rel_err(gs, z["gG0_sample"]) < 3e-2
 
 

@@ -134,3 +134,35 @@ def test_syncbn_collectives_are_captured_with_the_phases(kind, oracle, hipb):
     assert torch.equal(graph.parametersG, eager.parametersG) and torch.equal(graph.parametersD, eager.parametersD)
     # seven Adam steps later the trajectories are still together (Adam amplifies rounding on near-zero gradients: DESIGN.md)
     assert rel_err(graph.parametersG.cpu().numpy(), plain.parametersG.cpu().numpy()) < 5e-2
+
+
+def test_torch_distributed_fallback_collectives_stay_on_the_device(hipb):
+    """bench.py --comm torch / the --comm auto fallback: no C-ABI communicator, an NCCL (= RCCL) process group.  Every collective
+    the data-parallel step uses must run on the DEVICE tensor (reduce_scatter_avg / all_gather_shards went through a
+    host copy, which an NCCL-only group refuses) — a world of one rank, where every collective is the identity."""
+    import os
+    import torch.distributed as dist
+    B = hipb
+    saved, B.comm = B.comm, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=B.device)
+    try:
+        assert dist.get_backend() == "nccl"
+        v = torch.randn(1 << 16, device=B.device)
+        v0 = v.clone()
+        sh = B.reduce_scatter_avg(v, 1, 0)
+        B.all_gather_shards(v, 1, 0)
+        h = B.all_gather_shards(v, 1, 0, async_op=True)
+        h.wait()
+        B.all_reduce_avg(v, 1)
+        s = torch.arange(8, dtype=torch.float64, device=B.device)
+        B.all_reduce(s, op="sum")
+        torch.cuda.synchronize()
+        assert sh.data_ptr() == v.data_ptr() and torch.equal(v, v0) and torch.equal(s.cpu(), torch.arange(8, dtype=torch.float64))
+    finally:
+        B.comm = saved
+        if own:
+            dist.destroy_process_group()

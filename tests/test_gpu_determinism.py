@@ -1,26 +1,46 @@
-"""Run-to-run determinism with OTHER processes on the GPU.  On a GPU of its own a kernel whose result depends on what else runs on
-its CUs can look deterministic for ever (every bit-for-bit test of this suite passed on the first form of vf_smallm.hip's row-dot
-kernel); three processes at once expose it: each steps four identical trainers in turn, and every trainer must walk the same
-trajectory bit for bit (scripts/probe/multi_trainer_det.py).  The first form of that kernel — a 32-value x 6-step ds_bpermute
-butterfly — failed this in 6-9 of 24 process-runs; the LDS reduction that replaced it in 0 of 54."""
-import os
-import subprocess
-import sys
+"""Run-to-run determinism of the small-batch bottleneck passes (csrc/vf_smallm.hip), in ONE process: the same pass repeated in
+place on the same operands leaves the same split-K slabs and the same output, bit for bit.
 
+Round 3's first row-dot kernel gave run-to-run different values when other processes shared the GPU.  Round 4 found the cause
+(DESIGN.md 4.9): the compiler had packed its fmaf chains into `v_pk_fma_f32 ... op_sel:[0,1,0]`, an operand form that on gfx950
+occasionally drops its low result in lanes 48-63 under GPU sharing.  That form is kept out of the shipped code objects by a STATIC
+check in the CPU suite (scripts/check_pk_opsel.py, tests/test_cabi.py) — which is what guards the library; this test is the cheap
+in-place repeat, not a reproduction attempt (the fault needs busy neighbours: scripts/probe/mt_variants.sh holds that recipe and
+profiles/r04_rowdot_* what it showed)."""
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("fuse", ["on", "off"])
-def test_identical_trainers_agree_bit_for_bit_with_other_processes_on_the_gpu(fuse):
-    env = dict(os.environ, VF_PROBE_FUSE=fuse)
-    script = os.path.join(ROOT, "scripts", "probe", "multi_trainer_det.py")
-    for _ in range(2):
-        procs = [subprocess.Popen([sys.executable, script], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-                 for _ in range(3)]
-        outs = [p.communicate(timeout=600)[0] for p in procs]
-        for p, out in zip(procs, outs):
-            assert p.returncode == 0, out[-3000:]
-            assert "MISMATCH" not in out and "0 mismatching iterations" in out, out[-3000:]
+@pytest.mark.parametrize("form", ["rowdot", "axpy"])
+def test_small_batch_bottleneck_pass_repeats_bit_for_bit(form, hipb):
+    B = hipb
+    g = torch.Generator().manual_seed(3)
+    Bn, nB, C8 = 4, 128, 256
+    if form == "rowdot":        # conv nef*8 -> nBottleneck on the 4x4 map (train_wholeim_input.lua's E6 at reduced width): W [N][K]
+        x = torch.randn(Bn, 4, 4, C8, generator=g).to(B.device).permute(0, 3, 1, 2)
+        w = (torch.randn(nB, 4, 4, C8, generator=g) * 0.05).to(B.device).permute(0, 3, 1, 2)
+        y = B.empty_act(Bn, nB, 1, 1)
+        run = lambda: B.conv2d_fwd(x, w, None, y, 4, 1, 0)
+        nslab = 8 * Bn * nB
+    else:                       # full-conv nBottleneck -> ngf*8 from the 1x1 map (D1): W [K][N]
+        x = torch.randn(Bn, 1, 1, nB, generator=g).to(B.device).permute(0, 3, 1, 2)
+        w = (torch.randn(nB, 4, 4, C8, generator=g) * 0.05).to(B.device).permute(0, 3, 1, 2)
+        y = B.empty_act(Bn, C8, 4, 4)
+        run = lambda: B.deconv2d_fwd(x, w, None, y, 4, 1, 0)
+        nslab = 8 * Bn * 16 * C8
+    slab = B.workspace[:nslab * 4].view(torch.float32)
+    slab.zero_()
+    run()
+    torch.cuda.synchronize()
+    assert float(slab.abs().max()) > 0, "the pass did not take the split-K small-batch kernels"
+    ref_y, ref_slab = y.clone(), slab.clone()
+    filler = torch.randn(1 << 22, device=B.device)
+    for i in range(300):
+        if i % 3 == 0:
+            filler.mul_(1.0001)            # (something else in flight)
+        y.zero_()
+        slab.zero_()
+        run()
+        assert torch.equal(slab, ref_slab) and torch.equal(y, ref_y), "run %d differs" % i

@@ -246,11 +246,11 @@ def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb, p
     """One whole iteration (fDx + Adam + fGx + Adam) at FULL net width against the CPU oracle's result for the same seeds,
     computed in the build container and committed (tests/golden/full_<name>.npz; `center8` is BASELINE.json configs[0]: the
     train.lua recipe at batchSize 8, nBottleneck 4000).  Bars: losses 2e-5; generator output 1e-4 of its max; gradient
-    samples 2e-2 of the vector's max-norm — the kink effect of tests/test_gpu_trainers.py without the pin (a fixture
+    samples (the fused slices read back from Adam's first moment) and Adam's m / v samples 2e-2 / 4e-2 of the vector's max-norm — the kink effect of tests/test_gpu_trainers.py without the pin (a fixture
     cannot carry the oracle's activations), at batch sizes 4-8; the updated parameters within 2% of one learning-rate step
     wherever the gradient is significant."""
     import os
-    from helpers import FastRng, fast_init_flat, rel_err, to_np, unwritten_grad_mask
+    from helpers import FastRng, fast_init_flat, from_internal, grads_reference_order, rel_err, to_np
     from video_filler_amd.trainers import CenterTrainer, VidTrainer
     mk, gdir = _golden_full()
     cfg = mk.CONFIGS[name]
@@ -272,17 +272,20 @@ def test_full_width_iteration_matches_the_committed_oracle_fixture(name, hipb, p
     fake = to_np(tr.netG.output).reshape(-1)[::mk.STRIDE]
     assert rel_err(fake, z["fake_sample"]) < 1e-4
     lrG, lrD = tr.optimStateG["learningRate"], tr.optimStateD["learningRate"]
-    for net, gk, pk, lr in ((tr.netG, "gG", "pG", lrG), (tr.netD, "gD", "pD", lrD)):
-        g = to_np(net.reference_flat(grads=True))
+    for net, gk, pk, lr, st in ((tr.netG, "gG", "pG", lrG, tr.optimStateG), (tr.netD, "gD", "pD", lrD, tr.optimStateD)):
+        # the slices the fused Adam kernel consumed (E6 / D1: 92 % of netG's weights) are read back from Adam's first moment —
+        # after this FIRST update g = m / (1 - beta1) exactly (helpers.grads_reference_order); nothing is substituted
+        g = grads_reference_order(tr, net, None)
         gs, want = g[::mk.STRIDE], z[gk + "_sample"]
-        skip = unwritten_grad_mask(tr, net)      # (consumed inside the fused Adam kernel: the parameter check below vouches for them)
-        if skip is not None:
-            gs = np.where(skip[::mk.STRIDE], want, gs)
         # the samples' own max understates the vector's max-norm; the stored sum of squares gives its rms scale
         scale = max(np.abs(want).max(), 1e-30)
         assert np.abs(gs - want).max() <= 2e-2 * scale, (gk, np.abs(gs - want).max() / scale)
-        if skip is None:
-            assert abs(float(g.astype(np.float64).sum()) - z[gk + "_sums"][0]) <= 2e-2 * np.sqrt(z[gk + "_sums"][1] * g.size)
+        assert abs(float(g.astype(np.float64).sum()) - z[gk + "_sums"][0]) <= 2e-2 * np.sqrt(z[gk + "_sums"][1] * g.size)
+        # Adam's moments themselves, every sampled element (first update: m = (1 - beta1) g, v = (1 - beta2) g^2)
+        for nm, key, bar in (("m", "m" + gk[1], 2e-2), ("v", "v" + gk[1], 4e-2)):
+            have = from_internal(net, st[nm])[::mk.STRIDE]
+            w = z[key + "_sample"]
+            assert np.abs(have - w).max() <= bar * max(np.abs(w).max(), 1e-30), (key, np.abs(have - w).max() / max(np.abs(w).max(), 1e-30))
         p = to_np(net.reference_flat())[::mk.STRIDE]
         sel = np.abs(want) > 1e-2 * scale
         assert np.abs(p - z[pk + "_sample"])[sel].max() <= 0.02 * lr, (pk, np.abs(p - z[pk + "_sample"])[sel].max() / lr)

@@ -407,3 +407,47 @@ def test_net_object_activation_observer(oracle, hipb):
     h.forward(x)
     assert not seen
     h.close()
+
+
+def test_net_object_conv_relu_then_batchnorm_chain(oracle, hipb):
+    """conv(4x4 s2) + LeakyReLU -> BatchNorm -> conv: an ordering the reference nets do not have but vf_net / hipnn.Net accept.
+    The BatchNorm's backward writes the planes of its gradInput for the convolution below; that convolution first undoes its fused
+    LeakyReLU on the gradient IN PLACE, so the planes are stale and must not be used (the data-gradient and the weight
+    gradient of that layer were formed from the unmasked gradient).  Real LeakyReLU(0.2): the bug is an O(1) error, a kink flip
+    moves 1e-3, so 2e-2 separates them.  Planes gate dropped so that the planes path is what runs."""
+    lib = hipb.lib
+    assert lib.vf_net_set_planes_gate(0.0, 1) == 0
+    oracle.set_num_threads(16)
+    try:
+        rng = np.random.default_rng(11)
+        net = oracle.Sequential()
+        for m in (oracle.SpatialConvolution(16, 64, 4, 4, 2, 2, 1, 1), oracle.LeakyReLU(0.2, True),
+                  oracle.SpatialConvolution(64, 64, 4, 4, 2, 2, 1, 1), oracle.LeakyReLU(0.2, True), oracle.SpatialBatchNormalization(64),
+                  oracle.SpatialConvolution(64, 128, 4, 4, 2, 2, 1, 1), oracle.LeakyReLU(0.2, True)):
+            net.add(m)
+        oracle.weights_init(net, rng)
+        shape = (16, 16, 64, 64)
+        h = Host(hipb, net, shape)
+        h.load_from_oracle()
+        x = rng.uniform(-1, 1, shape).astype(np.float32)
+        y = net.forward(x.copy())
+        gy = rng.standard_normal(y.shape).astype(np.float32)
+        for m in _oleaves(net):
+            if hasattr(m, "gradWeight"):
+                m.gradWeight[...] = 0
+                m.gradBias[...] = 0
+        gx_want = net.backward(x.copy(), gy.copy()).copy()
+        xd, gyd = h.dev_in(x), h.dev_in(gy)
+        got = h.download(h.forward(xd), y.size)
+        assert rel_err(got.reshape(y.transpose(0, 2, 3, 1).shape), y.transpose(0, 2, 3, 1)) <= 2e-5
+        h.ok(h.lib.vf_net_zero_grad(h.net))
+        gxp = C.c_void_p()
+        h.ok(h.lib.vf_net_backward(h.net, C.c_void_p(xd.data_ptr()), C.c_void_p(gyd.data_ptr()), C.byref(gxp)))
+        assert rel_err(h.read_act(gxp.value, shape), gx_want) <= 2e-2, "gradInput"
+        for i, which, got, t in h.grads():
+            scale = max(np.abs(h.mods[i].gradWeight).max(), np.abs(h.mods[i].gradBias).max())
+            assert np.abs(got - t).max() <= 2e-2 * scale, ("gradient", i, which, np.abs(got - t).max() / scale)
+        h.close()
+    finally:
+        oracle.set_num_threads(1)
+        assert lib.vf_net_set_planes_gate(3.0, 1024) == 0

@@ -277,6 +277,35 @@ def test_graph_replay_matches_eager(oracle, hipb, planes_gate, host):
         assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k]))
 
 
+def test_checkpoint_load_after_capture_reaches_the_replayed_graph(oracle, hipb, planes_gate, host):
+    """load_reference_flat AFTER capture() (a checkpoint load): the captured fDx holds no refresh of netD's weight planes (the
+    host-side staleness test ran once, at capture time), so replay() must refresh them in front of the graph — else the first
+    replayed netD passes multiply the OLD weights' planes.  Same trajectory as an eager trainer given the same load."""
+    from video_filler_amd.trainers import CenterTrainer
+    opt = dict(nBottleneck=64, wtl2=0.999, overlapPred=4)
+    batch = torch.from_numpy(oracle.synth_center_batch(4, np.random.default_rng(5)))
+    a, b = CenterTrainer(opt, seed=3), CenterTrainer(opt, seed=3)
+    a.set_batch(batch)
+    b.set_batch(batch)
+    for _ in range(3):
+        a.step()
+    b.capture(warmup=3)
+    gen = torch.Generator().manual_seed(9)
+    for net_a, net_b in ((a.netD, b.netD), (a.netG, b.netG)):
+        flat = net_a.reference_flat()
+        new = flat + 0.02 * torch.randn(flat.shape, generator=gen).to(flat.device) * flat.abs().mean()
+        net_a.load_reference_flat(new)
+        net_b.load_reference_flat(new)
+    a.step()
+    b.replay()
+    torch.cuda.synchronize()
+    assert rel_err(to_np(b.parametersD), to_np(a.parametersD)) < 1e-6
+    assert rel_err(to_np(b.parametersG), to_np(a.parametersG)) < 1e-6
+    la, lb = a.losses(), b.losses()
+    for k in ("errD", "errG", "errG_l2"):
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+
+
 @pytest.mark.parametrize("kind", ["center", "vid"])
 def test_adam_overlap_walks_the_same_trajectory(kind, oracle, hipb, planes_gate):
     """Adam(G) split over two streams (the two bottleneck weight tensors beside the next iteration's encoder forward,

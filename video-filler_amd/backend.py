@@ -331,10 +331,7 @@ class HipBackend:
             return
         import torch.distributed as dist
         rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
-        if dist.get_backend(group) != "nccl":
-            self._host_collective(lambda h: dist.all_reduce(h, op=rop, group=group), t)
-        else:
-            dist.all_reduce(t, op=rop, group=group)
+        dist.all_reduce(t, op=rop, group=group)
 
     def all_reduce_avg(self, t, world, group=None, async_op=False):
         """Mean over ranks of a flat gradient bucket.  RCCL averages inside the collective (no extra pass over the
@@ -353,28 +350,12 @@ class HipBackend:
         if dist.get_backend(group) == "nccl":
             h = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
             return h if async_op else None
-        self._host_collective(lambda h: dist.all_reduce(h, group=group), t)
+        # (gloo, the CPU tests and the one-GPU rehearsal: it stages device tensors itself, ordered with the current stream, which
+        #  is this backend's.  Round 3 wrapped these calls in a host copy after "intermittently a stale bucket" in the rehearsal;
+        #  that was the packed-FMA fault of the then row-dot kernel showing under GPU sharing — DESIGN.md 4.9 — not gloo.)
+        dist.all_reduce(t, group=group)
         self.scale_shift(t, 1.0 / world, 0.0)
         return None
-
-    def _host_collective(self, fn, t):
-        """a host-side (gloo) collective on a device tensor, through a host copy: gloo's own staging of device tensors proved
-        unreliable with several ranks on one GPU (the rehearsal's plain all-reduce path: intermittently a stale bucket).  This path
-        serves the CPU tests and the one-GPU rehearsal, never a timed run."""
-        if t.device.type != "cuda":
-            fn(t)
-            return
-        torch.cuda.synchronize(t.device)
-        h = t.detach().cpu()
-        fn(h)
-        t.copy_(h)
-        torch.cuda.synchronize(t.device)
-
-    def _host_sync(self):
-        """around a host-side (gloo) collective on device tensors: the producers of its input have finished and its result has
-        landed before anything else is launched — this path is the CPU tests' and the one-GPU rehearsal's, never a timed one"""
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
 
     def reduce_scatter_avg(self, t, world, rank, group=None):
         """mean over ranks of shard `rank` of the flat vector t (numel % world == 0), in place at t[rank * n : (rank + 1) * n];
@@ -385,10 +366,13 @@ class HipBackend:
             ticket = C.c_int32(-1)
             _lib.check(self.lib.vf_comm_reduce_scatter_avg_async(self.comm, self.ctx, _ptr(t), n, C.byref(ticket)))
             _CommHandle(self, ticket.value).wait()
-        else:       # (gloo has no reduce-scatter: the whole vector is averaged, the shard read out of it)
+        else:
             import torch.distributed as dist
-            self._host_collective(lambda h: dist.all_reduce(h, group=group), t)
-            self.scale_shift(t, 1.0 / world, 0.0)
+            if dist.get_backend(group) == "nccl":      # RCCL through torch.distributed: on the device, in place (recv = send + rank * n)
+                dist.reduce_scatter_tensor(t[rank * n:(rank + 1) * n], t, op=dist.ReduceOp.AVG, group=group)
+            else:       # (gloo has no reduce-scatter: the whole vector is averaged, the shard read out of it)
+                dist.all_reduce(t, group=group)
+                self.scale_shift(t, 1.0 / world, 0.0)
         return t[rank * n:(rank + 1) * n]
 
     def all_gather_shards(self, t, world, rank, group=None, async_op=False):
@@ -405,10 +389,11 @@ class HipBackend:
             h.wait()
             return None
         import torch.distributed as dist
-        def gather(h):
-            parts = [h[r * n:(r + 1) * n] for r in range(world)]
-            dist.all_gather(parts, parts[rank].clone(), group=group)
-        self._host_collective(gather, t)
+        if dist.get_backend(group) == "nccl":          # RCCL through torch.distributed: on the device, in place (send = recv + rank * n)
+            h = dist.all_gather_into_tensor(t, t[rank * n:(rank + 1) * n], group=group, async_op=async_op)
+            return h if async_op else None
+        parts = [t[r * n:(r + 1) * n] for r in range(world)]
+        dist.all_gather(parts, parts[rank].clone(), group=group)
         return None
 
     def _c(self, name, *args):

@@ -123,7 +123,13 @@ class CNet(nn.Sequential):
         self._push("managed", bool(self._wp_managed), lambda v: lib.vf_net_set_weight_planes_managed(self._net, 1 if v else 0))
         _lib.check(lib.vf_net_set_planes_gate(float(nn._PCONV_MIN_GFLOP), int(nn._PCONV_MIN_ROWS)))      # (process-wide on both sides)
         sync = self._sync_state()
-        self._push("sync", sync, lambda v: lib.vf_net_set_sync_bn(self._net, get_backend().comm if v[0] > 1 else None, v[0], 1 if v[1] else 0))
+        comm = get_backend().comm
+        if sync[0] > 1 and comm is None:
+            raise RuntimeError("SyncBN over vf_net needs the C-ABI communicator (backend.comm); without it the trainers keep such "
+                               "nets on the module-by-module host (trainers._host_nets)")
+        # (keyed by the communicator too: one attached after the first forward must reach the net)
+        self._push("sync", sync + (getattr(comm, "value", None),),
+                   lambda v: lib.vf_net_set_sync_bn(self._net, comm if (v[0] > 1 or v[1]) else None, v[0], 1 if v[1] else 0))
         hook = nn.Sequential.act_hook
         if (hook is not None) != (self._cb is not None):
             if hook is not None:

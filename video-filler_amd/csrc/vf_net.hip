@@ -546,6 +546,7 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
         const bool ours = g != gy;
         if (relu_like(l.fused_act) && ours) {
           rc = vf_act_bwd(ctx, mout, g, const_cast<float*>(g), out_e, l.fused_act, l.fused_slope);
+          g_pl = nullptr;      // (planes a BatchNorm above wrote hold the UNMASKED gradient: conv + ReLU -> BN chains)
         } else {
           if (!l.gtmp && (rc = net_alloc(n->act_owned, (void**)&l.gtmp, sizeof(float) * (size_t)n->B * l.Ho * l.Wo * l.Co))) break;
           rc = vf_act_bwd(ctx, mout, g, l.gtmp, out_e, l.fused_act, l.fused_slope);
@@ -1014,6 +1015,8 @@ VF_API int vf_net_set_planes_gate(double min_gflop, int min_rows) {
 }
 VF_API int vf_net_set_sync_bn(vf_net* n, vf_comm* comm, int world, int force) {
   VF_REQUIRE(n && world >= 1, "vf_net_set_sync_bn: bad arguments");
+  // (a world of several ranks without a communicator would silently normalise with rank-local statistics)
+  VF_REQUIRE(world == 1 || comm != nullptr, "vf_net_set_sync_bn: world = %d needs a communicator (vf_comm_init)", world);
   n->comm = comm;
   n->sync_world = world;
   n->sync_force = force != 0;

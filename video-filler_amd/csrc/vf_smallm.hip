@@ -96,10 +96,14 @@ __global__ __launch_bounds__(256) void k_smallm_rowdot(const float* __restrict__
     __builtin_amdgcn_sched_barrier(0);
   }
   // the 64 lanes' partial sums meet in LDS: value v = r * MT + b of this wave is summed over the lanes, in lane order, by lane v.
-  // (NOT a __shfl_xor butterfly: 32 values x 6 steps put dozens of ds_bpermute in flight, and with other processes on the GPU —
-  //  three trainers' worth of LDS traffic on the same CUs — one to seven of a launch's 4096 slab values then differed from run to
-  //  run on identical operands, by up to 3x (scripts/probe/multi_trainer_det.py ran the pass twice in place and compared; 6-9 of 24
-  //  process-runs deviated, 0 of 54 with this form).  The other shuffles of the library keep at most eight in flight.)
+  // (History, DESIGN.md 4.9: the first form of this kernel ended in a __shfl_xor butterfly with all 32 results stored by lane 0,
+  //  and gave run-to-run different slabs when other processes shared the GPU.  Round 3 blamed the butterfly; round 4 found the
+  //  cause in the FMA phase above: storing PAIRS OF ROWS from one lane made the compiler pack the chains as
+  //  `v_pk_fma_f32 acc[r:r+1], w[r:r+1], x.hi ... op_sel:[0,1,0]`, a form that on gfx950 occasionally drops its low result in lanes
+  //  48-63 under GPU sharing (checker kernel: the per-lane partials in front of the reduction equal the chain with exactly that
+  //  FMA missing; the same instruction with src0/src1 exchanged, or split into two v_fma_f32, never failed).  With this epilogue
+  //  the compiler packs pairs of activation rows instead (`op_sel:[1,0,0]`), which is what the shipped code objects hold —
+  //  scripts/check_pk_opsel.py keeps it that way, in the CPU suite.)
   __shared__ float red[4][R * MT][65];
   const int wl = threadIdx.x >> 6;
 #pragma unroll

@@ -940,6 +940,7 @@ class Sequential(Module):
                                     gb_ = bufs[tuple(g.shape)] = torch.empty_like(g)
                                 B.act_bwd(mout, g, gb_, a.act, a.slope)
                                 g = gb_
+                            g_pl = None       # (planes a BatchNorm above wrote hold the UNMASKED gradient: conv + ReLU -> BN chains)
                         a.gradInput = g
                     # the module below is a bare conv + in-place (leaky) ReLU: its activation backward rides in this
                     # module's data-gradient epilogue (x IS that activated output)

@@ -35,11 +35,15 @@ DEFAULT_OPT_VID = dict(batchSize=16, fineSize=128, nBottleneck=4000, nef=64, ngf
 DEFAULT_HOST = os.environ.get("VF_HOST", "cabi")
 
 
-def _host_nets(host, netG, netD):
+def _host_nets(host, netG, netD, sync_world=1):
     host = host or DEFAULT_HOST
     assert host in ("mirror", "cabi"), host
     if getattr(get_backend(), "name", "") != "hip-gfx950":
         host = "mirror"        # (a test backend on the CPU: host logic only — vf_net lives in libvf_hip.so)
+    if host == "cabi" and sync_world > 1 and getattr(get_backend(), "comm", None) is None:
+        # SyncBN inside vf_net exchanges its sums through vf_comm_*; without that communicator (bench.py --comm torch, or the
+        # --comm auto fallback) the module-by-module mirror carries the exchange over torch.distributed instead
+        host = "mirror"
     if host == "cabi":
         from .cnet import adopt_if_chain
         return adopt_if_chain(netG), adopt_if_chain(netD), host
@@ -577,6 +581,8 @@ class _TrainerBase:
         B = get_backend()
         pa, pb, pb2, pc = ([g.replay for g in self._graphs] if self._graphs is not None
                            else [self._phase_a, self._phase_b, self._phase_b2, self._phase_c])
+        if self._graphs is not None:
+            self._refresh_planes_written_outside_the_graph()
         _, off = self.netG.bucket_split()
         gG = self.gradParametersG
         pa()
@@ -623,6 +629,8 @@ class _TrainerBase:
         pa1, pa2, pb, pb2 = ([g.replay for g in self._graphs] if self._graphs is not None
                              else [self._phase_a1, self._phase_a2, self._phase_b, self._phase_b2])
         assert not self._graph_stale, "flush() was called: the captured graphs would apply Adam(G) twice; capture again"
+        if self._graphs is not None:
+            self._refresh_planes_written_outside_the_graph()
         _, off = self.netG.bucket_split()
         gG = self.gradParametersG
         pa1()
@@ -717,8 +725,17 @@ class _TrainerBase:
         self._pending_g = False
         return g
 
+    def _refresh_planes_written_outside_the_graph(self):
+        """fDx refreshes netD's weight planes only when the host-side parameter version says they are stale, and that test is
+        evaluated once, at capture time.  A parameter write OUTSIDE the graph (load_reference_flat: a checkpoint load) bumps the
+        version afterwards: refresh eagerly, in front of the replay."""
+        for net in (self.netD, self.netG):
+            if getattr(net, "_wp_managed", False) and net._wp_stale():
+                net.refresh_weight_planes()
+
     def replay(self):
         assert not self._graph_stale, "flush() was called: the captured graph would apply Adam(G) twice; capture() again"
+        self._refresh_planes_written_outside_the_graph()
         self._graph.replay()
 
     def losses(self):
@@ -742,7 +759,7 @@ class CenterTrainer(_TrainerBase):
         if o["conditionAdv"] and skip_dead_grads:
             self.netD.modules[0].skip_grad = (0,)     # nobody reads the gradient w.r.t. the context (train.lua:371)
         if fuse:
-            self.netG, self.netD, self.host = _host_nets(host, self.netG, self.netD)
+            self.netG, self.netD, self.host = _host_nets(host, self.netG, self.netD, world if sync_bn else 1)
         else:
             self.host = "mirror"
         self.criterionMSE = nn.MSECriterion() if o["wtl2"] != 0 else None
@@ -895,7 +912,7 @@ class VidTrainer(_TrainerBase):
                                half_last=bool(o.get("logoNet", False)), extra_bottleneck_stage=_ext256(o))
         self.netD = build_netD(self.nc_out, o["ndf"], True, fuse, lazy_zero, sm, extra_last_layer=_ext256(o))
         if fuse:
-            self.netG, self.netD, self.host = _host_nets(host, self.netG, self.netD)
+            self.netG, self.netD, self.host = _host_nets(host, self.netG, self.netD, world if sync_bn else 1)
         else:
             self.host = "mirror"
         self.netI = None                 # withInit: set_initializer(net) (train_vid_weighted.lua:260-264)
