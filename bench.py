@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--fuse-adam", default="on", choices=["on", "keep", "off"], help="N=1: optim.adam(fGx) applied to the two bottleneck weight "
                     "tensors inside the kernel that forms their gradient (vf_wgrad_adam_outer: 24 B per weight instead of 32). on (default): "
                     "gradParametersG does not receive those two slices; keep: it does (28 B); off: accGradParameters + the plain update")
+    ap.add_argument("--dp-fused", default="gathered", choices=["gathered", "rows", "reduced"], help="N>1: what becomes of the bottleneck "
+                    "pair's gradient (262 of G's 284 MB): gathered (default) = every rank all-gathers the pair's OPERANDS (6 MB per rank) and "
+                    "forms the global-batch gradient of all rows inside the fused update; rows = the same gather, each rank updates its "
+                    "1/N of the rows and the updated rows are all-gathered; reduced = the gradients are all-reduced like the rest")
     ap.add_argument("--adam-overlap", action="store_true", help="N=1: update Adam(G)'s two bottleneck weight tensors on a side stream "
                     "beside the next encoder forward (measured: -4 %%: the 2048-block HBM stream slows the convolutions it shares "
                     "the chip with by more than it hides)")
@@ -194,6 +198,7 @@ def main():
     dp = world > 1 or args.force_dist
     tr.force_comm = args.force_dist
     tr.fuse_adam = args.fuse_adam
+    tr.dp_fused = args.dp_fused
     if args.no_batch_d and tr.batch_d:
         tr.set_batch_d(False)
     use_graph = not args.no_graph and not (dp and args.sync_bn)
@@ -483,6 +488,7 @@ def main():
                        "host": ("vf_net_* (C-ABI net object: forward / backward / updateGradInput are one library call each)" if tr.host == "cabi"
                                 else "nn.py mirror (module by module over the C-ABI)"),
                        "bn": ("sync" if args.sync_bn else "local") if world > 1 else "single-device",
+                       "dp_fused": (args.dp_fused if dp and tr.fuse_adam != "off" else None),
                        "exchange": (("vf_comm_* (C-ABI, RCCL; verified at start-up on every rank)" if B.comm is not None else "torch.distributed (%s)" % args.backend) if dp else None)},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -314,6 +314,11 @@ int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int 
 int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu,
                                  int Ncols, float* x, float* m, float* v, float* g, float gscale, double beta1, double beta2,
                                  double eps, const int32_t* t_dev);
+/* the same for rows [row0, row0 + nrows) of the tensors only (row0 even, nrows even and >= 64; x, m, v, g point at row 0): the
+ * data-parallel update sharded by weight rows — bit for bit what the whole-tensor call gives those rows */
+int vf_wgrad_adam_outer_rows(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu, int Ncols,
+                             int row0, int nrows, float* x, float* m, float* v, float* g, float gscale, double beta1, double beta2,
+                             double eps, const int32_t* t_dev);
 
 /* ---- batch preparation and the inference tile loop (the data formats either side of the closures) ---------
  * train.lua:284-298: from the loader's batch (B x C x fs x fs planar, [-1,1]) produce the NHWC generator input with
@@ -518,6 +523,12 @@ int vf_net_fused_adam_pack_size(const vf_net* net, int64_t* floats);
 int vf_net_fused_adam_pack(vf_net* net, float* segment);
 int vf_net_adam_fused_gathered(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1,
                                double beta2, double eps, const int32_t* t_dev, int keep_grad);
+/* ... with the update sharded by weight ROWS: this rank (row_rank of row_world) forms the global-batch gradient of its 1 / row_world of
+ * every fused tensor's rows and updates them (m, v: those rows only); the host then all-gathers the updated rows of each
+ * vf_net_fused_adam_range slice (equal, contiguous row blocks).  vf_net_fused_adam_rows_ok: do the row counts split that way? */
+int vf_net_fused_adam_rows_ok(const vf_net* net, int row_world);
+int vf_net_adam_fused_gathered_rows(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1,
+                                    double beta2, double eps, const int32_t* t_dev, int keep_grad, int row_rank, int row_world);
 /* SyncBN: BatchNorm sums all-reduced over `comm` (world ranks; statistics of the global batch).  force: take that path at world 1
  * too.  comm NULL / world 1 / force 0: device-local statistics.  world > 1 with comm NULL is refused (it would silently be local). */
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);

@@ -3,7 +3,11 @@ about the N > 1 iteration.  Every rank runs the train.lua nets through the C-ABI
 
   * `on`  : the phased step with the bottleneck pair's OPERANDS all-gathered and the global-batch gradient formed inside the fused
             Adam kernel on every rank (trainers._phase_b / _phase_c, vf_net_fused_adam_pack / vf_net_adam_fused_gathered);
-  * `off` : the same step with that pair's gradients all-reduced like the rest.
+  * `off` : the same step with that pair's gradients all-reduced like the rest;
+  * `rows`: `on` with the fused update SHARDED BY WEIGHT ROWS (trainer.dp_fused = "rows": rank r forms and applies rows
+            [r R / N, (r + 1) R / N) of the pair, the updated rows are all-gathered) — must hold the SAME BITS as `on` in every
+            parameter, and in Adam's moments on this rank's rows (where the row counts do not split over the ranks the trainer keeps
+            the gathered form: then everything is identical).
 
 Checked on every rank: the two walk the same trajectory to fp32 rounding (gradients of everything that is still exchanged,
 parameters where the gradient is significant), the fused slices were really left out of the exchange, and the replicas hold the
@@ -44,9 +48,11 @@ def make(mode):
     return tr
 
 
-on, off = make("on"), make("off")
+on, off, rows = make("on"), make("off"), make("on")
+rows.dp_fused = "rows"
 assert torch.equal(on.parametersG, off.parametersG)
 for _ in range(3):
+    rows.step_phased()
     on.step_phased()
     if os.environ.get("VF_REHEARSAL_SYNC") == "1":
         torch.cuda.synchronize()
@@ -75,14 +81,28 @@ def bits(t):
     return int(t.view(torch.int32).to(torch.int64).sum().item())
 
 
+# the row-sharded form against the gathered one: same bits in every parameter; Adam's moments on this rank's rows of the pair and
+# everywhere outside it
+rows_active = rows._dp_rows()
+rows_ok = torch.equal(rows.parametersG, on.parametersG) and torch.equal(rows.parametersD, on.parametersD)
+for key in ("m", "v"):
+    a, c = rows.optimStateG[key], on.optimStateG[key]
+    rows_ok = rows_ok and torch.equal(a[~mask], c[~mask])
+    for lo, hi in ranges:
+        per = (hi - lo) // world if rows_active else hi - lo
+        r0 = lo + (rank * per if rows_active else 0)
+        rows_ok = rows_ok and torch.equal(a[r0:r0 + per], c[r0:r0 + per])
+
+
 sig = torch.tensor([bits(on.parametersG), bits(on.optimStateG["m"]), bits(on.optimStateG["v"]), bits(on.parametersD)], dtype=torch.int64)
 every = [torch.zeros_like(sig) for _ in range(world)]
 dist.all_gather(every, sig)
 same = all(torch.equal(e, every[0]) for e in every)
 line = ("rank %d/%d  batch %d/rank  fused slices %s  gather buffer %d floats  |  on vs off: grad(exchanged part) %.2e  param %.3f lr  "
-        "adam m %.2e  netD %.3f lr  |  replicas bit-identical: %s" % (rank, world, b, ranges, on._opbuf.numel(), err_g, err_p, err_m, err_d, same))
+        "adam m %.2e  netD %.3f lr  |  replicas bit-identical: %s  |  row-sharded update (%s) == gathered, bit for bit: %s"
+        % (rank, world, b, ranges, on._opbuf.numel(), err_g, err_p, err_m, err_d, same, "active" if rows_active else "rows do not split: gathered", rows_ok))
 print(line, flush=True)
-ok = err_g < 1e-4 and err_p < 0.05 and err_m < 1e-3 and same
+ok = err_g < 1e-4 and err_p < 0.05 and err_m < 1e-3 and same and rows_ok
 if not ok:
     sys.stderr.write("dp_rehearsal FAILED on " + line + "\n")
 dist.barrier()

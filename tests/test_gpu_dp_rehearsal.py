@@ -1,6 +1,7 @@
 """Two and three data-parallel ranks on the one GPU of the box, exchanging over gloo (scripts/dp_rehearsal.py): the N > 1 form of the
 phased step with the bottleneck pair's operands gathered (vf_net_fused_adam_pack -> all-gather -> vf_net_adam_fused_gathered) against
-the same step with that pair's gradients all-reduced; replicas must hold the same bits.  (RCCL itself refuses two ranks on one
+the same step with that pair's gradients all-reduced; replicas must hold the same bits; and the same step with the fused update
+sharded by weight rows (dp_fused = "rows": each rank updates its rows, the updated rows are all-gathered) — the same bits again.  (RCCL itself refuses two ranks on one
 device; its entries are exercised on a one-rank communicator in tests/test_gpu_comm.py.)"""
 import os
 import socket
@@ -33,6 +34,9 @@ def test_gathered_operand_exchange_with_real_ranks(world):
     # (every rank exits non-zero on a failed check and torchrun passes that on; the ranks' lines may interleave on the shared stdout)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-6000:])
     assert r.stdout.count("replicas bit-identical: True") == world, r.stdout[-2000:]
+    # the update sharded by weight rows (2 ranks: active; 3 ranks: 128 rows do not split, the trainer keeps the gathered form)
+    assert r.stdout.count("== gathered, bit for bit: True") == world, r.stdout[-2000:]
+    assert ("row-sharded update (active)" in r.stdout) == (world == 2), r.stdout[-2000:]
     lines = [r.stdout]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "dp_rehearsal_%d.log" % world), "w") as fh:

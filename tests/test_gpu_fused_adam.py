@@ -91,6 +91,36 @@ def test_gathered_operands_give_the_mean_gradient_of_the_ranks(world, K, Nu, Nco
     assert torch.equal(x1, x2) and torch.equal(m1, m2) and torch.equal(v1, v2)
 
 
+@pytest.mark.parametrize("world,K,Nu,Ncols", [(2, 4, 256, 128), (4, 16, 512, 256), (8, 8, 4000, 1024)])
+def test_update_sharded_by_weight_rows_equals_the_whole_tensor_update(world, K, Nu, Ncols, hipb):
+    """data parallel without redoing the work N times: rank r forms the global-batch gradient of rows
+    [r Nu / N, (r + 1) Nu / N) only and updates them; the row blocks of all ranks together are, BIT FOR BIT, the whole-tensor
+    gathered update (x, m, v and the stored gradient) — so replicas that all-gather the updated rows stay identical."""
+    pad4 = lambda n: (n + 3) & ~3
+    u_off, v_off = 0, pad4(K * Nu)
+    seg = v_off + pad4(K * Ncols)
+    gen = torch.Generator().manual_seed(world * 10 + K)
+    buf = torch.randn(world * seg, generator=gen).to(hipb.device)
+    n = Nu * Ncols
+    lr, b1, b2, eps = 2e-4, 0.5, 0.999, 1e-8
+    x1, m1, v1, t1 = _state(hipb, n, 9)
+    g1 = torch.zeros(n, device=hipb.device)
+    hipb.adam_prep(lr, b1, b2, t1)
+    hipb.wgrad_adam_outer_gathered(buf, u_off, v_off, world, K, seg, Nu, Ncols, x1, m1, v1, g1, b1, b2, eps, t1)
+    x2, m2, v2, t2 = _state(hipb, n, 9)
+    g2 = torch.zeros(n, device=hipb.device)
+    hipb.adam_prep(lr, b1, b2, t2)
+    rows = Nu // world
+    x0 = x2.clone()
+    for r in range(world):       # every virtual rank updates its row block of the shared tensors
+        hipb.wgrad_adam_outer_rows(buf, u_off, v_off, world, K, seg, Nu, Ncols, r * rows, rows, x2, m2, v2, g2, b1, b2, eps, t2)
+        lo, hi = r * rows * Ncols, (r + 1) * rows * Ncols
+        assert torch.equal(x2[hi:], x0[hi:]), "rank %d wrote past its rows" % r
+    assert torch.equal(x1, x2) and torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(g1, g2)
+    with pytest.raises(Exception, match="rows"):
+        hipb.wgrad_adam_outer_rows(buf, u_off, v_off, world, K, seg, Nu, Ncols, 1, rows, x2, m2, v2, None, b1, b2, eps, t2)
+
+
 def test_unsupported_shapes_are_refused(hipb):
     for K, Nu, Ncols in ((4, 62, 128), (4, 65, 128), (4, 64, 192), (0, 64, 128)):
         assert hipb.lib.vf_wgrad_adam_outer_supported(K, Nu, Ncols) == 0

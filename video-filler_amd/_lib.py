@@ -96,6 +96,7 @@ SIGNATURES = {
     "vf_wgrad_adam_outer_supported": (i32, [i32, i32, i32]),
     "vf_wgrad_adam_outer": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, f64, f64, f64, vp]),
     "vf_wgrad_adam_outer_gathered": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, C.c_float, f64, f64, f64, vp]),
+    "vf_wgrad_adam_outer_rows": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, i32, i32, vp, vp, vp, vp, C.c_float, f64, f64, f64, vp]),
     "vf_conv_is_fast": (i32, [i32, i32, i32, i32, i32]),
     "vf_conv2d_bwd_weight_planes": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32]),
     "vf_deconv2d_bwd_weight_planes": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32]),
@@ -145,6 +146,8 @@ SIGNATURES = {
     "vf_net_fused_adam_pack_size": (i32, [vp, C.POINTER(i64)]),
     "vf_net_fused_adam_pack": (i32, [vp, vp]),
     "vf_net_adam_fused_gathered": (i32, [vp, vp, i32, i64, vp, vp, f64, f64, f64, vp, i32]),
+    "vf_net_fused_adam_rows_ok": (i32, [vp, i32]),
+    "vf_net_adam_fused_gathered_rows": (i32, [vp, vp, i32, i64, vp, vp, f64, f64, f64, vp, i32, i32, i32]),
     "vf_net_set_sync_bn": (i32, [vp, vp, i32, i32]),
     "vf_net_set_weight_planes_managed": (i32, [vp, i32]),
     "vf_net_refresh_weight_planes": (i32, [vp]),

@@ -780,6 +780,13 @@ class HipBackend:
         self._c("vf_wgrad_adam_outer_gathered", C.c_void_p(base + 4 * u_off), C.c_void_p(base + 4 * v_off), world * K, K, seg, Nu, Ncols,
                 _ptr(x), _ptr(m), _ptr(v), _ptr(g) if g is not None else None, 1.0 / world, beta1, beta2, eps, _ptr(t_dev))
 
+    def wgrad_adam_outer_rows(self, buf, u_off, v_off, world, K, seg, Nu, Ncols, row0, nrows, x, m, v, g, beta1, beta2, eps, t_dev):
+        """vf_wgrad_adam_outer_rows: wgrad_adam_outer_gathered for rows [row0, row0 + nrows) of the tensors only (x, m, v, g are the
+        whole [Nu][Ncols] tensors) — one rank's share of the update sharded by weight rows"""
+        base = buf.data_ptr()
+        self._c("vf_wgrad_adam_outer_rows", C.c_void_p(base + 4 * u_off), C.c_void_p(base + 4 * v_off), world * K, K, seg, Nu, Ncols,
+                row0, nrows, _ptr(x), _ptr(m), _ptr(v), _ptr(g) if g is not None else None, 1.0 / world, beta1, beta2, eps, _ptr(t_dev))
+
     # ---- per-kernel timers
     def prof_begin(self):
         self._c("vf_prof_begin")

@@ -242,12 +242,21 @@ class CNet(nn.Sequential):
         assert segment.is_contiguous() and segment.numel() >= self.fused_adam_pack_size()
         _lib.check(_lib.load().vf_net_fused_adam_pack(self._net, C.c_void_p(segment.data_ptr())))
 
-    def adam_fused_gathered(self, all_segments, world, m, v, beta1, beta2, eps, t_dev, keep_grad=False):
+    def adam_fused_gathered(self, all_segments, world, m, v, beta1, beta2, eps, t_dev, keep_grad=False, rows=None):
+        """rows = (rank, ranks): this rank forms and applies ITS 1 / ranks of every fused tensor's rows only (the caller all-gathers
+        the updated rows: fused_adam_ranges() slices, equal contiguous row blocks)"""
         seg = all_segments.numel() // world
         assert seg * world == all_segments.numel() and seg % 4 == 0
-        _lib.check(_lib.load().vf_net_adam_fused_gathered(self._net, C.c_void_p(all_segments.data_ptr()), world, seg, C.c_void_p(m.data_ptr()),
-                                                          C.c_void_p(v.data_ptr()), beta1, beta2, eps, C.c_void_p(t_dev.data_ptr()),
-                                                          1 if keep_grad else 0))
+        args = (self._net, C.c_void_p(all_segments.data_ptr()), world, seg, C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()), beta1,
+                beta2, eps, C.c_void_p(t_dev.data_ptr()), 1 if keep_grad else 0)
+        if rows is None:
+            _lib.check(_lib.load().vf_net_adam_fused_gathered(*args))
+        else:
+            _lib.check(_lib.load().vf_net_adam_fused_gathered_rows(*args, int(rows[0]), int(rows[1])))
+
+    def fused_adam_rows_ok(self, ranks):
+        """do the fused tensors' row counts split evenly (and in even numbers) over `ranks`?"""
+        return self._net is not None and bool(_lib.load().vf_net_fused_adam_rows_ok(self._net, int(ranks)))
 
     def backward_finish(self):
         if self._net is not None:

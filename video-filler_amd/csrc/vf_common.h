@@ -173,6 +173,8 @@ __device__ __forceinline__ void vf_adam_upd(float& xv, float gv, float& mv, floa
 // One layer of the fused bottleneck update (vf_wgrad_small.hip k_adam_fused_wgrad; built by vf_wgrad_adam_outer* and by vf_net.hip):
 //   g = gscale * sum_k U[k][:]^T V[k][:]  consumed by optim.adam on x, m, v [Nu][Ncols]; g_out (may be NULL) also receives it.
 // Batch row k lives in segment k / kps at row k % kps, the segments `seg` floats apart (seg == 0: one segment, plain rows).
+// Rows [row0, row0 + Nu) of a weight matrix of ldu rows (ldu == 0: all of it — row0 = 0, ldu = Nu): U's batch rows are ldu floats
+// long; x, m, v, g_out point at the matrix's first row, the kernel offsets them (data parallel: every rank forms and applies ITS rows).
 struct VfFusedLayer {
   const float *U, *V;
   float *x, *m, *v, *g_out;
@@ -180,6 +182,7 @@ struct VfFusedLayer {
   int kps;
   int64_t seg;
   float gscale;
+  int row0, ldu;
 };
 #define VF_FUSED_MAX 4
 int vf_internal_adam_fused_multi(vf_ctx* ctx, const VfFusedLayer* layers, int nl, double beta1, double beta2, double eps,

@@ -1159,8 +1159,9 @@ VF_API int vf_net_fused_adam_range(const vf_net* n, int i, int64_t* offset, int6
   return 0;
 }
 static int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+// row_world > 1: this rank forms and applies rows [row_rank * Nu / row_world, (row_rank + 1) * Nu / row_world) of every fused tensor only
 static int fused_layers_launch(vf_net* n, const float* all, int world, int64_t seg_stride, float* m, float* v, double beta1, double beta2,
-                               double eps, const int32_t* t_dev, int keep_grad) {
+                               double eps, const int32_t* t_dev, int keep_grad, int row_rank = 0, int row_world = 1) {
   VfFusedLayer F[VF_FUSED_MAX];
   int nf = 0;
   int64_t off = 0;
@@ -1192,6 +1193,14 @@ static int fused_layers_launch(vf_net* n, const float* all, int world, int64_t s
     L.x = x; L.m = m + l.w_off; L.v = v + l.w_off; L.g_out = keep_grad ? g : nullptr;
     L.K = world * l.fa_k; L.Nu = Nu; L.Ncols = 16 * Cv;
     L.kps = l.fa_k; L.seg = all ? seg_stride : 0; L.gscale = 1.f / (float)world;
+    L.row0 = 0; L.ldu = 0;
+    if (row_world > 1) {
+      VF_REQUIRE(Nu % (2 * row_world) == 0 && Nu / row_world >= 64, "vf_net_adam_fused_gathered_rows: %d rows do not split over %d ranks", Nu,
+                 row_world);
+      L.ldu = Nu;
+      L.Nu = Nu / row_world;
+      L.row0 = row_rank * L.Nu;
+    }
     l.fa_k = 0;
   }
   return nf ? vf_internal_adam_fused_multi(n->ctx, F, nf, beta1, beta2, eps, t_dev) : 0;
@@ -1236,6 +1245,27 @@ VF_API int vf_net_adam_fused_gathered(vf_net* n, const float* all, int world, in
                                       double beta2, double eps, const int32_t* t_dev, int keep_grad) {
   VF_REQUIRE(n && all && m && v && t_dev && world >= 1, "vf_net_adam_fused_gathered: bad argument");
   return fused_layers_launch(n, all, world, seg_stride, m, v, beta1, beta2, eps, t_dev, keep_grad);
+}
+// The same with the update SHARDED BY WEIGHT ROWS: rank row_rank of row_world forms the global-batch gradient of ITS
+// 1 / row_world of every fused tensor's rows and applies optim.adam to them — 2 B flops per weight and 24 B / row_world of Adam traffic
+// per rank again, instead of every rank redoing all rows — then the ranks all-gather the updated rows (the host's collective over
+// vf_net_fused_adam_range's slice: row blocks are contiguous and equal).  m and v are touched in this rank's rows only.
+VF_API int vf_net_fused_adam_rows_ok(const vf_net* n, int row_world) {
+  if (!n || row_world < 1) return 0;
+  int cnt = 0;
+  for (const Layer& l : n->L) {       // (the layers vf_net_set_fused_adam would mark, whether or not they are marked right now)
+    if (!fused_adam_shape(l)) continue;
+    const int Nu = is_full(l) ? l.C : l.Co;
+    if (Nu % (2 * row_world) != 0 || Nu / row_world < 64) return 0;
+    ++cnt;
+  }
+  return cnt > 0;
+}
+VF_API int vf_net_adam_fused_gathered_rows(vf_net* n, const float* all, int world, int64_t seg_stride, float* m, float* v, double beta1,
+                                           double beta2, double eps, const int32_t* t_dev, int keep_grad, int row_rank, int row_world) {
+  VF_REQUIRE(n && all && m && v && t_dev && world >= 1 && row_world >= 1 && row_rank >= 0 && row_rank < row_world,
+             "vf_net_adam_fused_gathered_rows: bad argument");
+  return fused_layers_launch(n, all, world, seg_stride, m, v, beta1, beta2, eps, t_dev, keep_grad, row_rank, row_world);
 }
 // net:updateGradInput(input, gradOutput): gradInput only (parameter gradients untouched; train.lua:366)
 VF_API int vf_net_update_grad_input(vf_net* n, const float* x, const float* gy, const float** gx) {

@@ -48,12 +48,12 @@ __device__ __forceinline__ float ws_rne(float f) {
 }
 // RB: rows of x, m, v in flight per epilogue batch; OCC: waves per SIMD the register budget is held to; PF: the first batch is
 // loaded BEFORE the K loop, so it travels under the matrix-core phase
-template <int NJ, bool FUSE = false, int RB = 4, int OCC = 3, bool PF = false>
-__global__ __launch_bounds__(256, FUSE ? OCC : 1) void k_wgrad_smallk(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ dW,
-                                                      int K, int Nu, int Ncols, int tiles_c, float beta, const VfAdamFuse A) {
+// wt: this wave's tile, column tiles fastest (the four waves of a block share U rows); ldu: floats per batch row of U (>= Nu)
+template <int NJ, bool FUSE, int RB, bool PF>
+__device__ __forceinline__ void wgrad_smallk_body(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ dW, int K, int Nu,
+                                                  int ldu, int Ncols, int tiles_c, float beta, const VfAdamFuse& A, int wt) {
   typedef float fvec __attribute__((ext_vector_type(NJ)));
   const int lane = threadIdx.x & 63;
-  const int wt = blockIdx.x * 4 + (threadIdx.x >> 6);         // wave tile: column tiles fastest (the four waves share U rows)
   const int tr = wt / tiles_c, tc = wt - tr * tiles_c;
   const int n0 = tr * 64, c0 = tc * (32 * NJ);
   if (n0 >= Nu) return;
@@ -81,10 +81,10 @@ __global__ __launch_bounds__(256, FUSE ? OCC : 1) void k_wgrad_smallk(const floa
     const int kc = live ? kk : K - 1;
     if (FUSE && A.seg != 0) {       // (wave-uniform: gathered operands only)
       const int sg = A.kshift >= 0 ? kc >> A.kshift : kc / A.kps, kr = kc - sg * A.kps;
-      p.a = *(const f32x2*)(upc + sg * A.seg + (int64_t)kr * Nu);
+      p.a = *(const f32x2*)(upc + sg * A.seg + (int64_t)kr * ldu);
       p.b = *(const fvec*)(vp + sg * A.seg + (int64_t)kr * Ncols);
     } else {
-      p.a = *(const f32x2*)(upc + (int64_t)kc * Nu);
+      p.a = *(const f32x2*)(upc + (int64_t)kc * ldu);
       p.b = *(const fvec*)(vp + (int64_t)kc * Ncols);
     }
     p.mb = live ? 1.f : 0.f;
@@ -203,6 +203,32 @@ __global__ __launch_bounds__(256, FUSE ? OCC : 1) void k_wgrad_smallk(const floa
   }
 }
 
+template <int NJ, bool FUSE = false, int RB = 4, int OCC = 3, bool PF = false>
+__global__ __launch_bounds__(256, FUSE ? OCC : 1) void k_wgrad_smallk(const float* __restrict__ U, const float* __restrict__ V, float* __restrict__ dW,
+                                                      int K, int Nu, int Ncols, int tiles_c, float beta, const VfAdamFuse A) {
+  wgrad_smallk_body<NJ, FUSE, RB, PF>(U, V, dW, K, Nu, Nu, Ncols, tiles_c, beta, A, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// the fused update of SEVERAL layers (the bottleneck pair: two tensors) in one launch: a block's four wave tiles belong to one
+// layer (each layer's tile count is padded to a multiple of four); a tail of one layer overlaps the start of the next instead of
+// draining the chip between two launches
+struct VfFusedTable {
+  int nl;
+  int blk_off[VF_FUSED_MAX + 1];      // first block of layer i
+  int tiles_c[VF_FUSED_MAX];
+  int K[VF_FUSED_MAX], Nu[VF_FUSED_MAX], ldu[VF_FUSED_MAX], Ncols[VF_FUSED_MAX];
+  const float* U[VF_FUSED_MAX];
+  const float* V[VF_FUSED_MAX];
+  VfAdamFuse A[VF_FUSED_MAX];
+};
+template <int RB, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_adam_fused_multi(const VfFusedTable T) {
+  int l = 0;
+  while (l + 1 < T.nl && (int)blockIdx.x >= T.blk_off[l + 1]) ++l;
+  const int wt = ((int)blockIdx.x - T.blk_off[l]) * 4 + (threadIdx.x >> 6);
+  wgrad_smallk_body<2, true, RB, false>(T.U[l], T.V[l], (float*)nullptr, T.K[l], T.Nu[l], T.ldu[l], T.Ncols[l], T.tiles_c[l], 0.f, T.A[l], wt);
+}
+
 }  // namespace
 
 // dW[Nu][Ncols] = beta * dW + sum_k U[k][Nu] * V[k][Ncols].  Returns -1 when the shape is not this kernel's (the caller keeps
@@ -235,14 +261,6 @@ int vf_internal_wgrad_smallk(vf_ctx* ctx, const float* U, const float* V, float*
 // loads, so half the bytes are in flight, and the other half's MFMAs have one or two waves per SIMD to hide their operand latency
 // with instead of three.  Start-up phase offsets between the waves of the plain form (so that one wave's MFMAs fall into the
 // others' memory phase) only added their own delay: 178 -> 188 / 201 / 256 us for offsets of 1 / 3 / 8 x 4096 cycles.
-struct VfFusedArgs {
-  int nl;
-  int tile_off[VF_FUSED_MAX + 1];
-  int tiles_c[VF_FUSED_MAX];
-  int kshift[VF_FUSED_MAX];       // log2(kps) when it is a power of two, else -1
-  VfFusedLayer L[VF_FUSED_MAX];
-};
-
 // The bottleneck pair's weight gradient with optim.adam in its epilogue:  g = sum_k U[k][:]^T V[k][:]  (K = batch) is formed in the
 // matrix-core accumulators and consumed there — x, m, v [Nu][Ncols] are read and written once (24 B per weight; + 4 when g, which
 // may be NULL, is stored too), where the two-kernel form writes g, then reads it again beside x, m, v (32 B).  t_dev is the
@@ -254,9 +272,10 @@ VF_API int vf_wgrad_adam_outer_supported(int K, int Nu, int Ncols) {
 int vf_internal_adam_fused_multi(vf_ctx* ctx, const VfFusedLayer* layers, int nl, double beta1, double beta2, double eps,
                                  const int32_t* t_dev) {
   VF_REQUIRE(ctx && layers && t_dev && nl >= 1 && nl <= VF_FUSED_MAX, "fused update: %d layers (at most %d per launch)", nl, VF_FUSED_MAX);
-  VfFusedArgs A;
-  memset(&A, 0, sizeof(A));
-  A.nl = nl;
+  VfFusedTable T;
+  memset(&T, 0, sizeof(T));
+  T.nl = nl;
+  double flops = 0, bytes = 0;
   for (int i = 0; i < nl; ++i) {
     const VfFusedLayer& L = layers[i];
     VF_REQUIRE(L.U && L.V && L.x && L.m && L.v, "vf_wgrad_adam_outer: NULL argument");
@@ -264,34 +283,37 @@ int vf_internal_adam_fused_multi(vf_ctx* ctx, const VfFusedLayer* layers, int nl
                L.Ncols);
     VF_REQUIRE(L.kps >= 1 && L.K % L.kps == 0 && (L.K == L.kps || L.seg % 4 == 0),
                "vf_wgrad_adam_outer: %d batch rows in segments of %d (stride %lld floats)", L.K, L.kps, (long long)L.seg);
+    const int ldu = L.ldu ? L.ldu : L.Nu, row0 = L.ldu ? L.row0 : 0;
+    VF_REQUIRE(row0 >= 0 && row0 % 2 == 0 && row0 + L.Nu <= ldu, "vf_wgrad_adam_outer: rows [%d, %d) of %d", row0, row0 + L.Nu, ldu);
     VF_REQUIRE(!((((uintptr_t)L.U) | ((uintptr_t)L.V)) & 7) &&
                    !((((uintptr_t)L.x) | ((uintptr_t)L.m) | ((uintptr_t)L.v) | ((uintptr_t)L.g_out)) & 15),
                "vf_wgrad_adam_outer: U, V must be 8-byte aligned, x, m, v, g 16-byte aligned");
-    A.L[i] = L;
-    if (L.K == L.kps) A.L[i].seg = 0;       // (one segment: plain row addressing)
-    A.kshift[i] = vf_is_pow2(L.kps) ? vf_ilog2(L.kps) : -1;
-    A.tiles_c[i] = L.Ncols / 64;
-    A.tile_off[i + 1] = A.tile_off[i] + A.tiles_c[i] * (int)vf_cdiv(L.Nu, 64);
-  }
-  for (int i = 0; i < nl; ++i) {      // one launch per layer
-    const VfFusedLayer& L = A.L[i];
-    VfAdamFuse F;
-    F.x = L.x; F.m = L.m; F.v = L.v; F.g = L.g_out;
+    const int64_t roff = (int64_t)row0 * L.Ncols;
+    VfAdamFuse& F = T.A[i];
+    F.x = L.x + roff; F.m = L.m + roff; F.v = L.v + roff; F.g = L.g_out ? L.g_out + roff : nullptr;
     F.state = t_dev;
     F.b1 = (float)beta1; F.omb1 = (float)(1.0 - beta1);
     F.b2 = (float)beta2; F.omb2 = (float)(1.0 - beta2);
     F.eps = (float)eps;
     F.round_bf16 = ctx->mfma_bf16 == 1;
-    F.kps = L.kps; F.kshift = A.kshift[i]; F.seg = L.seg; F.gscale = L.gscale;
+    F.kps = L.kps; F.kshift = vf_is_pow2(L.kps) ? vf_ilog2(L.kps) : -1;
+    F.seg = L.K == L.kps ? 0 : L.seg;       // (one segment: plain row addressing)
+    F.gscale = L.gscale;
+    T.U[i] = L.U + row0; T.V[i] = L.V;
+    T.K[i] = L.K; T.Nu[i] = L.Nu; T.ldu[i] = ldu; T.Ncols[i] = L.Ncols;
+    T.tiles_c[i] = L.Ncols / 64;
+    const int64_t tiles = (int64_t)T.tiles_c[i] * vf_cdiv(L.Nu, 64);
+    T.blk_off[i + 1] = T.blk_off[i] + (int)vf_cdiv(tiles, 4);
     const double n = (double)L.Nu * L.Ncols;
     // (2 K flops per 24 bytes is far below the matrix pipe's ridge: bench.py prices it by its bytes)
-    // measured (scripts/bench_fused_adam.py; K = 64, 4000 x 8192): RB 4 / three waves per SIMD 180 us; RB 8 / two waves 181; RB 16 / two
-    // waves 233 (spills); first batch loaded ahead of the K loop 174-180
-    VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", 2.0 * L.K * n, (L.g_out ? 28.0 : 24.0) * n + 4.0 * L.K * ((double)L.Nu + L.Ncols),
-                    (k_wgrad_smallk<2, true, 4, 3, false>), dim3((unsigned)vf_cdiv(A.tile_off[i + 1] - A.tile_off[i], 4)), dim3(256), L.U,
-                    L.V, (float*)nullptr, L.K, L.Nu, L.Ncols, A.tiles_c[i], 0.f, F);
-    VF_LAUNCH_CHECK();
+    flops += 2.0 * L.K * n;
+    bytes += (L.g_out ? 28.0 : 24.0) * n + 4.0 * L.K * ((double)L.Nu + L.Ncols);
   }
+  // measured (scripts/bench_fused_adam.py; K = 64, 4000 x 8192): RB 4 / three waves per SIMD 180 us; RB 8 / two waves 181; RB 16 / two
+  // waves 233 (spills); first batch loaded ahead of the K loop 174-180.  Round 4: all layers in ONE launch (a table in the
+  // kernel arguments) — the tail of one tensor's update overlaps the start of the next.
+  VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", flops, bytes, (k_adam_fused_multi<4, 3>), dim3((unsigned)T.blk_off[nl]), dim3(256), T);
+  VF_LAUNCH_CHECK();
   return 0;
 }
 VF_API int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu,
@@ -302,6 +324,20 @@ VF_API int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float
   L.U = U; L.V = V; L.x = x; L.m = m; L.v = v; L.g_out = g;
   L.K = K; L.Nu = Nu; L.Ncols = Ncols;
   L.kps = rows_per_seg; L.seg = seg_stride; L.gscale = gscale;
+  L.row0 = 0; L.ldu = 0;
+  return vf_internal_adam_fused_multi(ctx, &L, 1, beta1, beta2, eps, t_dev);
+}
+// rows [row0, row0 + nrows) of the [Nu][Ncols] tensors only (x, m, v, g point at row 0; U's batch rows stay Nu floats long): the
+// data-parallel update sharded by weight rows — every row block gets, bit for bit, what the whole-tensor call gives it
+VF_API int vf_wgrad_adam_outer_rows(vf_ctx* ctx, const float* U, const float* V, int K, int rows_per_seg, int64_t seg_stride, int Nu,
+                                    int Ncols, int row0, int nrows, float* x, float* m, float* v, float* g, float gscale, double beta1,
+                                    double beta2, double eps, const int32_t* t_dev) {
+  VF_REQUIRE(ctx && U && V && x && m && v && t_dev, "vf_wgrad_adam_outer_rows: NULL argument");
+  VfFusedLayer L;
+  L.U = U; L.V = V; L.x = x; L.m = m; L.v = v; L.g_out = g;
+  L.K = K; L.Nu = nrows; L.Ncols = Ncols;
+  L.kps = rows_per_seg; L.seg = seg_stride; L.gscale = gscale;
+  L.row0 = row0; L.ldu = Nu;
   return vf_internal_adam_fused_multi(ctx, &L, 1, beta1, beta2, eps, t_dev);
 }
 VF_API int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v,

@@ -65,13 +65,14 @@ def adam_update_split(x, dfdx, state, side_ranges, side):
     bump_param_version(x)
 
 
-def adam_update_fused(x, dfdx, state, net, keep_grad=False, gathered=None):
+def adam_update_fused(x, dfdx, state, net, keep_grad=False, gathered=None, rows=None):
     """adam_update for a net whose bottleneck weight gradients were left to the optimiser (cnet.CNet.set_fused_adam): the plain
     one-pass update everywhere else, vf_wgrad_adam_outer on those slices — their gradient is formed in the matrix-core accumulators
     and consumed there (24 B per weight instead of 32; dfdx receives it only with keep_grad).  Element for element the update of
     adam_update, given the same gradient.  gathered = (buffer, world): data parallel — the buffer holds every rank's packed
     operands (CNet.fused_adam_pack, all-gathered); the fused slices get the gradient of the global batch, the rest of dfdx is
-    expected to have been all-reduced."""
+    expected to have been all-reduced.  rows = (rank, ranks) with gathered: the fused slices are updated in this rank's rows only
+    (the caller all-gathers them afterwards)."""
     B = get_backend()
     lr = state.get("learningRate", 0.001)
     beta1 = state.get("beta1", 0.9)
@@ -87,7 +88,7 @@ def adam_update_fused(x, dfdx, state, net, keep_grad=False, gathered=None):
             B.adam_apply(x[pos:lo], dfdx[pos:lo], m[pos:lo], v[pos:lo], beta1, beta2, eps, t_dev)
         pos = hi
     if gathered is not None:
-        net.adam_fused_gathered(gathered[0], gathered[1], m, v, beta1, beta2, eps, t_dev, keep_grad)
+        net.adam_fused_gathered(gathered[0], gathered[1], m, v, beta1, beta2, eps, t_dev, keep_grad, rows=rows)
     else:
         net.adam_fused(m, v, beta1, beta2, eps, t_dev, keep_grad)
     bump_param_version(x)

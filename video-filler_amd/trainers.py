@@ -269,6 +269,14 @@ class _TrainerBase:
         # slices), "keep" (it does: 28 B per weight instead of 24), "off" (accGradParameters + the plain one-pass update, 32 B)
         self.fuse_adam = os.environ.get("VF_FUSE_ADAM", "on")
         assert self.fuse_adam in ("on", "keep", "off"), "VF_FUSE_ADAM: on | keep | off"
+        # data parallel, what becomes of the bottleneck pair's gradient (92 % of G's bytes) — a recorded choice:
+        #   "gathered" (default)  every rank all-gathers the OPERANDS (6 MB per rank) and forms the global-batch gradient of ALL rows
+        #                         inside the fused update: 72 MB on the wire at 8 ranks, N-fold redundant matrix-core work
+        #   "rows"                the same gather, but rank r forms and applies rows [r R / N, (r + 1) R / N) only (2 B flops per weight
+        #                         again, Adam traffic / N), then the updated rows are all-gathered (131 MB per tensor)
+        #   "reduced"             the pair's gradients are all-reduced like everything else (fuse_adam off under data parallelism)
+        self.dp_fused = os.environ.get("VF_DP_FUSED", "gathered")
+        assert self.dp_fused in ("gathered", "rows", "reduced"), "VF_DP_FUSED: gathered | rows | reduced"
         self._dpf = []               # phased data-parallel step: the fused slices of this iteration (set in phase B)
         self._opbuf = None           # ... and the gather buffer of their operands: world segments
         self.defer_adam_g = False
@@ -434,7 +442,13 @@ class _TrainerBase:
             dp = self._comm_on()
         ok = (self.fuse_adam != "off" and isinstance(self.netG, CNet) and self.netG._net is not None and not self.shard_adam
               and not self.defer_adam_g and not self.adam_overlap)
+        if dp and self.dp_fused == "reduced":
+            return False
         return ok and (self._comm_on() and not self._pipelined if dp else not self._comm_on())
+
+    def _dp_rows(self):
+        """the row-sharded form of the data-parallel fused update: asked for, and the tensors' rows split evenly over the ranks"""
+        return self.dp_fused == "rows" and self.world > 1 and bool(self._dpf) and self.netG.fused_adam_rows_ok(self.world)
 
     def _fuse_adam_ranges(self):
         """marks netG's bottleneck pair for the fused update when step() may use it; the slices it covers (empty: plain update)"""
@@ -571,7 +585,7 @@ class _TrainerBase:
         if self._dpf:
             try:
                 optim.adam_update_fused(self.parametersG, self.gradParametersG, self.optimStateG, self.netG, self.fuse_adam == "keep",
-                                        gathered=(self._opbuf, self.world))
+                                        gathered=(self._opbuf, self.world), rows=(self.rank, self.world) if self._dp_rows() else None)
             finally:
                 self.netG.set_fused_adam(False)
             return
@@ -603,7 +617,11 @@ class _TrainerBase:
         for h in hs:
             if h is not None:
                 h.wait()
+        rows = self._dp_rows()               # (asked before phase C clears the marks)
+        slices = list(self._dpf) if rows else []
         pc()
+        for lo, hi in slices:                # every rank updated ITS rows of the pair: the updated row blocks to everybody
+            B.all_gather_shards(self.parametersG[lo:hi], self.world, self.rank, self.group)
 
     # -- pipelined data-parallel iteration: G's exchange and Adam move into the NEXT iteration, behind netD's real pass
     #    A1: netD real pass | wait G buckets (i-1) | A2: Adam(G) (i-1), netG forward, netD fake pass | all-reduce D |
