@@ -297,6 +297,10 @@ int vf_adam_step(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int6
 int vf_adam_prep(vf_ctx* ctx, double lr, double beta1, double beta2, int32_t* t_dev);
 int vf_adam_apply(vf_ctx* ctx, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2,
                   double eps, const int32_t* t_dev);
+/* the same pass over several element ranges of the flat vectors in ONE launch (offsets / lengths in floats, multiples of 4, at most 8
+ * ranges; host arrays): the generator's vector around the slices vf_net_adam_fused takes */
+int vf_adam_apply_ranges(vf_ctx* ctx, float* x, const float* g, float* m, float* v, const int64_t* offsets, const int64_t* lengths,
+                         int nranges, double beta1, double beta2, double eps, const int32_t* t_dev);
 /* optim.adam applied inside the weight-gradient kernel of a bottleneck layer (train.lua:104 conv nef*8 -> nBottleneck on a 4x4
  * map, :134 full-conv nBottleneck -> ngf*8 onto one; THNN accGradParameters with K = batch):
  *   g[n][col] = sum_{k < K} U[k][n] * V[k][col]        U = [K][Nu] (the 1x1-map side), V = [K][Ncols] (the 4x4-map side, Ncols = 16*C)

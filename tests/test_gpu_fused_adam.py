@@ -121,6 +121,27 @@ def test_update_sharded_by_weight_rows_equals_the_whole_tensor_update(world, K, 
         hipb.wgrad_adam_outer_rows(buf, u_off, v_off, world, K, seg, Nu, Ncols, 1, rows, x2, m2, v2, None, b1, b2, eps, t2)
 
 
+def test_adam_over_several_ranges_in_one_launch(hipb):
+    """vf_adam_apply_ranges (the generator's flat vector around the two fused slices: three ranges, one launch) == vf_adam_apply range
+    by range, bit for bit; elements outside the ranges are untouched; ranges must be whole float4s."""
+    n = 1 << 16
+    lr, b1, b2, eps = 2e-4, 0.5, 0.999, 1e-8
+    ranges = [(0, 1024), (4096, 4096 + 20000), (40000, n)]
+    g = torch.randn(n, generator=torch.Generator().manual_seed(4)).to(hipb.device)
+    x1, m1, v1, t1 = _state(hipb, n, 9)
+    x2, m2, v2, t2 = _state(hipb, n, 9)
+    x0 = x1.clone()
+    hipb.adam_prep(lr, b1, b2, t1)
+    hipb.adam_apply_ranges(x1, g, m1, v1, ranges + [(512, 512)], b1, b2, eps, t1)      # (an empty range is skipped)
+    hipb.adam_prep(lr, b1, b2, t2)
+    for lo, hi in ranges:
+        hipb.adam_apply(x2[lo:hi], g[lo:hi], m2[lo:hi], v2[lo:hi], b1, b2, eps, t2)
+    assert torch.equal(x1, x2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert torch.equal(x1[1024:4096], x0[1024:4096]) and float((x1[:1024] - x0[:1024]).abs().max()) > 0
+    with pytest.raises(Exception, match="whole float4s"):
+        hipb.adam_apply_ranges(x1, g, m1, v1, [(2, 1026)], b1, b2, eps, t1)
+
+
 def test_unsupported_shapes_are_refused(hipb):
     for K, Nu, Ncols in ((4, 62, 128), (4, 65, 128), (4, 64, 192), (0, 64, 128)):
         assert hipb.lib.vf_wgrad_adam_outer_supported(K, Nu, Ncols) == 0

@@ -93,6 +93,7 @@ SIGNATURES = {
     "vf_adam_step": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, f64, vp]),
     "vf_adam_prep": (i32, [vp, f64, f64, f64, vp]),
     "vf_adam_apply": (i32, [vp, vp, vp, vp, vp, i64, f64, f64, f64, vp]),
+    "vf_adam_apply_ranges": (i32, [vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, vp]),
     "vf_wgrad_adam_outer_supported": (i32, [i32, i32, i32]),
     "vf_wgrad_adam_outer": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, f64, f64, f64, vp]),
     "vf_wgrad_adam_outer_gathered": (i32, [vp, vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, C.c_float, f64, f64, f64, vp]),

@@ -764,6 +764,16 @@ class HipBackend:
     def adam_apply(self, x, g, m, v, beta1, beta2, eps, t_dev):
         self._c("vf_adam_apply", _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), beta1, beta2, eps, _ptr(t_dev))
 
+    def adam_apply_ranges(self, x, g, m, v, ranges, beta1, beta2, eps, t_dev):
+        """vf_adam_apply_ranges: the update of the element ranges [(lo, hi)] of the flat vectors in one launch"""
+        ranges = [(lo, hi) for lo, hi in ranges if hi > lo]
+        if not ranges:
+            return
+        n = len(ranges)
+        offs = (C.c_int64 * n)(*[lo for lo, _ in ranges])
+        lens = (C.c_int64 * n)(*[hi - lo for lo, hi in ranges])
+        self._c("vf_adam_apply_ranges", _ptr(x), _ptr(g), _ptr(m), _ptr(v), offs, lens, n, beta1, beta2, eps, _ptr(t_dev))
+
     def wgrad_adam_outer(self, U, V, x, m, v, g, beta1, beta2, eps, t_dev):
         """vf_wgrad_adam_outer: the bottleneck weight gradient U^T V (U [K][Nu], V [K][Ncols]) consumed by optim.adam in the
         kernel that forms it; x, m, v (and g, or None) = [Nu][Ncols] slices, t_dev after adam_prep."""

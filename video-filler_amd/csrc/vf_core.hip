@@ -611,6 +611,64 @@ static int adam_apply(vf_ctx* ctx, float* x, const float* g, float* m, float* v,
   VF_LAUNCH_CHECK();
   return 0;
 }
+// the same pass over up to VF_ADAM_RANGES element ranges of the flat vectors in ONE launch (the generator's vector minus the slices
+// the fused bottleneck update takes: three ranges): a thread's float4 index walks the ranges laid end to end
+#define VF_ADAM_RANGES 8
+struct VfAdamRanges {
+  int n;
+  int64_t off4[VF_ADAM_RANGES];       // range start / 4
+  int64_t end4[VF_ADAM_RANGES + 1];   // running total of float4s: range r covers virtual indices [end4[r], end4[r + 1])
+};
+__global__ __launch_bounds__(256) void k_adam_ranges(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, const VfAdamRanges R, float b1, float omb1, float b2, float omb2,
+                                                     float eps, const int32_t* __restrict__ state) {
+  const float step = __int_as_float(state[1]);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, total4 = R.end4[R.n];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += stride) {
+    int r = 0;
+    while (r + 1 < R.n && i >= R.end4[r + 1]) ++r;
+    const int64_t j = R.off4[r] + (i - R.end4[r]);
+    f32x4 xv = ((const f32x4*)x)[j], mv = ((const f32x4*)m)[j], vv = ((const f32x4*)v)[j];
+    const f32x4 gv = ((const f32x4*)g)[j];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xe = xv[e], me = mv[e], ve = vv[e];
+      vf_adam_upd(xe, gv[e], me, ve, b1, omb1, b2, omb2, eps, step);
+      xv[e] = xe;
+      mv[e] = me;
+      vv[e] = ve;
+    }
+    ((f32x4*)x)[j] = xv;
+    ((f32x4*)m)[j] = mv;
+    ((f32x4*)v)[j] = vv;
+  }
+}
+VF_API int vf_adam_apply_ranges(vf_ctx* ctx, float* x, const float* g, float* m, float* v, const int64_t* offsets, const int64_t* lengths,
+                                int nranges, double beta1, double beta2, double eps, const int32_t* t_dev) {
+  VF_REQUIRE(ctx && x && g && m && v && offsets && lengths && t_dev, "vf_adam_apply_ranges: NULL argument");
+  VF_REQUIRE(nranges >= 1 && nranges <= VF_ADAM_RANGES, "vf_adam_apply_ranges: %d ranges (1 .. %d)", nranges, VF_ADAM_RANGES);
+  VF_REQUIRE((((uintptr_t)x | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam operands must be 16-byte aligned");
+  VfAdamRanges R;
+  memset(&R, 0, sizeof(R));
+  int k = 0;
+  for (int i = 0; i < nranges; ++i) {
+    VF_REQUIRE(offsets[i] >= 0 && lengths[i] >= 0 && offsets[i] % 4 == 0 && lengths[i] % 4 == 0,
+               "vf_adam_apply_ranges: range %d (offset %lld, length %lld) must be whole float4s", i, (long long)offsets[i], (long long)lengths[i]);
+    if (lengths[i] == 0) continue;
+    R.off4[k] = offsets[i] / 4;
+    R.end4[k + 1] = R.end4[k] + lengths[i] / 4;
+    ++k;
+  }
+  R.n = k;
+  if (k == 0) return 0;
+  const int64_t n = 4 * R.end4[k];
+  static const int tune_blocks = getenv("VF_ADAM_BLOCKS") ? atoi(getenv("VF_ADAM_BLOCKS")) : 2048;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(vf_cdiv(n, 1024), tune_blocks));
+  VF_LAUNCH_TIMED(ctx, "adam", 0.0, 28.0 * (double)n, k_adam_ranges, dim3(blocks), dim3(256), x, g, m, v, R, (float)beta1,
+                  (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, t_dev);
+  VF_LAUNCH_CHECK();
+  return 0;
+}
 VF_API int vf_adam_prep(vf_ctx* ctx, double lr, double beta1, double beta2, int32_t* t_dev) {
   hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, ctx->stream, t_dev, lr, beta1, beta2);
   VF_LAUNCH_CHECK();

@@ -82,11 +82,16 @@ def adam_update_fused(x, dfdx, state, net, keep_grad=False, gathered=None, rows=
     state["t"] += 1
     m, v, t_dev = state["m"], state["v"], state["t_dev"]
     B.adam_prep(lr, beta1, beta2, t_dev)
-    pos = 0
+    pos, plain = 0, []
     for lo, hi in sorted(net.fused_adam_ranges()) + [(x.numel(), x.numel())]:
         if lo > pos:
-            B.adam_apply(x[pos:lo], dfdx[pos:lo], m[pos:lo], v[pos:lo], beta1, beta2, eps, t_dev)
+            plain.append((pos, lo))
         pos = hi
+    if hasattr(B, "adam_apply_ranges") and len(plain) <= 8 and all(a % 4 == 0 and b % 4 == 0 for a, b in plain):
+        B.adam_apply_ranges(x, dfdx, m, v, plain, beta1, beta2, eps, t_dev)      # everything outside the fused slices: one launch
+    else:
+        for a, b in plain:
+            B.adam_apply(x[a:b], dfdx[a:b], m[a:b], v[a:b], beta1, beta2, eps, t_dev)
     if gathered is not None:
         net.adam_fused_gathered(gathered[0], gathered[1], m, v, beta1, beta2, eps, t_dev, keep_grad, rows=rows)
     else:
