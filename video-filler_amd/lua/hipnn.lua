@@ -65,6 +65,7 @@ int vf_masked_mse_bwd(vf_ctx*, const float* x, const float* xhat, const uint8_t*
 int vf_adam_step(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int32_t* t_dev);
 int vf_adam_prep(vf_ctx*, double lr, double beta1, double beta2, int32_t* t_dev);
 int vf_adam_apply(vf_ctx*, float* x, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps, const int32_t* t_dev);
+int vf_adam_apply_ranges(vf_ctx* ctx, float* x, const float* g, float* m, float* v, const int64_t* offsets, const int64_t* lengths, int nranges, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_conv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 int vf_deconv2d_bwd_weight_planes(vf_ctx* ctx, const float* x, const float* gy, const void* x_planes, const void* gy_planes, float* gw, float* gb, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, float beta);
 typedef struct vf_layer_desc { int kind; int nin, nout; int k, stride, pad; int act; float slope; float eps, momentum; } vf_layer_desc;
@@ -98,6 +99,8 @@ int vf_wgrad_adam_outer_gathered(vf_ctx* ctx, const float* U, const float* V, in
 int vf_net_fused_adam_pack_size(const vf_net* net, int64_t* floats);
 int vf_net_fused_adam_pack(vf_net* net, float* segment);
 int vf_net_adam_fused_gathered(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad);
+int vf_net_fused_adam_rows_ok(const vf_net* net, int row_world);
+int vf_net_adam_fused_gathered_rows(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1, double beta2, double eps, const int32_t* t_dev, int keep_grad, int row_rank, int row_world);
 int vf_wgrad_adam_outer(vf_ctx* ctx, const float* U, const float* V, int K, int Nu, int Ncols, float* x, float* m, float* v, float* g, double beta1, double beta2, double eps, const int32_t* t_dev);
 int vf_net_set_sync_bn(vf_net* net, vf_comm* comm, int world, int force);
 int vf_net_set_weight_planes_managed(vf_net* net, int on);
@@ -781,13 +784,13 @@ function hipnn.adamFused(opfunc, x, state, net, keepGrad)
    end
    table.sort(ranges, function(a, b) return a[1] < b[1] end)
    ranges[#ranges + 1] = { x:nElement(), x:nElement() }
-   local pos = 0
+   -- everything outside the fused slices: ONE launch over the ranges in between (vf_adam_apply_ranges)
+   local offs, lens, n, pos = ffi.new('int64_t[8]'), ffi.new('int64_t[8]'), 0, 0
    for _, r in ipairs(ranges) do
-      if r[1] > pos then
-         check(C.vf_adam_apply(hipnn.ctx, fptr(x) + pos, fptr(dfdx) + pos, fptr(state.m) + pos, fptr(state.v) + pos, r[1] - pos, b1, b2, eps, t))
-      end
+      if r[1] > pos then offs[n], lens[n] = pos, r[1] - pos; n = n + 1 end
       pos = r[2]
    end
+   if n > 0 then check(C.vf_adam_apply_ranges(hipnn.ctx, fptr(x), fptr(dfdx), fptr(state.m), fptr(state.v), offs, lens, n, b1, b2, eps, t)) end
    check(C.vf_net_adam_fused(net.h, fptr(state.m), fptr(state.v), b1, b2, eps, t, keepGrad and 1 or 0))
    check(C.vf_net_set_fused_adam(net.h, 0, cnt))
    return x, { fx }
