@@ -1096,12 +1096,16 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     char dname[64];
     snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s_bf16", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
     const double dfl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
+    // algorithmic bytes: operand planes and weight planes once, the output (or its split-K slabs), and what the epilogue reads
+    // (derivative mask, BatchNorm input) — bench.py prices a kernel against the LONGER of its two floors
+    const double dby = (double)g.a_bytes + (double)g.w_bytes + 4.0 * (double)g.out_elems * (ksplit > 1 ? ksplit : 1) +
+                       (g.dmask ? 4.0 * (double)g.out_elems : 0.0) + (g.st.mode == 2 ? 4.0 * (double)g.out_elems : 0.0);
     if (t.bm == 128) {
-      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, 2, 1>), dim3(nt), dim3(512), g);
-      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, 2, 1>), dim3(nt), dim3(512), g);
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 16, 2, 1>), dim3(nt), dim3(512), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 4, 2, 1>), dim3(nt), dim3(512), g);
     } else {
-      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, 2, 1>), dim3(nt), dim3(256), g);
-      else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, 2, 1>), dim3(nt), dim3(256), g);
+      if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<64, 64, 16, 2, 1>), dim3(nt), dim3(256), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<64, 64, 4, 2, 1>), dim3(nt), dim3(256), g);
     }
     VF_LAUNCH_CHECK();
     if (ksplit > 1) {
@@ -1117,6 +1121,10 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     char dname[64];
     snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
     const double dfl = 2.0 * (double)g.M * g.N * (double)ntaps * g.C * zpar;
+    // algorithmic bytes: operand planes and weight planes once, the output (or its split-K slabs), and what the epilogue reads
+    // (derivative mask, BatchNorm input) — bench.py prices a kernel against the LONGER of its two floors
+    const double dby = (double)g.a_bytes + (double)g.w_bytes + 4.0 * (double)g.out_elems * (ksplit > 1 ? ksplit : 1) +
+                       (g.dmask ? 4.0 * (double)g.out_elems : 0.0) + (g.st.mode == 2 ? 4.0 * (double)g.out_elems : 0.0);
     // a grid of at least two tiles per CU runs the single-stage variant, two blocks per CU (measured, scripts/bench_pconv.py:
     // E2 transposed pass 79 -> 67 us, E2 gather 68 -> 62, E3 transposed 31.2 -> 28.8, netD's first layer at 2B 58 -> 53;
     // with one tile per CU the second stage is what is needed instead: E3 gather 29.7 vs 39.8 single-stage)
@@ -1125,19 +1133,19 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     if (one_stage) snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s_1stage", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
     if (t.bm == 128) {
       if (ntaps == 16) {
-        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, 1>), dim3(nt), dim3(512), g);
-        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 16, 2>), dim3(nt), dim3(512), g);
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 16, 1>), dim3(nt), dim3(512), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 16, 2>), dim3(nt), dim3(512), g);
       } else {
-        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, 1>), dim3(nt), dim3(512), g);
-        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<128, 64, 4, 2>), dim3(nt), dim3(512), g);
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 4, 1>), dim3(nt), dim3(512), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 4, 2>), dim3(nt), dim3(512), g);
       }
     } else {
       if (ntaps == 16) {
-        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, 1>), dim3(nt), dim3(256), g);
-        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 16, 2>), dim3(nt), dim3(256), g);
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<64, 64, 16, 1>), dim3(nt), dim3(256), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<64, 64, 16, 2>), dim3(nt), dim3(256), g);
       } else {
-        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, 1>), dim3(nt), dim3(256), g);
-        else VF_LAUNCH_TIMED(ctx, dname, dfl, 0.0, (k_pconv_dma<64, 64, 4, 2>), dim3(nt), dim3(256), g);
+        if (one_stage) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<64, 64, 4, 1>), dim3(nt), dim3(256), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<64, 64, 4, 2>), dim3(nt), dim3(256), g);
       }
     }
     VF_LAUNCH_CHECK();
