@@ -500,6 +500,10 @@ int vf_net_update_grad_input_group(vf_net* net, const float* x, const float* gy,
  * plan[k:] owning >= frac of the parameters; vf_net_backward_range(hi, lo) runs backward over entries hi-1 .. lo (hi < 0: from
  * the top; gy = what the entry above hi returned).  After the walk over [k, top) the flat gradient [offset, end) is final. */
 int vf_net_plan_size(const vf_net* net);
+/* 1 if the last forward left the SIGN BITS of this layer's activated output beside it (a 3-channel-input conv + (Leaky)ReLU): the
+ * data-gradient pass of the conv above then reads its derivative mask from them — one broadcast word per pixel and 32 channels
+ * instead of the fp32 activation.  Internal to the net object; not under an activation observer. */
+int vf_net_layer_has_act_bits(const vf_net* net, int layer);
 int vf_net_bucket_split(const vf_net* net, double frac, int* plan_index, int64_t* flat_offset);
 int vf_net_backward_range(vf_net* net, const float* x, const float* gy, int hi, int lo, int need_input_grad, const float** gx);
 /* the same cut without interrupting the data-gradient chain: vf_net_backward_split walks the WHOLE net, then launches the weight

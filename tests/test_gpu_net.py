@@ -471,3 +471,45 @@ def test_syncbn_without_a_communicator_is_never_silently_local(oracle, hipb):
     assert host == "mirror" and g1 is netG and d1 is netD
     g2, d2, host = trainers._host_nets("cabi", netG, netD, sync_world=1)
     assert host == "cabi" and type(g2).__name__ == "CNet"
+
+
+def test_derivative_mask_from_sign_bits_equals_the_fp32_mask(hipb):
+    """The data-gradient of the second convolution masks with the derivative of the LeakyReLU below it (train.lua:183-186: conv ->
+    LeakyReLU -> conv).  vf_net reads that mask as SIGN BITS which the thin-input convolution leaves beside its output (2 MB instead
+    of the 67 MB activation at batchSize 64); the module-by-module host reads the fp32 activation.  Same kernels otherwise: gradInput
+    and every parameter gradient of the two hosts must be the same bits — on the REAL net (LeakyReLU(0.2): a wrong mask bit is an
+    O(1) error), for the whole batch and for a group pass over the second half of a two-group batch."""
+    from video_filler_amd import nn, trainers
+    from video_filler_amd.cnet import CNet, adopt_if_chain
+    old = (nn._PCONV_MIN_GFLOP, nn._PCONV_MIN_ROWS)
+    nn._PCONV_MIN_GFLOP, nn._PCONV_MIN_ROWS = 0.0, 1
+    try:
+        g = torch.Generator().manual_seed(21)
+        mirror = trainers.build_netD(3, 64, False, True, True, False)
+        cab = adopt_if_chain(trainers.build_netD(3, 64, False, True, True, False))
+        assert isinstance(cab, CNet)
+        pm, _ = mirror.getParameters()
+        pc, _ = cab.getParameters()
+        assert pm.shape == pc.shape
+        pm.copy_(torch.randn(pm.shape, generator=g).to(pm.device) * 0.05)
+        pc.copy_(pm)
+        x = (torch.rand((16, 3, 64, 64), generator=g) * 2 - 1).to(hipb.device)
+        for net in (mirror, cab):
+            net.setBatchGroups(2)
+            net.zeroGradParameters()
+        ym, yc = mirror.forward(x), cab.forward(x)
+        assert torch.equal(ym, yc)
+        assert hipb.lib.vf_net_layer_has_act_bits(cab._net, 0) == 1, "the first conv did not leave its sign bits: the test would compare nothing"
+        gy = torch.randn(ym.shape, generator=g).to(hipb.device)
+        gm, gc = mirror.backward(x, gy).clone(), cab.backward(x, gy).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(gm, gc), float((gm - gc).abs().max())
+        assert torch.equal(mirror.reference_flat(grads=True), cab.reference_flat(grads=True))
+        # the generator's pass over the fake half only (fGx: netD:updateGradInput with the saved activations of group 2 of 2)
+        h = x.shape[0] // 2
+        gm2 = mirror.updateGradInput(x[h:], gy[h:], group=(1, 2)).clone()
+        gc2 = cab.updateGradInput(x[h:], gy[h:], group=(1, 2)).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(gm2, gc2), float((gm2 - gc2).abs().max())
+    finally:
+        nn._PCONV_MIN_GFLOP, nn._PCONV_MIN_ROWS = old

@@ -137,6 +137,7 @@ SIGNATURES = {
     "vf_net_set_batch_groups": (i32, [vp, i32]),
     "vf_net_update_grad_input_group": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp)]),
     "vf_net_plan_size": (i32, [vp]),
+    "vf_net_layer_has_act_bits": (i32, [vp, i32]),
     "vf_net_bucket_split": (i32, [vp, f64, C.POINTER(i32), C.POINTER(i64)]),
     "vf_net_backward_range": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(vp)]),
     "vf_net_backward_split": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp)]),

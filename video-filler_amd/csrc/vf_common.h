@@ -42,6 +42,14 @@ struct vf_ctx {
   float bnf_slope;
   int bnf_groups, bnf_rows_cap;
   int bnf_result_rows;    // rows_per_group of the fused launch; 0: not fused
+  // sign bits of an activated tensor (vf_net.hip): one-shot attachments like bnf.  act_bits_out: the next thin-input conv forward
+  // (vf_conv_thin.hip) also writes, per output pixel and 64-channel group, two words — bit j of word h = (channel 2j + h) > 0;
+  // act_bits_written says whether it did.  dmask_bits: the next planes-fed transposed pass (vf_pgemm.hip) reads its activation-
+  // derivative mask from such bits (a broadcast word per pixel) instead of the fp32 activation — 2 MB instead of 67 MB for E2's
+  // data-gradient (train.lua:90: the LeakyReLU below the second conv)
+  unsigned* act_bits_out;
+  int act_bits_written;
+  const unsigned* dmask_bits;
 };
 void vf_internal_wg_free(vf_ctx* ctx);
 

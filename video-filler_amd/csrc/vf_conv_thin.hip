@@ -25,7 +25,7 @@ template <int CIN>
 __global__ __launch_bounds__(256) void k_conv_thin_in(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       unsigned short* __restrict__ planes, int64_t pstride, int H, int W, int Cout,
-                                                      int tiles_x, int tiles_y, float neg) {
+                                                      int tiles_x, int tiles_y, float neg, unsigned* __restrict__ bits) {
   static_assert(CIN <= 4, "pixels are padded to one float4 in LDS");
   constexpr int K = 16 * CIN, ROW4 = PW;                 // patch rows of PW float4 pixels (channels CIN..3 unused)
   constexpr int PP = (PW * ROW4 + 255) / 256;            // patch pixels per thread
@@ -103,6 +103,17 @@ __global__ __launch_bounds__(256) void k_conv_thin_in(const float* __restrict__ 
       const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * Cout + n;
       f32x2 v = {a0, a1};
       *(f32x2*)(y + o) = v;
+      if (bits) {
+        // the sign bits a later data-gradient pass masks with (ctx->act_bits_out): lanes 0-31 / 32-63 of a wave hold the 64
+        // channels of ONE pixel each (two per lane): word h of the pixel's group = the ballot over channels 2j + h
+        const unsigned long long k0 = __ballot(a0 > 0.f), k1 = __ballot(a1 > 0.f);
+        if ((tid & 31) == 0) {
+          const int sh = tid & 32;
+          unsigned* bw = bits + (o - n) / Cout * (Cout >> 5) + 2 * blockIdx.y;      // (o - n) / Cout: the pixel index
+          bw[0] = (unsigned)(k0 >> sh);
+          bw[1] = (unsigned)(k1 >> sh);
+        }
+      }
       if (planes) {
         float r0 = a0, r1 = a1;
 #pragma unroll
@@ -256,8 +267,11 @@ int vf_internal_conv_thin_fwd(vf_ctx* ctx, const float* x, const float* w, const
   const int tiles_x = W / (2 * TP), tiles_y = H / (2 * TP);
   const int64_t out = (int64_t)B * (H / 2) * (W / 2) * Cout;
   VfProf prof(ctx, y_planes ? "conv_thin_in_planes" : "conv_thin_in", 2.0 * (double)out * 16 * Cin, 0.0);
+  unsigned* bits = ctx->act_bits_out;      // one-shot (vf_net.hip): also leave the sign bits of the activated output
+  ctx->act_bits_out = nullptr;
+  ctx->act_bits_written = bits != nullptr;
   hipLaunchKernelGGL((k_conv_thin_in<3>), dim3((unsigned)(B * tiles_y), (unsigned)(Cout / 64)), dim3(256), 0, ctx->stream, x, w,
-                     bias, y, (unsigned short*)y_planes, out, H, W, Cout, tiles_x, tiles_y, neg);
+                     bias, y, (unsigned short*)y_planes, out, H, W, Cout, tiles_x, tiles_y, neg, bits);
   VF_LAUNCH_CHECK();
   return 0;
 }

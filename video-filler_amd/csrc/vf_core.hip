@@ -43,6 +43,9 @@ VF_API int vf_ctx_create(vf_ctx** out, int device, void* stream) {
   c->bnf_rows_cap = 0;
   c->bnf_result_rows = 0;
   c->mfma_bf16 = 3;      // fp32 operands as three exact bf16 planes (see vf_ctx_set_mfma_mode)
+  c->act_bits_out = nullptr;
+  c->act_bits_written = 0;
+  c->dmask_bits = nullptr;
   *out = c;
   return 0;
 }

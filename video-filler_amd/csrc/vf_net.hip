@@ -51,6 +51,7 @@ namespace {
 double g_gate_gflop = getenv("VF_PCONV_MIN_GFLOP") ? atof(getenv("VF_PCONV_MIN_GFLOP")) : 3.0;
 int g_gate_rows = getenv("VF_PCONV_MIN_ROWS") ? atoi(getenv("VF_PCONV_MIN_ROWS")) : 1024;
 const bool g_no_pconv = getenv("VF_NO_PCONV") != nullptr;
+const bool g_no_act_bits = getenv("VF_NO_ACT_BITS") != nullptr;      // (A/B switch: derivative masks from the fp32 activations only)
 const bool g_no_bn_fuse = getenv("VF_NO_BN_FUSE") != nullptr;
 const bool g_pwgrad = !(getenv("VF_PWGRAD") && strcmp(getenv("VF_PWGRAD"), "1") != 0);
 
@@ -91,6 +92,8 @@ struct Layer {
   void* gp = nullptr;            // conv: split of its gradOutput for the data-gradient pass
   void* yp = nullptr;            // BatchNorm / thin-input conv: planes of the own output, written beside it
   void* bgp = nullptr;           // BatchNorm: planes of its gradInput, written by its backward
+  unsigned* ybits = nullptr;     // thin-input conv + (Leaky)ReLU: sign bits of its output (vf_common.h act_bits_out), for the data-gradient above
+  bool bits_live = false;        // ... written by the last forward (and nobody has edited y since)
   const void* out_planes = nullptr;     // set by the last forward: planes of y (or NULL)
   const void* grad_planes = nullptr;    // set by the last backward: planes of gx (or NULL)
   void *wp_nat = nullptr, *wp_tr = nullptr;      // weight planes, native and transposed
@@ -272,7 +275,19 @@ int conv_forward(vf_net* n, Layer& l, const float* x, const void* in_planes, int
   const bool simple_act = act == VF_ACT_NONE || relu_like(act);
   if (want_planes && !full && l.C == 3 && simple_act && is_s2(l) && l.Co % 64 == 0 && l.H % 16 == 0 && l.W % 16 == 0) {
     if (int rc = ensure_planes(n, &l.yp, (int64_t)n->B * l.Ho * l.Wo * l.Co)) return rc;
-    if (int rc = vf_conv2d_fwd_planes(ctx, x, w, b, l.y, l.yp, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, act, slope)) return rc;
+    // the sign bits of the activated output, for the derivative mask of the data-gradient pass above (2 MB read there instead of the
+    // 67 MB activation); not under an activation observer, whose edits of y the bits would not follow (tests/helpers.py KinkSync)
+    l.bits_live = false;
+    if (relu_like(act) && !n->observer && !g_no_act_bits) {
+      if (!l.ybits)
+        if (int rc = net_alloc(n->act_owned, (void**)&l.ybits, sizeof(unsigned) * (size_t)n->B * l.Ho * l.Wo * (l.Co / 32))) return rc;
+      ctx->act_bits_out = l.ybits;
+    }
+    const int frc = vf_conv2d_fwd_planes(ctx, x, w, b, l.y, l.yp, Bn, l.H, l.W, l.C, l.Co, l.d.k, l.d.stride, l.d.pad, act, slope);
+    l.bits_live = ctx->act_bits_out == nullptr && ctx->act_bits_written && relu_like(act) && !n->observer && !g_no_act_bits;
+    ctx->act_bits_out = nullptr;
+    ctx->act_bits_written = 0;
+    if (frc) return frc;
     l.out_planes = l.yp;
     l.x_seen = nullptr;
     return 0;
@@ -335,7 +350,8 @@ int bn_forward(vf_net* n, Layer& l, const float* x, int Bn, int act, float slope
 
 // ---- backward pieces -----------------------------------------------------------------------------------------------
 // in_act != NONE: `x` is the in-place activated output of the module below; its updateGradInput rides in this epilogue
-int conv_bwd_data(vf_net* n, Layer& l, const float* x, const float* go, int Bn, int in_act, float in_slope, const void* g_planes) {
+int conv_bwd_data(vf_net* n, Layer& l, const float* x, const float* go, int Bn, int in_act, float in_slope, const void* g_planes,
+                  const unsigned* in_bits = nullptr) {
   vf_ctx* ctx = n->ctx;
   const float* w = n->params + l.w_off;
   const bool full = is_full(l);
@@ -351,8 +367,11 @@ int conv_bwd_data(vf_net* n, Layer& l, const float* x, const float* go, int Bn, 
     const void* wp = nullptr;
     if (int rc = weight_planes(n, l, !full, &wp)) return rc;
     if (full) return vf_pconv_gather(ctx, gp, wp, nullptr, l.gx, Bn, l.Ho, l.Wo, l.Co, l.C, VF_ACT_NONE, 0.f);
-    return vf_pconv_scatter(ctx, gp, wp, nullptr, l.gx, Bn, l.Ho, l.Wo, l.Co, l.C, VF_ACT_NONE, 0.f,
-                            in_act != VF_ACT_NONE ? x : nullptr, in_act, in_slope);
+    ctx->dmask_bits = in_act != VF_ACT_NONE ? in_bits : nullptr;      // (one-shot: the mask `x` as sign bits, where its producer left them)
+    const int rc = vf_pconv_scatter(ctx, gp, wp, nullptr, l.gx, Bn, l.Ho, l.Wo, l.Co, l.C, VF_ACT_NONE, 0.f,
+                                    in_act != VF_ACT_NONE ? x : nullptr, in_act, in_slope);
+    ctx->dmask_bits = nullptr;
+    return rc;
   }
   l.g_seen = nullptr;
   if (in_act != VF_ACT_NONE)
@@ -559,11 +578,14 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
       // data-gradient epilogue (x IS that activated output)
       int in_act = VF_ACT_NONE;
       float in_slope = 0.f;
+      const unsigned* in_bits = nullptr;
       if (want_gx && idx > 0 && l.d.kind == VF_L_CONV && is_s2(l)) {
         const Layer& pm = n->L[n->plan[idx - 1].main];
         if (is_conv(pm) && relu_like(pm.fused_act)) {
           in_act = pm.fused_act;
           in_slope = pm.fused_slope;
+          if (pm.bits_live && pm.ybits && !n->observer)
+            in_bits = pm.ybits + (gi >= 0 ? (int64_t)gi * Bn * pm.Ho * pm.Wo * (pm.Co / 32) : 0);
         }
       }
       // the module below is a BatchNorm (+ activation): this module's data-gradient pass also sums what that BatchNorm's
@@ -583,7 +605,7 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
         }
       }
       if (want_gx) {
-        rc = conv_bwd_data(n, l, x, go, Bn, fuse_below ? VF_ACT_NONE : in_act, in_slope, g_pl);
+        rc = conv_bwd_data(n, l, x, go, Bn, fuse_below ? VF_ACT_NONE : in_act, in_slope, g_pl, fuse_below ? nullptr : in_bits);
         if (fuse_below && !rc) rc = vf_bn_fuse_result(ctx, &pre);
         if (rc) break;
       }
@@ -668,6 +690,8 @@ int net_shape(vf_net* n, int B, int C, int H, int W) {
     c = l.Co; h = l.Ho; w = l.Wo;
     l.y = l.y_own = l.gx = l.gtmp = nullptr;
     l.xp = l.gp = l.yp = l.bgp = nullptr;
+    l.ybits = nullptr;
+    l.bits_live = false;
     l.out_planes = l.grad_planes = nullptr;
     l.x_seen = l.g_seen = nullptr;
     l.xp_seen = l.gp_seen = nullptr;
@@ -1027,6 +1051,10 @@ VF_API int vf_net_set_act_observer(vf_net* n, vf_net_act_observer fn, void* user
   n->observer = fn;
   n->observer_user = user;
   return 0;
+}
+// did the last forward leave the sign bits of this layer's activated output (the derivative mask of the data-gradient above)?
+VF_API int vf_net_layer_has_act_bits(const vf_net* n, int layer) {
+  return n && layer >= 0 && layer < (int)n->L.size() && n->L[layer].bits_live && !n->observer ? 1 : 0;
 }
 VF_API int vf_net_plan_size(const vf_net* n) { return n ? (int)n->plan.size() : -1; }
 // (plan index k, flat offset): the shortest tail plan[k:] that owns at least `frac` of the parameters.  After a backward walk

@@ -224,6 +224,7 @@ struct PGemm {
   int act;
   float slope;
   const float* dmask;
+  const unsigned* dbits;   // the same mask as sign bits (vf_common.h act_bits_out layout), or NULL: read by the epilogue prefetch
   int dact;
   float dslope;
   int dbg;               // timing experiments only (VF_PG_DBG; wrong results): 1 = no operand loads after the first step,
@@ -735,12 +736,15 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
   }
   if (want_d || want_x) {
     const int n = n0 + wn + lr;
+    // (sign bits instead of the fp32 activation where the producer left them: word 2 * (n / 64) + (n & 1) of the pixel, bit
+    //  (n / 2) % 32 — the 32 lanes of a half wave share two words)
+    const int bw = 2 * (n >> 6) + (n & 1), bb = (n >> 1) & 31, wpp = p.N >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
       const int64_t pix = ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
-      if (want_d) pre_d[r] = p.dmask[pix * p.N + n];
+      if (want_d) pre_d[r] = p.dbits ? (float)((p.dbits[pix * wpp + bw] >> bb) & 1u) : p.dmask[pix * p.N + n];
       if (want_x) pre_x[r] = p.st.x[pix * p.N + n];
     }
   }
@@ -1099,7 +1103,7 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     // algorithmic bytes: operand planes and weight planes once, the output (or its split-K slabs), and what the epilogue reads
     // (derivative mask, BatchNorm input) — bench.py prices a kernel against the LONGER of its two floors
     const double dby = (double)g.a_bytes + (double)g.w_bytes + 4.0 * (double)g.out_elems * (ksplit > 1 ? ksplit : 1) +
-                       (g.dmask ? 4.0 * (double)g.out_elems : 0.0) + (g.st.mode == 2 ? 4.0 * (double)g.out_elems : 0.0);
+                       (g.dmask ? (g.dbits ? 0.125 : 4.0) * (double)g.out_elems : 0.0) + (g.st.mode == 2 ? 4.0 * (double)g.out_elems : 0.0);
     if (t.bm == 128) {
       if (ntaps == 16) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 16, 2, 1>), dim3(nt), dim3(512), g);
       else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_dma<128, 64, 4, 2, 1>), dim3(nt), dim3(512), g);
@@ -1124,7 +1128,7 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     // algorithmic bytes: operand planes and weight planes once, the output (or its split-K slabs), and what the epilogue reads
     // (derivative mask, BatchNorm input) — bench.py prices a kernel against the LONGER of its two floors
     const double dby = (double)g.a_bytes + (double)g.w_bytes + 4.0 * (double)g.out_elems * (ksplit > 1 ? ksplit : 1) +
-                       (g.dmask ? 4.0 * (double)g.out_elems : 0.0) + (g.st.mode == 2 ? 4.0 * (double)g.out_elems : 0.0);
+                       (g.dmask ? (g.dbits ? 0.125 : 4.0) * (double)g.out_elems : 0.0) + (g.st.mode == 2 ? 4.0 * (double)g.out_elems : 0.0);
     // a grid of at least two tiles per CU runs the single-stage variant, two blocks per CU (measured, scripts/bench_pconv.py:
     // E2 transposed pass 79 -> 67 us, E2 gather 68 -> 62, E3 transposed 31.2 -> 28.8, netD's first layer at 2B 58 -> 53;
     // with one tile per CU the second stage is what is needed instead: E3 gather 29.7 vs 39.8 single-stage)
@@ -1235,6 +1239,9 @@ static int pconv_like_tr(vf_ctx* ctx, const void* ap, const void* wp, const floa
   g.out_elems = (int64_t)B * g.outH * g.outW * N;
   g.act = act; g.slope = slope;
   g.dmask = dmask; g.dact = dact; g.dslope = dslope;
+  // one-shot (vf_net.hip): the same mask as sign bits, where the tensor's producer left them and the channel count is whole groups
+  g.dbits = (dmask && N % 64 == 0) ? ctx->dmask_bits : nullptr;
+  ctx->dmask_bits = nullptr;
   return launch_pconv(ctx, g, 4, "tr");
 }
 
