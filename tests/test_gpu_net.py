@@ -459,18 +459,21 @@ def test_syncbn_without_a_communicator_is_never_silently_local(oracle, hipb):
     bench line said `sync`.  Now: the library refuses world > 1 without a communicator, and the trainers keep such nets on the
     module-by-module host, which exchanges the sums over torch.distributed."""
     from video_filler_amd import nn, trainers
-    assert hipb.comm is None
-    onet, shape, rng = _nets("netD64", oracle, smooth=True)
-    h = Host(hipb, onet, shape)
-    assert h.lib.vf_net_set_sync_bn(h.net, None, 2, 0) != 0 and b"communicator" in h.lib.vf_last_error()
-    assert h.lib.vf_net_set_sync_bn(h.net, None, 1, 0) == 0
-    h.close()
-    netG = trainers.build_netG(3, 3, 16, 16, 32, False, True, True, False)
-    netD = trainers.build_netD(3, 16, False, True, True, False)
-    g1, d1, host = trainers._host_nets("cabi", netG, netD, sync_world=2)
-    assert host == "mirror" and g1 is netG and d1 is netD
-    g2, d2, host = trainers._host_nets("cabi", netG, netD, sync_world=1)
-    assert host == "cabi" and type(g2).__name__ == "CNet"
+    saved, hipb.comm = hipb.comm, None        # (an earlier test of the session may have attached a one-rank communicator)
+    try:
+        onet, shape, rng = _nets("netD64", oracle, smooth=True)
+        h = Host(hipb, onet, shape)
+        assert h.lib.vf_net_set_sync_bn(h.net, None, 2, 0) != 0 and b"communicator" in h.lib.vf_last_error()
+        assert h.lib.vf_net_set_sync_bn(h.net, None, 1, 0) == 0
+        h.close()
+        netG = trainers.build_netG(3, 3, 16, 16, 32, False, True, True, False)
+        netD = trainers.build_netD(3, 16, False, True, True, False)
+        g1, d1, host = trainers._host_nets("cabi", netG, netD, sync_world=2)
+        assert host == "mirror" and g1 is netG and d1 is netD
+        g2, d2, host = trainers._host_nets("cabi", netG, netD, sync_world=1)
+        assert host == "cabi" and type(g2).__name__ == "CNet"
+    finally:
+        hipb.comm = saved
 
 
 def test_derivative_mask_from_sign_bits_equals_the_fp32_mask(hipb):
