@@ -40,6 +40,63 @@ def csrc_digest():
     return h.hexdigest()
 
 
+def _pytorch_cpu_row(batch, nBottleneck, threads):
+    """train.lua's nets (87-199) and closures (278-410) in stock PyTorch on the CPU: whole iterations (fDx + Adam, fGx + Adam) on a
+    synthetic batch for about five seconds.  Timing only — parity lives with the oracle."""
+    import torch
+    import torch.nn as tnn
+    torch.set_num_threads(max(1, threads))
+    nef = ngf = ndf = 64
+
+    def conv(i, o, s2=True):
+        return tnn.Conv2d(i, o, 4, 2, 1) if s2 else tnn.Conv2d(i, o, 4)
+
+    def full(i, o, s2=True):
+        return tnn.ConvTranspose2d(i, o, 4, 2, 1) if s2 else tnn.ConvTranspose2d(i, o, 4)
+    G = tnn.Sequential(conv(3, nef), tnn.LeakyReLU(0.2, True),
+                       conv(nef, nef), tnn.BatchNorm2d(nef), tnn.LeakyReLU(0.2, True),
+                       conv(nef, nef * 2), tnn.BatchNorm2d(nef * 2), tnn.LeakyReLU(0.2, True),
+                       conv(nef * 2, nef * 4), tnn.BatchNorm2d(nef * 4), tnn.LeakyReLU(0.2, True),
+                       conv(nef * 4, nef * 8), tnn.BatchNorm2d(nef * 8), tnn.LeakyReLU(0.2, True),
+                       conv(nef * 8, nBottleneck, False), tnn.BatchNorm2d(nBottleneck), tnn.LeakyReLU(0.2, True),
+                       full(nBottleneck, ngf * 8, False), tnn.BatchNorm2d(ngf * 8), tnn.ReLU(True),
+                       full(ngf * 8, ngf * 4), tnn.BatchNorm2d(ngf * 4), tnn.ReLU(True),
+                       full(ngf * 4, ngf * 2), tnn.BatchNorm2d(ngf * 2), tnn.ReLU(True),
+                       full(ngf * 2, ngf), tnn.BatchNorm2d(ngf), tnn.ReLU(True),
+                       full(ngf, 3), tnn.Tanh())
+    D = tnn.Sequential(conv(3, ndf), tnn.LeakyReLU(0.2, True),
+                       conv(ndf, ndf * 2), tnn.BatchNorm2d(ndf * 2), tnn.LeakyReLU(0.2, True),
+                       conv(ndf * 2, ndf * 4), tnn.BatchNorm2d(ndf * 4), tnn.LeakyReLU(0.2, True),
+                       conv(ndf * 4, ndf * 8), tnn.BatchNorm2d(ndf * 8), tnn.LeakyReLU(0.2, True),
+                       conv(ndf * 8, 1, False), tnn.Sigmoid(), tnn.Flatten())
+    optD = torch.optim.Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    optG = torch.optim.Adam(G.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    bce, mse = tnn.BCELoss(), tnn.MSELoss()
+    g = torch.Generator().manual_seed(1)
+    ctx = torch.rand((batch, 3, 128, 128), generator=g) * 2 - 1
+    center = ctx[:, :, 32:96, 32:96].clone()
+    ones, zeros = torch.ones(batch, 1), torch.zeros(batch, 1)
+
+    def step():
+        optD.zero_grad(set_to_none=True)
+        fake = G(ctx)
+        errD = bce(D(center), ones) + bce(D(fake.detach()), zeros)
+        errD.backward()
+        optD.step()
+        optG.zero_grad(set_to_none=True)
+        errG = 0.001 * bce(D(fake), ones) + 0.999 * mse(fake, center)
+        errG.backward()
+        optG.step()
+    step()                                  # (allocations, oneDNN primitive creation)
+    t0, n = time.perf_counter(), 0
+    while n < 8 and (n == 0 or time.perf_counter() - t0 < 5.0):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(n * batch / dt, 3), unit="images/s", cores=threads, kind="pytorch %s CPU, not the reference's code" % torch.__version__,
+                sample="%d iterations of the same nets and losses at batchSize=%d, %.1f s" % (n, batch, dt))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +113,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-torch-cpu-baseline", action="store_true", help="skip the optional third baseline row (the same iteration in stock "
+                    "PyTorch on the host cores, ~6 s; configs[1] only)")
     ap.add_argument("--sync-bn", action="store_true", help="N>1: all-reduce BatchNorm sums (big-batch parity mode)")
     ap.add_argument("--fine-size", type=int, default=128, choices=[128, 256], help="wholeim only: 256 = the labelled NON-PARITY "
                     "extension opt.ext256 (the reference's nets fail at that size: one more stride-2 stage in netD and around "
@@ -457,6 +516,14 @@ def main():
             O.set_num_threads(1)
             cpu["all_cores"] = dict(value=round(cb / cdt2, 3), unit="images/s", cores=ncores,
                                     sample="the same iteration, OpenMP over %d threads (the one-GPU box's CPU share), %.1f s" % (ncores, cdt2))
+
+        # third row (SURVEY 8(d) iii, optional): the same train.lua iteration in stock PyTorch on the host cores — not the reference's
+        # code (Torch7's CPU `nn` is what the oracle restates), a familiar yardstick beside it.  configs[1] only; bounded sample.
+        if args.workload == "center" and not args.no_torch_cpu_baseline:
+            try:
+                cpu["pytorch_cpu"] = _pytorch_cpu_row(cb, args.nBottleneck, ncores)
+            except Exception as e:      # noqa: BLE001 — a yardstick must never cost the bench line
+                cpu["pytorch_cpu"] = dict(error="%s: %s" % (type(e).__name__, e))
 
     if rank == 0:
         n_img = world * args.batch * args.steps
