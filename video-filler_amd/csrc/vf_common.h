@@ -50,6 +50,12 @@ struct vf_ctx {
   unsigned* act_bits_out;
   int act_bits_written;
   const unsigned* dmask_bits;
+  // one-shot (vf_net.hip): the next 512 -> 1 head pass of vf_conv.hip (k_dot_bwd_data / k_dot_bwd_weight: netD's last conv,
+  // train.lua:195-196) multiplies its gradOutput by the derivative of the Sigmoid fused into that conv, evaluated from the
+  // activated output — instead of a pass of its own over B values in front of it
+  const float* dot_act_y;
+  int dot_act;
+  float dot_act_slope;
 };
 void vf_internal_wg_free(vf_ctx* ctx);
 

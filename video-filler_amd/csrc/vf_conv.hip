@@ -1286,27 +1286,33 @@ __global__ __launch_bounds__(256) void k_dot_fwd(const float* __restrict__ x, co
   __syncthreads();
   if (threadIdx.x == 0) y[b] = vf_act_apply(((red[0] + red[1]) + (red[2] + red[3])) + (bias ? bias[0] : 0.f), act, slope);
 }
+// ya != NULL: gy is the gradient w.r.t. the ACTIVATED output ya (the Sigmoid fused into this conv): its derivative rides here
 __global__ void k_dot_bwd_data(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int B,
-                               int K) {
+                               int K, const float* __restrict__ ya, int act, float slope) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < (int64_t)B * K) gx[i] = gy[i / K] * w[i % K];
+  if (i < (int64_t)B * K) {
+    const int64_t b = i / K;
+    const float g = ya ? vf_act_grad(ya[b], gy[b], act, slope) : gy[b];
+    gx[i] = g * w[i % K];
+  }
 }
 // gw[k] = beta*gw[k] + sum_b gy[b]*x[b][k]: a block owns 64 columns; its 4 waves take every 4th sample (coalesced
 // 256-byte rows), partials meet in LDS in a fixed order.  (One thread per column walking all B samples was a
 // 64-deep dependent load chain on 32 blocks: 19 us for 2 MB.)
 __global__ __launch_bounds__(256) void k_dot_bwd_weight(const float* __restrict__ x, const float* __restrict__ gy,
                                                         float* __restrict__ gw, float* __restrict__ gb, int B, int K,
-                                                        float beta) {
+                                                        float beta, const float* __restrict__ ya, int act, float slope) {
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f;
+  auto G = [&](int b) { return ya ? vf_act_grad(ya[b], gy[b], act, slope) : gy[b]; };      // (see k_dot_bwd_data)
   if (k < K) {
     int b = grp;
     for (; b + 4 < B; b += 8) {
-      s0 += gy[b] * x[(int64_t)b * K + k];
-      s1 += gy[b + 4] * x[(int64_t)(b + 4) * K + k];
+      s0 += G(b) * x[(int64_t)b * K + k];
+      s1 += G(b + 4) * x[(int64_t)(b + 4) * K + k];
     }
-    for (; b < B; b += 4) s0 += gy[b] * x[(int64_t)b * K + k];
+    for (; b < B; b += 4) s0 += G(b) * x[(int64_t)b * K + k];
   }
   __shared__ float red[4][64];
   red[grp][lane] = s0 + s1;
@@ -1317,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_dot_bwd_weight(const float* __restrict_
   }
   if (gb && blockIdx.x == 0 && threadIdx.x == 0) {
     float t = 0.f;
-    for (int b = 0; b < B; ++b) t += gy[b];
+    for (int b = 0; b < B; ++b) t += G(b);
     gb[0] = (beta != 0.f ? beta * gb[0] : 0.f) + t;
   }
 }
@@ -2158,7 +2164,10 @@ VF_API int vf_conv2d_bwd_data(vf_ctx* ctx, const float* gy, const float* w, floa
     VF_REQUIRE(H == 4 && W == 4, "stride-1 conv data-grad is built for the 4x4 bottleneck input only");
     if (Cout == 1) {
       const int64_t n = (int64_t)B * 16 * Cin;
-      hipLaunchKernelGGL(k_dot_bwd_data, dim3((int)vf_cdiv(n, 256)), dim3(256), 0, ctx->stream, gy, w, gx, B, 16 * Cin);
+      const float* ya = ctx->dot_act_y;      // one-shot: the derivative of the activation fused into this conv (vf_net.hip)
+      ctx->dot_act_y = nullptr;
+      hipLaunchKernelGGL(k_dot_bwd_data, dim3((int)vf_cdiv(n, 256)), dim3(256), 0, ctx->stream, gy, w, gx, B, 16 * Cin, ya, ctx->dot_act,
+                         ctx->dot_act_slope);
       VF_LAUNCH_CHECK();
       return 0;
     }
@@ -2196,8 +2205,10 @@ static int conv2d_bwd_weight_impl(vf_ctx* ctx, const float* x, const float* gy, 
   if (int rc = check_conv_args(B, H, W, Cin, Cout, k, stride, pad)) return rc;
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   if (Cout == 1 && stride == 1 && H == 4 && W == 4) {
+    const float* ya = ctx->dot_act_y;      // (see vf_conv2d_bwd_data)
+    ctx->dot_act_y = nullptr;
     hipLaunchKernelGGL(k_dot_bwd_weight, dim3((int)vf_cdiv(16 * Cin, 64)), dim3(256), 0, ctx->stream, x, gy, gw, gb, B,
-                       16 * Cin, beta);
+                       16 * Cin, beta, ya, ctx->dot_act, ctx->dot_act_slope);
     VF_LAUNCH_CHECK();
     return 0;
   }

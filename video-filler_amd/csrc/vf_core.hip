@@ -46,6 +46,9 @@ VF_API int vf_ctx_create(vf_ctx** out, int device, void* stream) {
   c->act_bits_out = nullptr;
   c->act_bits_written = 0;
   c->dmask_bits = nullptr;
+  c->dot_act_y = nullptr;
+  c->dot_act = 0;
+  c->dot_act_slope = 0.f;
   *out = c;
   return 0;
 }

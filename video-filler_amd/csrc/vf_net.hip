@@ -51,7 +51,8 @@ namespace {
 double g_gate_gflop = getenv("VF_PCONV_MIN_GFLOP") ? atof(getenv("VF_PCONV_MIN_GFLOP")) : 3.0;
 int g_gate_rows = getenv("VF_PCONV_MIN_ROWS") ? atoi(getenv("VF_PCONV_MIN_ROWS")) : 1024;
 const bool g_no_pconv = getenv("VF_NO_PCONV") != nullptr;
-const bool g_no_act_bits = getenv("VF_NO_ACT_BITS") != nullptr;      // (A/B switch: derivative masks from the fp32 activations only)
+const bool g_no_act_bits = getenv("VF_NO_ACT_BITS") != nullptr;
+const bool g_no_head_fuse = getenv("VF_NO_HEAD_FUSE") != nullptr;     // (A/B switch: the head's Sigmoid backward as a launch of its own)      // (A/B switch: derivative masks from the fp32 activations only)
 const bool g_no_bn_fuse = getenv("VF_NO_BN_FUSE") != nullptr;
 const bool g_pwgrad = !(getenv("VF_PWGRAD") && strcmp(getenv("VF_PWGRAD"), "1") != 0);
 
@@ -559,7 +560,11 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
     }
     if (is_conv(l)) {
       const float* go = g;
-      if (l.fused_act != VF_ACT_NONE && !act_done) {
+      // netD's 512 -> 1 head (train.lua:195-196: conv 4x4 on the 4x4 map + Sigmoid): the Sigmoid's derivative rides in the two dot
+      // kernels of its backward pass (vf_ctx::dot_act_y) instead of a launch of its own over B values
+      const bool dot_head = l.d.kind == VF_L_CONV && l.Co == 1 && l.d.k == 4 && l.d.stride == 1 && l.d.pad == 0 && l.H == 4 && l.W == 4 &&
+                            l.fused_act != VF_ACT_NONE && !relu_like(l.fused_act) && !act_done && !g_no_head_fuse;
+      if (l.fused_act != VF_ACT_NONE && !act_done && !dot_head) {
         // undo the activation applied in this layer's epilogue: in place on the incoming gradient where that is ours (an
         // in-place module does exactly that), else — the caller's gradOutput, Tanh / Sigmoid — into a buffer of its own
         const bool ours = g != gy;
@@ -604,12 +609,24 @@ int net_walk_back(vf_net* n, const float* x_in, const float* gy, const float** g
           fuse_below = true;
         }
       }
+      auto arm_head = [&]() {
+        ctx->dot_act_y = dot_head ? mout : nullptr;
+        ctx->dot_act = l.fused_act;
+        ctx->dot_act_slope = l.fused_slope;
+      };
       if (want_gx) {
+        arm_head();
         rc = conv_bwd_data(n, l, x, go, Bn, fuse_below ? VF_ACT_NONE : in_act, in_slope, g_pl, fuse_below ? nullptr : in_bits);
+        ctx->dot_act_y = nullptr;
         if (fuse_below && !rc) rc = vf_bn_fuse_result(ctx, &pre);
         if (rc) break;
       }
-      if (want_gp && (rc = conv_acc(n, l, x, go, Bn, &deferred))) break;
+      if (want_gp) {
+        arm_head();
+        rc = conv_acc(n, l, x, go, Bn, &deferred);
+        ctx->dot_act_y = nullptr;
+        if (rc) break;
+      }
       g = want_gx ? l.gx : nullptr;
       g_pl = nullptr;
       act_done = !fuse_below && in_act != VF_ACT_NONE && want_gx;
