@@ -369,7 +369,16 @@ def main():
         for n, k in kernels.items():
             fam[family(n)] = fam.get(family(n), 0.0) + k["ms"]
         top_family = max(fam, key=fam.get)
-        name, dom = max(((n, k) for n, k in kernels.items() if family(n) == top_family), key=lambda kv: kv[1]["ms"])
+        # ... and among that template's symbols the one with the most time; symbols within 5 % of the top time are a tie (which of two
+        # near-equal symbols leads changes from box to box), broken towards the SLOWER rate so that the headline cannot improve by a
+        # symbol swap (VERDICT r3 weak #5b).  roofline.family_weighted / worst_symbol carry the rest of the family.
+        members_all = [(n, k) for n, k in kernels.items() if family(n) == top_family]
+        top_ms = max(k["ms"] for _, k in members_all)
+
+        def _rate(k):
+            work = k["flops"] if k["flops"] > 0 else k["bytes"]
+            return work / k["ms"] if k["ms"] > 0 else 0.0
+        name, dom = min(((n, k) for n, k in members_all if k["ms"] >= 0.95 * top_ms), key=lambda kv: _rate(kv[1]))
         avg_ms = dom["ms"] / dom["launches"]
         # which roofline bounds it: a kernel that reports both its algorithmic FLOPs and bytes is priced against the LONGER of the
         # two floors (configs[4]'s batch-4 passes over a 629 MB weight tensor are matrix-core kernels bounded by the weight read)
