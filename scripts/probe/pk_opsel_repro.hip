@@ -24,6 +24,7 @@
 #endif                // packed instructions even with the GPU to itself)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Mis {
   int block, wave, lane, round, chain, half;
@@ -31,7 +32,7 @@ struct Mis {
 };
 
 __global__ __launch_bounds__(256) void k_repro(const float* __restrict__ wsrc, const float* __restrict__ xsrc, int rounds, Mis* log,
-                                               int* nlog, unsigned long long* checked) {
+                                               int* nlog, unsigned long long* checked, int* per_cu = nullptr) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   // per-lane operands: 4 steps x 2 chains of (w pair), 2 x pairs per round, reloaded every round from a table that differs per lane
@@ -89,6 +90,10 @@ __global__ __launch_bounds__(256) void k_repro(const float* __restrict__ wsrc, c
     for (int q = 0; q < 4; ++q)
       if (__float_as_uint(got[q]) != __float_as_uint(want[q])) {
         const int i = atomicAdd(nlog, 1);
+        if (per_cu) {       // where the wave runs: XCC_ID (hwreg 20) bits 3:0; HW_ID (hwreg 4): cu_id 11:8, sh_id 12, se_id 15:13
+          const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20), hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
+          atomicAdd(per_cu + (xcc & 7) * 128 + ((hw >> 13) & 7) * 16 + ((hw >> 8) & 15), 1);
+        }
         if (i < 256) log[i] = Mis{(int)blockIdx.x, (int)(threadIdx.x >> 6), lane, r, q >> 1, q & 1, want[q], got[q]};
       }
     // resynchronise (a fault must not be counted again every round) and keep the magnitudes bounded
@@ -198,6 +203,158 @@ __global__ __launch_bounds__(256) void k_nb_coexec(float* out, int iters) {
   }
   if (acc[0] == 12345.f || x == 12345.f) out[0] = acc[1];
 }
+// 11+: a GEMM-like loop assembled from pieces (bit mask `what`: 1 v_perm split VALU, 2 ds_write_b64, 4 ds_read_b128 + bf16 MFMAs, 8 a barrier
+// on either side of the LDS phase) — which combination does it take?
+__global__ __launch_bounds__(256) void k_nb_combo(float* out, int iters, int what) {
+  __shared__ __attribute__((aligned(16))) __bf16 sh[3 * 128 * 32];
+  for (int i = threadIdx.x; i < 3 * 128 * 32; i += 256) sh[i] = (__bf16)(0.001f * (i & 63));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x16 acc = {};
+  float r0 = threadIdx.x * 0.37f + 1.f, r1 = r0 * 1.7f, r2 = r0 * 0.3f, r3 = r1 * 0.9f;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  for (int i = 0; i < iters; ++i) {
+    u32x2 pl[3] = {};
+    if (what & 1) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1), u2 = __float_as_uint(r2), u3 = __float_as_uint(r3);
+        pl[q][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        pl[q][1] = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+        r0 -= __uint_as_float(u0 & 0xffff0000u); r1 -= __uint_as_float(u1 & 0xffff0000u);
+        r2 -= __uint_as_float(u2 & 0xffff0000u); r3 -= __uint_as_float(u3 & 0xffff0000u);
+      }
+      r0 = r0 * 3.1f + 0.77f; r1 = r1 * 2.9f + 0.31f; r2 = r2 * 1.3f + 0.11f; r3 = r3 * 0.7f + 0.05f;
+    }
+    if (what & 8) __syncthreads();
+    if (what & 2) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *(u32x2*)(sh + q * 128 * 32 + (threadIdx.x >> 3) * 32 + 4 * (threadIdx.x & 7)) = pl[q];
+    }
+    if (what & 8) __syncthreads();
+    if (what & 4) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bf16x8 a[3], b[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          a[q] = *(const bf16x8*)(sh + q * 128 * 32 + ((wave & 1) * 32 + (lane & 31)) * 32 + 16 * g + 8 * (lane >> 5));
+          b[q] = *(const bf16x8*)(sh + q * 128 * 32 + (64 + (wave >> 1) * 32 + (lane & 31)) * 32 + 16 * g + 8 * (lane >> 5));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+      }
+    }
+  }
+  if (acc[0] == 12345.f || r0 == 12345.f) out[0] = acc[1] + r1 + r2 + r3;
+}
+// 11: nothing but a workgroup that HOLDS KB kilobytes of LDS (gfx950 allows 160 KB per workgroup; up to gfx942 the limit was 64) and
+// reads/writes a few words of it, at the bottom (HIGH = 0) or at the top (HIGH = 1) of the allocation
+template <int KB, int HIGH>
+__global__ __launch_bounds__(256) void k_nb_biglds(float* out, int iters) {
+  __shared__ float sh[KB * 256];
+  const int at = (HIGH ? KB * 256 - 512 : 0) + threadIdx.x;
+  sh[at] = threadIdx.x;
+  float a = 0.f;
+  for (int i = 0; i < iters; ++i) {
+    a += sh[at ^ (i & 63)];
+    sh[at] = a * 0.5f;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  if (a == 12345.f) out[0] = a;
+}
+// 200 + mask: the schedule the ablation of the library's double-buffered GEMM points at (profiles/r04_pk_opsel_reproducer.txt): work issued
+// in the SHADOW of a running MFMA, pinned there with scheduling barriers.  Mask: 1 the v_perm/v_sub plane split, 2 a ds_write_b64 of the
+// result, 4 fragments re-read from LDS (ds_read_b128) every round, 8 a barrier per round
+template <int what>
+__global__ __launch_bounds__(256) void k_nb_shadow(float* out, int iters) {
+  __shared__ __attribute__((aligned(16))) __bf16 sh[2 * 3 * 128 * 32];
+  for (int i = threadIdx.x; i < 2 * 3 * 128 * 32; i += 256) sh[i] = (__bf16)(0.001f * (i & 63));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  f32x16 acc = {};
+  float r0 = threadIdx.x * 0.37f + 1.f, r1 = r0 * 1.7f, r2 = r0 * 0.3f, r3 = r1 * 0.9f;
+  bf16x8 a[3], b[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    a[q] = *(const bf16x8*)(sh + q * 128 * 32 + ((wave & 1) * 32 + (lane & 31)) * 32 + 8 * (lane >> 5));
+    b[q] = *(const bf16x8*)(sh + q * 128 * 32 + (64 + (wave >> 1) * 32 + (lane & 31)) * 32 + 8 * (lane >> 5));
+  }
+  for (int i = 0; i < iters; ++i) {
+    __bf16* wr = sh + (1 - (i & 1)) * 3 * 128 * 32;      // writes go to the buffer nobody reads this round
+    const __bf16* rd = sh + (i & 1) * 3 * 128 * 32;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      constexpr int qa[6] = {1, 0, 2, 0, 1, 0}, qb[6] = {1, 2, 0, 1, 0, 0};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa[t]], b[qb[t]], acc, 0, 0, 0);
+      if (t >= 3) {        // one piece per MFMA slot, as the GEMM does it
+        u32x2 pl[3] = {};
+        if (what & 1) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const unsigned u0 = __float_as_uint(r0), u1 = __float_as_uint(r1), u2 = __float_as_uint(r2), u3 = __float_as_uint(r3);
+            pl[q][0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+            pl[q][1] = __builtin_amdgcn_perm(u3, u2, 0x07060302u);
+            r0 -= __uint_as_float(u0 & 0xffff0000u); r1 -= __uint_as_float(u1 & 0xffff0000u);
+            r2 -= __uint_as_float(u2 & 0xffff0000u); r3 -= __uint_as_float(u3 & 0xffff0000u);
+          }
+          r0 = r0 * 3.1f + 0.77f; r1 = r1 * 2.9f + 0.31f; r2 = r2 * 1.3f + 0.11f; r3 = r3 * 0.7f + 0.05f;
+        }
+        if (what & 2) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *(u32x2*)(wr + q * 128 * 32 + ((t - 3) * 32 + (threadIdx.x >> 3)) * 32 + 4 * (threadIdx.x & 7)) = pl[q];
+        }
+      }
+      if (t == 0 && (what & 4)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          a[q] = *(const bf16x8*)(rd + q * 128 * 32 + ((wave & 1) * 32 + (lane & 31)) * 32 + 8 * (lane >> 5));
+          b[q] = *(const bf16x8*)(rd + q * 128 * 32 + (64 + (wave >> 1) * 32 + (lane & 31)) * 32 + 8 * (lane >> 5));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (what & 8) __syncthreads();
+  }
+  if (acc[0] == 12345.f || r0 == 12345.f) out[0] = acc[1] + r1 + r2 + r3;
+}
+// 300 + form: the smallest trigger found — one MFMA and one LDS store per round, nothing else.  form 0/1/2: ds_write_b32 / b64 / b128 right
+// behind the MFMA in the same wave; 3: waves 0-1 issue only the MFMAs, waves 2-3 only the ds_write_b64 (other SIMDs of the CU);
+// 4: the ds_write_b64 alone; 5: a 16x16x32 MFMA with the ds_write_b64; 6: an fp32 MFMA (32x32x2) with the ds_write_b64
+template <int FORM>
+__global__ __launch_bounds__(256) void k_nb_min(float* out, int iters) {
+  __shared__ __attribute__((aligned(16))) float sh[256 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x16 acc = {};
+  f32x4 acc4 = {};
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.01f * (lane + j)); b[j] = (__bf16)(0.02f * (lane - j)); }
+  const unsigned at = threadIdx.x * 16;
+  sh[threadIdx.x] = 0.f;
+  f32x4 val = {1.f * lane, 2.f, 3.f, 4.f};
+  const bool do_mfma = FORM != 4 && (FORM != 3 || wave < 2), do_write = FORM != 3 || wave >= 2;
+  for (int i = 0; i < iters; ++i) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_mfma) {
+      if constexpr (FORM == 5) acc4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc4, 0, 0, 0);
+      else if constexpr (FORM == 6) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(val[0], val[1], acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    if (do_write) {       // (inline assembly: a volatile C++ store through a generic pointer becomes flat_store; sh is the only LDS object, at 0)
+      if constexpr (FORM == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(at), "v"(val[0]) : "memory");
+      else if constexpr (FORM == 2) asm volatile("ds_write_b128 %0, %1" ::"v"(at), "v"(val) : "memory");
+      else asm volatile("ds_write_b64 %0, %1" ::"v"(at), "v"(f32x2{val[0], val[1]}) : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (acc[0] == 12345.f || acc4[0] == 12345.f) out[0] = acc[1] + acc4[1] + sh[lane];
+}
 // 10: bf16 MFMAs whose accumulator lives in AGPRs (as the library's GEMM kernels' do)
 __global__ __launch_bounds__(256) void k_nb_mfma_agpr(float* out, int iters) {
   bf16x8 a, b;
@@ -233,6 +390,8 @@ int main(int argc, char** argv) {
   hipMalloc(&dw, N * 4); hipMalloc(&dx, N * 4); hipMalloc(&dlog, 256 * sizeof(Mis)); hipMalloc(&dn, 4); hipMalloc(&dc, 8);
   hipMemcpy(dw, hw.data(), N * 4, hipMemcpyHostToDevice); hipMemcpy(dx, hx.data(), N * 4, hipMemcpyHostToDevice);
   hipMemset(dn, 0, 4); hipMemset(dc, 0, 8);
+  int* dcu;
+  hipMalloc(&dcu, 1024 * 4); hipMemset(dcu, 0, 1024 * 4);
   hipStream_t s1, s2;
   hipStreamCreate(&s1); hipStreamCreate(&s2);
   float* nbo; float4 *nbs = nullptr, *nbd = nullptr;
@@ -255,14 +414,35 @@ int main(int argc, char** argv) {
     void* ws;
     hipMalloc(&ws, (size_t)256 << 20);
     if (create(&vctx, 0, (void*)s2) || setws(vctx, ws, (size_t)256 << 20)) { printf("vf_ctx setup failed\n"); return 2; }
+    // NB_MFMA_MODE: the library's GEMM arithmetic (0 fp32 MFMA, 1 one bf16 plane, 3 three bf16 planes = its default)
+    if (getenv("NB_MFMA_MODE")) ((int (*)(void*, int))dlsym(lib, "vf_ctx_set_mfma_mode"))(vctx, atoi(getenv("NB_MFMA_MODE")));
     hipMalloc(&cx, (size_t)64 * 32 * 32 * 64 * 4); hipMalloc(&cw, (size_t)128 * 16 * 64 * 4); hipMalloc(&cy, (size_t)64 * 16 * 16 * 128 * 4);
     hipMemset(cx, 0, (size_t)64 * 32 * 32 * 64 * 4); hipMemset(cw, 0, (size_t)128 * 16 * 64 * 4);
   }
+  // NB_CONV_B: batch of the library launch (64 = E3's own 512 blocks; 1 = 8 blocks, i.e. 8 of the 256 CUs run the GEMM)
+  const int conv_b = getenv("NB_CONV_B") ? atoi(getenv("NB_CONV_B")) : 64;
   const auto t0 = std::chrono::steady_clock::now();
   int launches = 0;
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
     if (neighbour == 5)
-      for (int q = 0; q < 2; ++q) conv(vctx, cx, cw, nullptr, cy, 64, 32, 32, 64, 128, 4, 2, 1, 0, 0.f);      // E3 forward, ~45 us each
+      for (int q = 0; q < 2; ++q) conv(vctx, cx, cw, nullptr, cy, conv_b, 32, 32, 64, 128, 4, 2, 1, 0, 0.f);      // E3 forward, ~45 us each
+    if (neighbour >= 300) {
+      const int w = neighbour - 300;
+      auto f = w == 0 ? k_nb_min<0> : w == 1 ? k_nb_min<1> : w == 2 ? k_nb_min<2> : w == 3 ? k_nb_min<3> : w == 4 ? k_nb_min<4> : w == 5 ? k_nb_min<5> : k_nb_min<6>;
+      if (launches % 16 == 0) hipLaunchKernelGGL(f, dim3(512), dim3(256), 0, s2, nbo, 100000);
+    } else
+    if (neighbour >= 200) {
+      const int w = neighbour - 200;
+      auto f = w == 2 ? k_nb_shadow<2> : w == 3 ? k_nb_shadow<3> : w == 6 ? k_nb_shadow<6> : w == 7 ? k_nb_shadow<7> : w == 10 ? k_nb_shadow<10>
+             : w == 11 ? k_nb_shadow<11> : w == 14 ? k_nb_shadow<14> : k_nb_shadow<15>;
+      if (launches % 16 == 0) hipLaunchKernelGGL(f, dim3(512), dim3(256), 0, s2, nbo, 20000);
+    } else
+    if (neighbour >= 100) {         // NB_ITERS / NB_PER_LAUNCH: short kernels launched often (as the library's 45 us GEMMs are) or one long one
+      static const int nb_iters = getenv("NB_ITERS") ? atoi(getenv("NB_ITERS")) : 20000, nb_per = getenv("NB_PER_LAUNCH") ? atoi(getenv("NB_PER_LAUNCH")) : 0;
+      static const int nb_blocks = getenv("NB_BLOCKS") ? atoi(getenv("NB_BLOCKS")) : 512;
+      if (nb_per) for (int q = 0; q < nb_per; ++q) hipLaunchKernelGGL(k_nb_combo, dim3(nb_blocks), dim3(256), 0, s2, nbo, nb_iters, neighbour - 100);
+      else if (launches % 16 == 0) hipLaunchKernelGGL(k_nb_combo, dim3(nb_blocks), dim3(256), 0, s2, nbo, nb_iters, neighbour - 100);
+    }
     if (launches % 16 == 0) {       // ~16 reproducer launches' worth of neighbour work, two blocks per CU
       if (neighbour == 1) hipLaunchKernelGGL(k_nb_mfma, dim3(512), dim3(256), 0, s2, nbo, 40000);
       if (neighbour == 2) hipLaunchKernelGGL(k_nb_lds, dim3(512), dim3(256), 0, s2, nbo, 40000);
@@ -272,9 +452,15 @@ int main(int argc, char** argv) {
       if (neighbour == 7) hipLaunchKernelGGL(k_nb_trread, dim3(512), dim3(256), 0, s2, nbo, 40000);
       if (neighbour == 8) hipLaunchKernelGGL(k_nb_split, dim3(512), dim3(256), 0, s2, nbo, 60000);
       if (neighbour == 9) hipLaunchKernelGGL(k_nb_coexec, dim3(512), dim3(256), 0, s2, nbo, 40000);
+      if (neighbour == 11) {
+        static const int kb = getenv("NB_LDS_KB") ? atoi(getenv("NB_LDS_KB")) : 66, high = getenv("NB_LDS_HIGH") ? atoi(getenv("NB_LDS_HIGH")) : 0;
+        auto f = kb == 48 ? k_nb_biglds<48, 0> : kb == 64 ? (high ? k_nb_biglds<64, 1> : k_nb_biglds<64, 0>)
+               : kb == 66 ? (high ? k_nb_biglds<66, 1> : k_nb_biglds<66, 0>) : (high ? k_nb_biglds<128, 1> : k_nb_biglds<128, 0>);
+        hipLaunchKernelGGL(f, dim3(256), dim3(256), 0, s2, nbo, 20000);
+      }
       if (neighbour == 10) hipLaunchKernelGGL(k_nb_mfma_agpr, dim3(512), dim3(256), 0, s2, nbo, 40000);
     }
-    hipLaunchKernelGGL(k_repro, dim3(512), dim3(256), 0, s1, dw, dx, 2000, dlog, dn, dc);      // short launches: waves come and go beside the neighbours'
+    hipLaunchKernelGGL(k_repro, dim3(512), dim3(256), 0, s1, dw, dx, 2000, dlog, dn, dc, dcu);      // short launches: waves come and go beside the neighbours'
     if (++launches % 16 == 0) hipDeviceSynchronize();
   }
   hipDeviceSynchronize();
@@ -283,7 +469,7 @@ int main(int argc, char** argv) {
   std::vector<Mis> h(256);
   hipMemcpy(&n, dn, 4, hipMemcpyDeviceToHost); hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
   hipMemcpy(h.data(), dlog, 256 * sizeof(Mis), hipMemcpyDeviceToHost);
-  printf("neighbour %d (0 none, 1 MFMA, 2 LDS, 3 global memory, 4 VALU, 5 the library's implicit GEMM, 6 MFMA from LDS + barrier, 7 ds_read_b64_tr_b16, 8 v_perm split, 9 MFMA + VALU, 10 MFMA into AGPRs) | ", neighbour);
+  printf("neighbour %d (0 none, 1 MFMA, 2 LDS, 3 global memory, 4 VALU, 5 the library's implicit GEMM, 6 MFMA from LDS + barrier, 7 ds_read_b64_tr_b16, 8 v_perm split, 9 MFMA + VALU, 10 MFMA into AGPRs, 11 a workgroup holding NB_LDS_KB of LDS, 100 + mask: GEMM-like combination, 200 + mask: work in the shadow of MFMAs, 300 + form: one MFMA + one LDS store per round) | ", neighbour);
   printf("variant %d: %d launches, %.3e packed results checked, %d mismatches\n", VARIANT, launches, (double)c, n);
   int q48 = 0, lo = 0;
   for (int i = 0; i < n && i < 256; ++i) {
@@ -292,6 +478,16 @@ int main(int argc, char** argv) {
     if (i < 12)
       printf("  block %d wave %d lane %d round %d chain %d half %s: want %.9g got %.9g\n", h[i].block, h[i].wave, h[i].lane, h[i].round,
              h[i].chain, h[i].half ? "hi" : "lo", h[i].want, h[i].got);
+  }
+  if (n) {
+    std::vector<int> cu(1024);
+    hipMemcpy(cu.data(), dcu, 1024 * 4, hipMemcpyDeviceToHost);
+    int hit = 0;
+    for (int i = 0; i < 1024; ++i) hit += cu[i] != 0;
+    printf("  mismatching waves ran on %d distinct (xcc, se, cu) places:", hit);
+    for (int i = 0, shown = 0; i < 1024 && shown < 16; ++i)
+      if (cu[i]) { printf(" x%d.s%d.c%d=%d", i >> 7, (i >> 4) & 7, i & 15, cu[i]); ++shown; }
+    printf("\n");
   }
   if (n) printf("  of the first %d logged: %d in lanes 48-63, %d in the low dword\n", n < 256 ? n : 256, q48, lo);
   return 0;
