@@ -789,6 +789,221 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
                                        pre_d, pre_x);
 }
 
+// ------------------------------------------------------------------------------------------------ transposed passes from a PATCH
+// k_pconv_dma walks a transposed pass (conv data-gradient, full-conv forward) as four independent 2x2-tap GEMMs, one per output-parity
+// class, and fills its LDS stages tap by tap: every low-res pixel of the operand travels L2 -> LDS 4 (taps) x 4 (classes) times, the
+// weights once per 128-row tile and class.  For the 64-output-channel layers, whose tiles have only 4-8 K steps, that fill stream IS
+// the kernel: E2's data-gradient moves 590 MB through L2 in 55 us (10.7 TB/s of the ~17 the L2 can feed to LDS-DMA,
+// MI355X_MICROARCH.md "Indexed rows: gather into LDS") for 20 us of MFMAs.  Here a block owns an 8 x 16 region of the low-res grid for
+// CPB = 2 or 4 parity classes at once: the region's pixels with a one-pixel halo are staged ONCE per 64-channel chunk as a patch
+// ([3 planes][PR x 18 slots][64 ch], 62-69 KB), every (class, tap) A fragment is a ds_read_b128 from that patch at a per-lane slot
+// (row (ry, rx) of the tile, tap (th, tw) of class (ph, pw): slot (ry + ph + th) * 18 + rx + pw + tw), and only the weights stream
+// through two 24 KB stages, one (class, tap) step of 24 MFMAs per wave each.  Per 512 outputs x 64 channels of K: 69 + 393 KB instead
+// of 4 x 288.  N = 64 exactly, C % 64 == 0, Wi % 16 == 0, Hi % 8 == 0, no split-K; 8 waves of one 32 x 32 accumulator per class.
+// CPB = 2: the block's classes share ph (its patch has 9 rows); twice the blocks — for the grids that would otherwise leave CUs idle.
+template <int CPB>
+__global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
+  constexpr int PR = CPB == 4 ? 10 : 9, PW = 18, NSLOT = PR * PW, NG = (NSLOT + 7) / 8;      // patch slots, 8-slot DMA groups
+  constexpr int AGW = (NG + 7) / 8;                                                         // patch groups per wave
+  constexpr int PATCH_PL = NG * 8 * 128, PATCH_BYTES = 3 * PATCH_PL;                         // bytes
+  constexpr int W_PL = 64 * 128, WBUF = 3 * W_PL;                                            // one (class, tap) weight stage
+  constexpr int NS = 4 * CPB;                                                               // (class, tap) steps per channel chunk
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[PATCH_BYTES + 2 * WBUF + 2 * 4 * 64 * 4];
+  float* red = (float*)(smem + PATCH_BYTES + 2 * WBUF);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int lr = lane & 31, lh = lane >> 5;
+  int lid = pg_xcd_remap(blockIdx.x, gridDim.x);
+  int ph_blk = 0;
+  if constexpr (CPB == 2) {
+    ph_blk = lid & 1;
+    lid >>= 1;
+  }
+  const int tiles_x = p.Wi >> 4, tiles_y = p.Hi >> 3;
+  const int tx = lid % tiles_x, ty = (lid / tiles_x) % tiles_y, b = lid / (tiles_x * tiles_y);
+  const int ry0 = 8 * ty, rx0 = 16 * tx;
+  const int bx = lid;                                       // row-tile index (batch-major): the statistics' partial row
+
+  // ---- this lane's share of the patch: slot 8 * group + lane / 8, LDS octet lane % 8 = global octet ^ swizzle(slot's column)
+  unsigned a_byte[AGW], a_lds[AGW];
+#pragma unroll
+  for (int i = 0; i < AGW; ++i) {
+    const int grp = wave + 8 * i;
+    const int sl = 8 * grp + (lane >> 3);
+    const int py = sl / PW, px = sl - py * PW;
+    const int il = ry0 - 1 + (CPB == 2 ? ph_blk : 0) + py, jl = rx0 - 1 + px;
+    const bool ok = grp < NG && sl < NSLOT && (unsigned)il < (unsigned)p.Hi && (unsigned)jl < (unsigned)p.Wi;
+    const int oct = (lane & 7) ^ ((px >> 1) & 7);          // (swizzle by patch COLUMN: see compute_step)
+    a_byte[i] = ok ? 2u * (unsigned)(((b * p.Hi + il) * p.Wi + jl) * p.C + 8 * oct) : VF_OOB;
+    a_lds[i] = (unsigned)(grp * 8 * 128);
+  }
+  // ---- and of every weight stage: row n = 8 * wave + lane / 8 of the 64
+  const int wrow = 8 * wave + (lane >> 3);
+  const unsigned w_byte = 2u * (unsigned)(wrow * 16 * p.C + 8 * ((lane & 7) ^ ((wrow >> 1) & 7)));
+  const unsigned w_lds = (unsigned)(wave * 8 * 128);
+  const __amdgpu_buffer_rsrc_t rsA = pg_rsrc(p.A, p.a_bytes), rsW = pg_rsrc(p.W, p.w_bytes);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  unsigned szero;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(szero));
+
+  auto dma_patch = [&](int ch) {
+    const unsigned cb = 128u * (unsigned)ch;
+#pragma unroll
+    for (int i = 0; i < AGW; ++i) {
+      if (wave + 8 * i < NG) {                              // (wave-uniform)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          pg_dma16(lds0 + (unsigned)(q * PATCH_PL) + a_lds[i], a_byte[i] == VF_OOB ? VF_OOB : a_byte[i] + cb, rsA, szero + q * p.a_ps);
+      }
+    }
+  };
+  // class `cls` of this block: (ph, pw); its window tap (th, tw) reads filter tap (3 - ph - 2 th, 3 - pw - 2 tw)
+  auto dma_w = [&](int ch, auto STEP, int buf) {
+    constexpr int s_ = decltype(STEP)::value, cls = s_ >> 2, th = (s_ >> 1) & 1, tw = s_ & 1;
+    const int ph = CPB == 4 ? (cls >> 1) : ph_blk, pw = CPB == 4 ? (cls & 1) : cls;
+    const int kh = 3 - ph - 2 * th, kw = 3 - pw - 2 * tw;
+    const unsigned tW = 2u * (unsigned)((kh * 4 + kw) * p.C) + 128u * (unsigned)ch;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      pg_dma16(lds0 + (unsigned)(PATCH_BYTES + buf * WBUF + q * W_PL) + w_lds, w_byte, rsW, q * p.w_ps + tW);
+  };
+
+  f32x16 acc[CPB];
+#pragma unroll
+  for (int c = 0; c < CPB; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  // this lane's A row of the class tile: (ry, rx) -> first slot of its window; B row: wn + lr.  (slot00 / b_off0 / e0 pass through an
+  // empty asm at the top of every chunk: left visible as loop invariants, the 16 unrolled steps' fragment addresses and the four
+  // epilogues' element offsets are all hoisted in front of the loop — 256 registers and a kilobyte of scratch)
+  const int arow = wm + lr;
+  int slot00 = (arow >> 4) * PW + (arow & 15);
+  const int brow = wn + lr;
+  unsigned b_off0 = (unsigned)(brow * 128);
+  const unsigned b_sw = (unsigned)((brow >> 1) & 7);
+  auto compute_step = [&](auto STEP, int buf) {
+    constexpr int s_ = decltype(STEP)::value, cls = s_ >> 2, th = (s_ >> 1) & 1, tw = s_ & 1;
+    const int ph = CPB == 4 ? (cls >> 1) : 0, pw = CPB == 4 ? (cls & 1) : cls;      // (CPB = 2: the patch origin carries ph)
+    // the 16-byte k-octets of a slot are XOR-swizzled by its patch column: a wave's 32 rows are two runs of 16 columns in adjacent patch
+    // rows, and with ((px >> 1) & 7) every 16-lane group of a ds_read_b128 covers all 64 banks once for each of the nine window
+    // offsets (by slot index, the usual choice, the 18-slot pitch makes every group two-way conflicted: measured 8 cycles per read)
+    const int slot = slot00 + (ph + th) * PW + pw + tw;
+    const unsigned a_off0 = (unsigned)(slot * 128), a_sw = (unsigned)((((arow & 15) + pw + tw) >> 1) & 7);
+    const unsigned char* wb = smem + PATCH_BYTES + buf * WBUF;
+    bf16x8 a[2][3], bb[2][3];
+    auto read_frag = [&](int g, int set) {
+      const unsigned o = (unsigned)(2 * g + lh);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[set][q] = *(const bf16x8*)(smem + q * PATCH_PL + a_off0 + ((o ^ a_sw) << 4));
+        bb[set][q] = *(const bf16x8*)(wb + q * W_PL + b_off0 + ((o ^ b_sw) << 4));
+      }
+    };
+    read_frag(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cs = g & 1;
+      if (g + 1 < 4) read_frag(g + 1, cs ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], bb[cs][1], acc[cls], 0, 0, 0);      // smallest terms first
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], bb[cs][2], acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][2], bb[cs][0], acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], bb[cs][1], acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], bb[cs][0], acc[cls], 0, 0, 0);
+      acc[cls] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], bb[cs][0], acc[cls], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- epilogue of one class (C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)): bias, (Leaky)ReLU, the
+  //      derivative mask, BatchNorm partials — pg_epilogue's arithmetic.  What it reads besides the accumulators (mask, BatchNorm
+  //      input) is fetched when the class's first step of the last chunk begins, 16 values each per lane.  Element offsets are 32-bit
+  //      (the host checks the extent) through buffer descriptors: element (row r of this lane, class (ph, pw)) =
+  //      e0 + (ph * outW + pw) * 64 + (r >> 3) * 2 * outW * 64 + ((r & 3) + 8 * ((r >> 2) & 1)) * 128
+  const int n = wn + lr;
+  const int stm = p.st.mode;
+  const bool want_d = p.dmask != nullptr, want_x = stm == 2;
+  const float bv = p.bias ? p.bias[n] : 0.f;
+  const float sv = stm ? p.st.vec[(stm == 2 ? (bx / p.st.tiles_per_group) * 64 : 0) + n] : 0.f;
+  const float neg = p.act == VF_ACT_LRELU ? p.slope : (p.act == VF_ACT_RELU ? 0.f : 1.f);
+  const float dneg = p.dact == VF_ACT_LRELU ? p.dslope : (p.dact == VF_ACT_RELU ? 0.f : 1.f);
+  const unsigned ybytes = (unsigned)(p.out_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsY = pg_rsrc(p.Y, ybytes), rsD = pg_rsrc(p.dbits ? (const void*)p.dbits : (const void*)p.dmask, p.dbits ? ybytes / 32 : ybytes),
+                               rsX = pg_rsrc(p.st.x, ybytes);
+  unsigned e0 = (unsigned)((((b * p.outH + 2 * (ry0 + 2 * (wave >> 1))) * p.outW) + 2 * (rx0 + 4 * lh)) * 64 + n);
+  const unsigned rstride = (unsigned)(2 * p.outW * 64);
+  float pre_d[16], pre_x[16];
+  auto elem = [&](int r, int ph, int pw) -> unsigned {
+    return e0 + (unsigned)((ph * p.outW + pw) * 64) + (unsigned)(r >> 3) * rstride + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * 128);
+  };
+  auto prefetch_epi = [&](int ph, int pw) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned e = elem(r, ph, pw);
+      pre_d[r] = 1.f;
+      pre_x[r] = 0.f;
+      if (want_d) {
+        // sign bits: word 2 * (n / 64) + (n & 1) of the pixel, bit (n / 2) % 32 (N = 64: two words per pixel, pixel = e / 64)
+        if (p.dbits) pre_d[r] = (float)((__builtin_amdgcn_raw_buffer_load_b32(rsD, 4u * ((e >> 6) * 2u + (unsigned)(n & 1)), 0, 0) >> ((n >> 1) & 31)) & 1u);
+        else pre_d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, 4u * e, 0, 0));
+      }
+      if (want_x) pre_x[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, 4u * e, 0, 0));
+    }
+  };
+  auto epilogue = [&](auto CLS, int ph, int pw) {
+    constexpr int cls = decltype(CLS)::value;
+    float st1[1] = {0.f}, st2[1] = {0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[cls][r] + bv;
+      v = v * (v > 0.f ? 1.f : neg);
+      if (want_d) v = v * (pre_d[r] > 0.f ? 1.f : dneg);
+      if (stm == 1) {
+        const float d = v - sv;
+        st1[0] += d;
+        st2[0] += d * d;
+      } else if (stm == 2) {
+        st1[0] += v;
+        st2[0] += v * (pre_x[r] - sv);
+      }
+      if (!(p.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, 4u * elem(r, ph, pw), 0, 0);
+    }
+    if (stm) pg_bn_tile_partials<1, 4, 64>(p.st, st1, st2, red, wave >> 1, wn, lane, tid, 0, 64, bx, (ph << 1) | pw);
+  };
+
+  // ---- main loop: channel chunk outer (the patch is restaged per chunk), (class, tap) steps inner, weights one step ahead
+  const int nch = p.nchunks;
+  dma_patch(0);
+  dma_w(0, VfIntC<0>{}, 0);
+  for (int ch = 0; ch < nch; ++ch) {
+    const bool last = ch + 1 == nch;
+    asm volatile("" : "+v"(slot00), "+v"(b_off0), "+v"(e0));
+    vf_static_for<NS>([&](auto S) {
+      constexpr int s_ = decltype(S)::value, buf = s_ & 1, cls = s_ >> 2, tap = s_ & 3;
+      const int ph = CPB == 4 ? (cls >> 1) : ph_blk, pw = CPB == 4 ? (cls & 1) : cls;
+      // this wave's DMAs (patch, this step's weights) have landed; after the barrier everybody's have, and nobody still reads the
+      // other weight stage
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 1)) {
+        if constexpr (s_ + 1 < NS) dma_w(ch, VfIntC<s_ + 1>{}, buf ^ 1);
+        else if (!last) dma_w(ch + 1, VfIntC<0>{}, buf ^ 1);
+      }
+      if (last && tap == 0 && (want_d || want_x)) prefetch_epi(ph, pw);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 4)) compute_step(S, buf);
+      if (last && tap == 3) epilogue(VfIntC<cls>{}, ph, pw);
+    });
+    if (!last) {
+      asm volatile("s_barrier" ::: "memory");            // everybody has read the patch: the next chunk's goes in
+      dma_patch(ch + 1);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradients from planes
 // dW[n][tap][c] = sum_p U[p][n] * V[p @ tap][c] (VfPWGrad, vf_common.h): a 128 (n) x 128 (tap, c) tile per block, K = pixels in
 // steps of 32.  Both operands are K-MAJOR in memory ([pixel][channel]), which is the layout gfx950's transposing LDS read
@@ -1132,6 +1347,19 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     // a grid of at least two tiles per CU runs the single-stage variant, two blocks per CU (measured, scripts/bench_pconv.py:
     // E2 transposed pass 79 -> 67 us, E2 gather 68 -> 62, E3 transposed 31.2 -> 28.8, netD's first layer at 2B 58 -> 53;
     // with one tile per CU the second stage is what is needed instead: E3 gather 29.7 vs 39.8 single-stage)
+    // transposed passes into 64 channels on grids of at least 8 x 16: the patch kernel (k_pconv_patch_tr).  VF_PG_PATCH: 0 off,
+    // 2 / 4 = that many parity classes per block, 1 (default) = 4 where that still gives two rounds of blocks, else 2
+    static const int env_patch = getenv("VF_PG_PATCH") ? atoi(getenv("VF_PG_PATCH")) : 1;
+    if (env_patch && ntaps == 4 && g.parity && g.N == 64 && ksplit == 1 && t.bm == 128 && g.Wi % 16 == 0 && g.Hi % 8 == 0 &&
+        (g.act == VF_ACT_NONE || g.act == VF_ACT_LRELU || g.act == VF_ACT_RELU)) {
+      const unsigned tiles = (unsigned)(g.M / 128);
+      const int cpb = env_patch == 2 || env_patch == 4 ? env_patch : (tiles >= 512 ? 4 : 2);
+      snprintf(dname, sizeof(dname), "pconv_patch_128x64_t4_c%d", cpb);
+      if (cpb == 4) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_tr<4>, dim3(tiles), dim3(512), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_tr<2>, dim3(2 * tiles), dim3(512), g);
+      VF_LAUNCH_CHECK();
+      return 0;
+    }
     static const int env_nbuf = getenv("VF_PG_NBUF") ? atoi(getenv("VF_PG_NBUF")) : 0;
     const bool one_stage = env_nbuf ? env_nbuf == 1 : (t.bm == 128 && nt >= 512);
     if (one_stage) snprintf(dname, sizeof(dname), "pconv_dma_%dx%dx64_%s_1stage", t.bm, t.bn, ntaps == 16 ? "t16" : "t4");
