@@ -476,6 +476,8 @@ def _fused_bn_net(kind, widths, hipb, seed):
     ("full", (512, 256, 128, 64), 16, 4, 1),       # transposed passes: four output-parity classes per row tile; split-K combine
     ("conv", (32, 48, 96), 6, 32, 1),              # channel counts that are not powers of two (C % 16 == 0 still)
     ("conv", (16, 20, 40), 3, 16, 1),              # C % 16 != 0: the scalar-gather tiles carry the same epilogue
+    ("full", (128, 64, 64), 32, 16, 1),            # transposed passes into 64 channels: the patch kernel's epilogue (forward sums)
+    ("conv", (64, 64, 64, 128), 32, 64, 2),        # ... and its backward sums + derivative mask (data-gradients into 64 channels)
 ])
 def test_batchnorm_statistics_from_the_neighbouring_gemms(kind, widths, Bn, H, groups, hipb):
     """nn.Sequential lets the convolution in front of a BatchNorm sum that BatchNorm's forward statistics in its own
@@ -512,6 +514,8 @@ def test_batchnorm_statistics_from_the_neighbouring_gemms(kind, widths, Bn, H, g
         assert fin == nb and "bn_stats" not in b["names"], b["names"].keys()
         # backward: every BatchNorm but the top one has a data-gradient pass above it
         assert bfin == nb - 1 and b["names"].get("bn_bwd_stats", {}).get("launches", 0) == 1
+    if Bn == 32:                                                # the two cases meant for k_pconv_patch_tr really ran it
+        assert any(k.startswith("pconv_patch") for k in b["names"]), b["names"].keys()
     # (other shapes may fall back — e.g. split-K with 256 % N != 0 — and must simply agree)
     for k, tol in (("y", 2e-5), ("gx", 1e-4), ("g", 1e-4), ("rm", 2e-5), ("rv", 2e-5)):
         e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-30))

@@ -969,9 +969,20 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
         st1[0] += v;
         st2[0] += v * (pre_x[r] - sv);
       }
-      if (!(p.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, 4u * elem(r, ph, pw), 0, 0);
+      acc[cls][r] = v;         // the finished value stays in the accumulator's registers: the stores leave after the last step
     }
     if (stm) pg_bn_tile_partials<1, 4, 64>(p.st, st1, st2, red, wave >> 1, wn, lane, tid, 0, 64, bx, (ph << 1) | pw);
+  };
+  // (every step begins with s_waitcnt vmcnt(0) for its DMAs, which would also wait for any store still on its way: 16 stores per lane
+  //  and class, issued between the classes, stalled the next step for the whole write latency — in the iteration, with the memory
+  //  system busy, more than in a microbenchmark)
+  auto store_class = [&](auto CLS, int ph, int pw) {
+    constexpr int cls = decltype(CLS)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[cls][r];      // (a copy: __builtin_bit_cast applied to the vector-element lvalue itself read element 0 sixteen times)
+      if (!(p.dbg & 8)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, 4u * elem(r, ph, pw), 0, 0);
+    }
   };
 
   // ---- main loop: channel chunk outer (the patch is restaged per chunk), (class, tap) steps inner, weights one step ahead
@@ -1002,6 +1013,10 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
       dma_patch(ch + 1);
     }
   }
+  vf_static_for<CPB>([&](auto C) {
+    constexpr int cls = decltype(C)::value;
+    store_class(C, CPB == 4 ? (cls >> 1) : ph_blk, CPB == 4 ? (cls & 1) : cls);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients from planes
