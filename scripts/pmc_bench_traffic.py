@@ -31,6 +31,13 @@ def bench_name(k):
         if m.group(5) == "1":
             return "pconv_dma_%sx%sx64_t%s_bf16" % (m.group(1), m.group(2), m.group(3))
         return "pconv_dma_%sx%sx64_t%s%s" % (m.group(1), m.group(2), m.group(3), "_1stage" if m.group(4) == "1" else "")
+    m = re.search(r"k_pconv_patch_tr<(\d)>", k)                                   # <parity classes per block>
+    if m:
+        return "pconv_patch_128x64_t4_c" + m.group(1)
+    if "k_adam_fused_multi" in k:      # the bottleneck pair's update as one launch (vf_internal_adam_fused_multi)
+        return "adam_fused_wgrad"
+    if "k_conv_thin_in" in k:          # (the nets' thin-input layers feed planes consumers: bench.py's name carries the suffix)
+        return "conv_thin_in_planes"
     if "k_deconv_thin_out" in k:
         return "deconv_thin_out"
     if "k_wgrad_smallk" in k:      # <NJ, FUSE>: FUSE = optim.adam in the epilogue (vf_wgrad_adam_outer)
