@@ -1296,34 +1296,46 @@ __global__ void k_dot_bwd_data(const float* __restrict__ gy, const float* __rest
     gx[i] = g * w[i % K];
   }
 }
-// gw[k] = beta*gw[k] + sum_b gy[b]*x[b][k]: a block owns 64 columns; its 4 waves take every 4th sample (coalesced
-// 256-byte rows), partials meet in LDS in a fixed order.  (One thread per column walking all B samples was a
-// 64-deep dependent load chain on 32 blocks: 19 us for 2 MB.)
-__global__ __launch_bounds__(256) void k_dot_bwd_weight(const float* __restrict__ x, const float* __restrict__ gy,
+// gw[k] = beta*gw[k] + sum_b gy[b]*x[b][k]: a block owns 64 columns; its 8 waves take every 8th sample (coalesced 256-byte rows),
+// eight samples in flight per wave, partials meet in LDS in a fixed order.  The per-sample factor (gy, times the derivative of a
+// fused activation: see k_dot_bwd_data) is formed once per block, in LDS.  (One thread per column walking all B samples was a 64-deep
+// dependent load chain on 32 blocks: 19 us for 2 MB; four waves with two sums in flight each still took 22 us at batch 128 — every
+// iteration waited for its row AND for two scalar loads in front of it.)
+__global__ __launch_bounds__(512) void k_dot_bwd_weight(const float* __restrict__ x, const float* __restrict__ gy,
                                                         float* __restrict__ gw, float* __restrict__ gb, int B, int K,
                                                         float beta, const float* __restrict__ ya, int act, float slope) {
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f;
-  auto G = [&](int b) { return ya ? vf_act_grad(ya[b], gy[b], act, slope) : gy[b]; };      // (see k_dot_bwd_data)
-  if (k < K) {
-    int b = grp;
-    for (; b + 4 < B; b += 8) {
-      s0 += G(b) * x[(int64_t)b * K + k];
-      s1 += G(b + 4) * x[(int64_t)(b + 4) * K + k];
+  __shared__ float g[1024];
+  __shared__ float red[8][64];
+  float acc = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 1024) {                 // (B <= 1024 in every net: one pass)
+    const int nb = min(1024, B - b0);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 512) g[b] = ya ? vf_act_grad(ya[b0 + b], gy[b0 + b], act, slope) : gy[b0 + b];
+    __syncthreads();
+    if (k < K) {
+      const float* xp = x + (int64_t)b0 * K + k;
+      int b = grp;
+      for (; b + 56 < nb; b += 64) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = xp[(int64_t)(b + 8 * j) * K];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += g[b + 8 * j] * v[j];
+      }
+      for (; b < nb; b += 8) acc += g[b] * xp[(int64_t)b * K];
     }
-    for (; b < B; b += 4) s0 += G(b) * x[(int64_t)b * K + k];
   }
-  __shared__ float red[4][64];
-  red[grp][lane] = s0 + s1;
+  red[grp][lane] = acc;
   __syncthreads();
   if (grp == 0 && k < K) {
-    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const float t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) + ((red[4][lane] + red[5][lane]) + (red[6][lane] + red[7][lane]));
     gw[k] = (beta != 0.f ? beta * gw[k] : 0.f) + t;
   }
   if (gb && blockIdx.x == 0 && threadIdx.x == 0) {
     float t = 0.f;
-    for (int b = 0; b < B; ++b) t += G(b);
+    for (int b = 0; b < B; ++b) t += ya ? vf_act_grad(ya[b], gy[b], act, slope) : gy[b];
     gb[0] = (beta != 0.f ? beta * gb[0] : 0.f) + t;
   }
 }
@@ -2207,7 +2219,7 @@ static int conv2d_bwd_weight_impl(vf_ctx* ctx, const float* x, const float* gy, 
   if (Cout == 1 && stride == 1 && H == 4 && W == 4) {
     const float* ya = ctx->dot_act_y;      // (see vf_conv2d_bwd_data)
     ctx->dot_act_y = nullptr;
-    hipLaunchKernelGGL(k_dot_bwd_weight, dim3((int)vf_cdiv(16 * Cin, 64)), dim3(256), 0, ctx->stream, x, gy, gw, gb, B,
+    hipLaunchKernelGGL(k_dot_bwd_weight, dim3((int)vf_cdiv(16 * Cin, 64)), dim3(512), 0, ctx->stream, x, gy, gw, gb, B,
                        16 * Cin, beta, ya, ctx->dot_act, ctx->dot_act_slope);
     VF_LAUNCH_CHECK();
     return 0;
