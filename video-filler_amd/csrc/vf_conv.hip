@@ -2015,7 +2015,16 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   const int64_t blocks = (int64_t)gx * gy;
   const int64_t total = (int64_t)Nu * ntaps * Cv;
   int ksplit = 1;
-  static const int tune_wg_blocks = getenv("VF_WGRAD_BLOCKS") ? atoi(getenv("VF_WGRAD_BLOCKS")) : 512;
+  // operands that arrive as planes (vf_*_bwd_weight_planes): the LDS-DMA kernel of vf_pgemm.hip, whole 128 x 128 x 32 tiles only
+  const bool use_pw = Up && Vp && (ctx->mfma_bf16 == 3 || ctx->mfma_bf16 == 1) && ntaps == 16 && stride == 2 && pad == 1 && Nu % 128 == 0 &&
+                      Cv % 64 == 0 && g.P % 32 == 0 && (int64_t)g.P * Nu * 6 < ((int64_t)1 << 31) &&
+                      (int64_t)B * Hv * Wv * Cv * 6 < ((int64_t)1 << 31) && total % 4 == 0;
+  // split-K target, blocks per layer.  The planes layers ride in ONE group launch of seven or more layers, which fills the chip as
+  // a whole: half the splits per layer leave k_pwgrad_group's time where it was and halve the slabs it writes and the combine
+  // reads (same-box: combine 2 x 37.4 -> 2 x 21.8 us); the fp32-fed thin layers' kernel wants the full 512 (62 -> 86 us at 256)
+  static const int env_wg_blocks = getenv("VF_WGRAD_BLOCKS") ? atoi(getenv("VF_WGRAD_BLOCKS")) : 0;
+  static const int env_pwg_blocks = getenv("VF_PWGRAD_BLOCKS") ? atoi(getenv("VF_PWGRAD_BLOCKS")) : 0;
+  const int tune_wg_blocks = use_pw ? (env_pwg_blocks ? env_pwg_blocks : (env_wg_blocks ? env_wg_blocks : 256)) : (env_wg_blocks ? env_wg_blocks : 512);
   if (blocks < tune_wg_blocks * 3 / 4 && g.nk >= 16) {
     ksplit = (int)std::min<int64_t>(g.nk / 8, vf_cdiv(tune_wg_blocks, blocks));
     while (ksplit > 1 && (size_t)ksplit * total * sizeof(float) > vf_ws_avail(ctx)) --ksplit;
@@ -2027,10 +2036,6 @@ static int wgrad(vf_ctx* ctx, const float* U, const float* V, float* dW, int B, 
   g.slab = ksplit > 1 ? (float*)vf_ws_ptr(ctx) : nullptr;
   g.gx = gx; g.gy = gy; g.gz = ksplit;
   dim3 grid((unsigned)gx * gy * ksplit), block(256);
-  // operands that arrive as planes (vf_*_bwd_weight_planes): the LDS-DMA kernel of vf_pgemm.hip, whole 128 x 128 x 32 tiles only
-  const bool use_pw = Up && Vp && (ctx->mfma_bf16 == 3 || ctx->mfma_bf16 == 1) && ntaps == 16 && stride == 2 && pad == 1 && Nu % 128 == 0 &&
-                      Cv % 64 == 0 && g.P % 32 == 0 && (int64_t)g.P * Nu * 6 < ((int64_t)1 << 31) &&
-                      (int64_t)B * Hv * Wv * Cv * 6 < ((int64_t)1 << 31) && total % 4 == 0;
   const bool own_group = use_pw && !ctx->wg_active;      // a planes layer outside a group: a group of one, launched at once
   if (own_group) {
     if (!ctx->wg_rec) ctx->wg_rec = new WgRecorder();

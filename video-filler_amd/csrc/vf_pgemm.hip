@@ -1366,7 +1366,8 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     // 2 / 4 = that many parity classes per block, 1 (default) = 4 where that still gives two rounds of blocks, else 2
     static const int env_patch = getenv("VF_PG_PATCH") ? atoi(getenv("VF_PG_PATCH")) : 1;
     if (env_patch && ntaps == 4 && g.parity && g.N == 64 && ksplit == 1 && t.bm == 128 && g.Wi % 16 == 0 && g.Hi % 8 == 0 &&
-        (g.act == VF_ACT_NONE || g.act == VF_ACT_LRELU || g.act == VF_ACT_RELU)) {
+        (g.act == VF_ACT_NONE || g.act == VF_ACT_LRELU || g.act == VF_ACT_RELU) &&
+        g.out_elems * 4 < ((int64_t)1 << 31)) {       // (its epilogue addresses the output through 32-bit buffer offsets)
       const unsigned tiles = (unsigned)(g.M / 128);
       const int cpb = env_patch == 2 || env_patch == 4 ? env_patch : (tiles >= 512 ? 4 : 2);
       snprintf(dname, sizeof(dname), "pconv_patch_128x64_t4_c%d", cpb);
