@@ -478,6 +478,7 @@ def _fused_bn_net(kind, widths, hipb, seed):
     ("conv", (16, 20, 40), 3, 16, 1),              # C % 16 != 0: the scalar-gather tiles carry the same epilogue
     ("full", (128, 64, 64), 32, 16, 1),            # transposed passes into 64 channels: the patch kernel's epilogue (forward sums)
     ("conv", (64, 64, 64, 128), 32, 64, 2),        # ... and its backward sums + derivative mask (data-gradients into 64 channels)
+    ("conv", (128, 128, 128), 32, 64, 1),          # ... into 128 channels (two column slices per patch tile)
 ])
 def test_batchnorm_statistics_from_the_neighbouring_gemms(kind, widths, Bn, H, groups, hipb):
     """nn.Sequential lets the convolution in front of a BatchNorm sum that BatchNorm's forward statistics in its own
@@ -514,7 +515,7 @@ def test_batchnorm_statistics_from_the_neighbouring_gemms(kind, widths, Bn, H, g
         assert fin == nb and "bn_stats" not in b["names"], b["names"].keys()
         # backward: every BatchNorm but the top one has a data-gradient pass above it
         assert bfin == nb - 1 and b["names"].get("bn_bwd_stats", {}).get("launches", 0) == 1
-    if Bn == 32:                                                # the two cases meant for k_pconv_patch_tr really ran it
+    if Bn == 32:                                                # the cases meant for k_pconv_patch_tr really ran it
         assert any(k.startswith("pconv_patch") for k in b["names"]), b["names"].keys()
     # (other shapes may fall back — e.g. split-K with 256 % N != 0 — and must simply agree)
     for k, tol in (("y", 2e-5), ("gx", 1e-4), ("g", 1e-4), ("rm", 2e-5), ("rv", 2e-5)):

@@ -42,7 +42,8 @@ def test_weight_planes_native_and_transposed(hipb):
 
 CASES = [(8, 64, 64, 64), (8, 64, 32, 128), (16, 128, 16, 256), (16, 256, 8, 512), (4, 192, 32, 384), (6, 32, 32, 96),
          (64, 64, 32, 128), (3, 96, 16, 36),
-         (16, 64, 128, 64), (64, 64, 64, 128)]      # scatter: >= 512 row tiles into 64 channels — four parity classes per patch block
+         (16, 64, 128, 64), (64, 64, 64, 128),      # scatter: >= 512 row tiles into 64 channels — four parity classes per patch block
+         (32, 128, 32, 64), (64, 128, 16, 256)]     # scatter: 16 x 16 grid into 128 channels (two column slices per patch tile); 8 x 8 grid
 
 
 @pytest.mark.parametrize("Bn,Cin,H,Cout", CASES, ids=lambda v: str(v))

@@ -799,8 +799,11 @@ __global__ __launch_bounds__((BM / 32) * (BN / 32) * 64) void k_pconv_dma(const 
 // ([3 planes][PR x 18 slots][64 ch], 62-69 KB), every (class, tap) A fragment is a ds_read_b128 from that patch at a per-lane slot
 // (row (ry, rx) of the tile, tap (th, tw) of class (ph, pw): slot (ry + ph + th) * 18 + rx + pw + tw), and only the weights stream
 // through two 24 KB stages, one (class, tap) step of 24 MFMAs per wave each.  Per 512 outputs x 64 channels of K: 69 + 393 KB instead
-// of 4 x 288.  N = 64 exactly, C % 64 == 0, Wi % 16 == 0, Hi % 8 == 0, no split-K; 8 waves of one 32 x 32 accumulator per class.
+// of 4 x 288.  N % 64 == 0 (a block serves one 64-column slice), C % 64 == 0, no split-K; 8 waves of one 32 x 32 accumulator per class.
 // CPB = 2: the block's classes share ph (its patch has 9 rows); twice the blocks — for the grids that would otherwise leave CUs idle.
+// Grids with Wi % 16 == 0, Hi % 8 == 0.  (Tried and removed: 8 x 8 grids as blocks of two whole images with 10-column patches, which
+// would have taken the 256-channel layers as well — four channel chunks per block, the patch restaged for each: 4 x 47.0 us against
+// 3 x 36.5 + 60.9 us for k_pconv_dma on the same four launches of configs[1].)
 template <int CPB>
 __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
   constexpr int PR = CPB == 4 ? 10 : 9, PW = 18, NSLOT = PR * PW, NG = (NSLOT + 7) / 8;      // patch slots, 8-slot DMA groups
@@ -816,6 +819,8 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int lr = lane & 31, lh = lane >> 5;
   int lid = pg_xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = 64 * (lid % p.gn);                         // this block's column slice (neighbours in the grid share the patch's lines)
+  lid /= p.gn;
   int ph_blk = 0;
   if constexpr (CPB == 2) {
     ph_blk = lid & 1;
@@ -825,6 +830,11 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
   const int tx = lid % tiles_x, ty = (lid / tiles_x) % tiles_y, b = lid / (tiles_x * tiles_y);
   const int ry0 = 8 * ty, rx0 = 16 * tx;
   const int bx = lid;                                       // row-tile index (batch-major): the statistics' partial row
+  // the 16-byte k-octets of a patch slot are XOR-swizzled by its patch COLUMN: a wave's 32 rows are two runs of 16 columns in adjacent
+  // patch rows, and with (px >> 1) & 7 every 16-lane group of a ds_read_b128 covers all 64 banks once for each of the nine window
+  // offsets (checked exhaustively against MI355X_MICROARCH.md's lane groups; by slot index, the usual choice, the 18-slot pitch makes
+  // every group two-way conflicted: 8 cycles per read)
+  auto patch_sw = [](int px) { return (px >> 1) & 7; };
 
   // ---- this lane's share of the patch: slot 8 * group + lane / 8, LDS octet lane % 8 = global octet ^ swizzle(slot's column)
   unsigned a_byte[AGW], a_lds[AGW];
@@ -835,13 +845,13 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
     const int py = sl / PW, px = sl - py * PW;
     const int il = ry0 - 1 + (CPB == 2 ? ph_blk : 0) + py, jl = rx0 - 1 + px;
     const bool ok = grp < NG && sl < NSLOT && (unsigned)il < (unsigned)p.Hi && (unsigned)jl < (unsigned)p.Wi;
-    const int oct = (lane & 7) ^ ((px >> 1) & 7);          // (swizzle by patch COLUMN: see compute_step)
+    const int oct = (lane & 7) ^ patch_sw(px);
     a_byte[i] = ok ? 2u * (unsigned)(((b * p.Hi + il) * p.Wi + jl) * p.C + 8 * oct) : VF_OOB;
     a_lds[i] = (unsigned)(grp * 8 * 128);
   }
   // ---- and of every weight stage: row n = 8 * wave + lane / 8 of the 64
   const int wrow = 8 * wave + (lane >> 3);
-  const unsigned w_byte = 2u * (unsigned)(wrow * 16 * p.C + 8 * ((lane & 7) ^ ((wrow >> 1) & 7)));
+  const unsigned w_byte = 2u * (unsigned)((n0 + wrow) * 16 * p.C + 8 * ((lane & 7) ^ ((wrow >> 1) & 7)));
   const unsigned w_lds = (unsigned)(wave * 8 * 128);
   const __amdgpu_buffer_rsrc_t rsA = pg_rsrc(p.A, p.a_bytes), rsW = pg_rsrc(p.W, p.w_bytes);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
@@ -876,22 +886,20 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  // this lane's A row of the class tile: (ry, rx) -> first slot of its window; B row: wn + lr.  (slot00 / b_off0 / e0 pass through an
+  // this lane's A row of the class tile: (ry, rx) -> first slot of its window; B row: wn + lr.  (slot00 / b_off0 / pix0 pass through an
   // empty asm at the top of every chunk: left visible as loop invariants, the 16 unrolled steps' fragment addresses and the four
   // epilogues' element offsets are all hoisted in front of the loop — 256 registers and a kilobyte of scratch)
   const int arow = wm + lr;
-  int slot00 = (arow >> 4) * PW + (arow & 15);
+  const int apy = arow >> 4, apx = arow & 15;              // tile row -> (ry, rx)
+  int slot00 = apy * PW + apx;
   const int brow = wn + lr;
   unsigned b_off0 = (unsigned)(brow * 128);
   const unsigned b_sw = (unsigned)((brow >> 1) & 7);
   auto compute_step = [&](auto STEP, int buf) {
     constexpr int s_ = decltype(STEP)::value, cls = s_ >> 2, th = (s_ >> 1) & 1, tw = s_ & 1;
     const int ph = CPB == 4 ? (cls >> 1) : 0, pw = CPB == 4 ? (cls & 1) : cls;      // (CPB = 2: the patch origin carries ph)
-    // the 16-byte k-octets of a slot are XOR-swizzled by its patch column: a wave's 32 rows are two runs of 16 columns in adjacent patch
-    // rows, and with ((px >> 1) & 7) every 16-lane group of a ds_read_b128 covers all 64 banks once for each of the nine window
-    // offsets (by slot index, the usual choice, the 18-slot pitch makes every group two-way conflicted: measured 8 cycles per read)
     const int slot = slot00 + (ph + th) * PW + pw + tw;
-    const unsigned a_off0 = (unsigned)(slot * 128), a_sw = (unsigned)((((arow & 15) + pw + tw) >> 1) & 7);
+    const unsigned a_off0 = (unsigned)(slot * 128), a_sw = (unsigned)patch_sw(apx + pw + tw);
     const unsigned char* wb = smem + PATCH_BYTES + buf * WBUF;
     bf16x8 a[2][3], bb[2][3];
     auto read_frag = [&](int g, int set) {
@@ -920,34 +928,37 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
 
   // ---- epilogue of one class (C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)): bias, (Leaky)ReLU, the
   //      derivative mask, BatchNorm partials — pg_epilogue's arithmetic.  What it reads besides the accumulators (mask, BatchNorm
-  //      input) is fetched when the class's first step of the last chunk begins, 16 values each per lane.  Element offsets are 32-bit
-  //      (the host checks the extent) through buffer descriptors: element (row r of this lane, class (ph, pw)) =
-  //      e0 + (ph * outW + pw) * 64 + (r >> 3) * 2 * outW * 64 + ((r & 3) + 8 * ((r >> 2) & 1)) * 128
-  const int n = wn + lr;
+  //      input) is fetched when the class's first step of the last chunk begins, 16 values each per lane.
+  const int n = wn + lr;                // column inside the block's slice; n0 + n in the tensor
+  const int N = p.N;
   const int stm = p.st.mode;
   const bool want_d = p.dmask != nullptr, want_x = stm == 2;
-  const float bv = p.bias ? p.bias[n] : 0.f;
-  const float sv = stm ? p.st.vec[(stm == 2 ? (bx / p.st.tiles_per_group) * 64 : 0) + n] : 0.f;
+  const float bv = p.bias ? p.bias[n0 + n] : 0.f;
+  const float sv = stm ? p.st.vec[(stm == 2 ? (bx / p.st.tiles_per_group) * N : 0) + n0 + n] : 0.f;
   const float neg = p.act == VF_ACT_LRELU ? p.slope : (p.act == VF_ACT_RELU ? 0.f : 1.f);
   const float dneg = p.dact == VF_ACT_LRELU ? p.dslope : (p.dact == VF_ACT_RELU ? 0.f : 1.f);
   const unsigned ybytes = (unsigned)(p.out_elems * 4);
   const __amdgpu_buffer_rsrc_t rsY = pg_rsrc(p.Y, ybytes), rsD = pg_rsrc(p.dbits ? (const void*)p.dbits : (const void*)p.dmask, p.dbits ? ybytes / 32 : ybytes),
                                rsX = pg_rsrc(p.st.x, ybytes);
-  unsigned e0 = (unsigned)((((b * p.outH + 2 * (ry0 + 2 * (wave >> 1))) * p.outW) + 2 * (rx0 + 4 * lh)) * 64 + n);
-  const unsigned rstride = (unsigned)(2 * p.outW * 64);
+  // output pixel of (row r of this lane, class (ph, pw)), 32-bit (the host checks the extent): row = wm + (r & 3) + 4 lh + 8 (r >> 2),
+  // (oy, ox) = (2 (ry0 + row / 16) + ph, 2 (rx0 + row % 16) + pw) = pix0 + (ph outW + pw) + (r >> 3) 2 outW + 2 ((r & 3) + 8 ((r >> 2) & 1))
+  unsigned pix0 = (unsigned)(((b * p.outH + 2 * (ry0 + 2 * (wave >> 1))) * p.outW) + 2 * (rx0 + 4 * lh));
+  const unsigned ostride = (unsigned)(2 * p.outW);
   float pre_d[16], pre_x[16];
-  auto elem = [&](int r, int ph, int pw) -> unsigned {
-    return e0 + (unsigned)((ph * p.outW + pw) * 64) + (unsigned)(r >> 3) * rstride + (unsigned)(((r & 3) + 8 * ((r >> 2) & 1)) * 128);
+  auto pixel = [&](int r, int ph, int pw) -> unsigned {
+    return pix0 + (unsigned)(ph * p.outW + pw) + (unsigned)(r >> 3) * ostride + (unsigned)(2 * ((r & 3) + 8 * ((r >> 2) & 1)));
   };
+  auto elem = [&](int r, int ph, int pw) -> unsigned { return pixel(r, ph, pw) * (unsigned)N + (unsigned)(n0 + n); };
   auto prefetch_epi = [&](int ph, int pw) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const unsigned e = elem(r, ph, pw);
+      const unsigned px_ = pixel(r, ph, pw), e = px_ * (unsigned)N + (unsigned)(n0 + n);
       pre_d[r] = 1.f;
       pre_x[r] = 0.f;
       if (want_d) {
-        // sign bits: word 2 * (n / 64) + (n & 1) of the pixel, bit (n / 2) % 32 (N = 64: two words per pixel, pixel = e / 64)
-        if (p.dbits) pre_d[r] = (float)((__builtin_amdgcn_raw_buffer_load_b32(rsD, 4u * ((e >> 6) * 2u + (unsigned)(n & 1)), 0, 0) >> ((n >> 1) & 31)) & 1u);
+        // sign bits: word 2 * (column / 64) + (column & 1) of the pixel's N / 32 words, bit (column / 2) % 32
+        if (p.dbits)
+          pre_d[r] = (float)((__builtin_amdgcn_raw_buffer_load_b32(rsD, 4u * (px_ * (unsigned)(N >> 5) + (unsigned)(2 * (n0 >> 6) + (n & 1))), 0, 0) >> ((n >> 1) & 31)) & 1u);
         else pre_d[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, 4u * e, 0, 0));
       }
       if (want_x) pre_x[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, 4u * e, 0, 0));
@@ -971,7 +982,7 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
       }
       acc[cls][r] = v;         // the finished value stays in the accumulator's registers: the stores leave after the last step
     }
-    if (stm) pg_bn_tile_partials<1, 4, 64>(p.st, st1, st2, red, wave >> 1, wn, lane, tid, 0, 64, bx, (ph << 1) | pw);
+    if (stm) pg_bn_tile_partials<1, 4, 64>(p.st, st1, st2, red, wave >> 1, wn, lane, tid, n0, N, bx, (ph << 1) | pw);
   };
   // (every step begins with s_waitcnt vmcnt(0) for its DMAs, which would also wait for any store still on its way: 16 stores per lane
   //  and class, issued between the classes, stalled the next step for the whole write latency — in the iteration, with the memory
@@ -991,7 +1002,7 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
   dma_w(0, VfIntC<0>{}, 0);
   for (int ch = 0; ch < nch; ++ch) {
     const bool last = ch + 1 == nch;
-    asm volatile("" : "+v"(slot00), "+v"(b_off0), "+v"(e0));
+    asm volatile("" : "+v"(slot00), "+v"(b_off0), "+v"(pix0));
     vf_static_for<NS>([&](auto S) {
       constexpr int s_ = decltype(S)::value, buf = s_ & 1, cls = s_ >> 2, tap = s_ & 3;
       const int ph = CPB == 4 ? (cls >> 1) : ph_blk, pw = CPB == 4 ? (cls & 1) : cls;
@@ -1362,17 +1373,18 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     // a grid of at least two tiles per CU runs the single-stage variant, two blocks per CU (measured, scripts/bench_pconv.py:
     // E2 transposed pass 79 -> 67 us, E2 gather 68 -> 62, E3 transposed 31.2 -> 28.8, netD's first layer at 2B 58 -> 53;
     // with one tile per CU the second stage is what is needed instead: E3 gather 29.7 vs 39.8 single-stage)
-    // transposed passes into 64 channels on grids of at least 8 x 16: the patch kernel (k_pconv_patch_tr).  VF_PG_PATCH: 0 off,
-    // 2 / 4 = that many parity classes per block, 1 (default) = 4 where that still gives two rounds of blocks, else 2
+    // transposed passes on grids of at least 8 x 16: the patch kernel (k_pconv_patch_tr).  VF_PG_PATCH: 0 off, 2 / 4 = that many parity
+    // classes per block, 1 (default) = 4 where that still gives two rounds of blocks, else 2
     static const int env_patch = getenv("VF_PG_PATCH") ? atoi(getenv("VF_PG_PATCH")) : 1;
-    if (env_patch && ntaps == 4 && g.parity && g.N == 64 && ksplit == 1 && t.bm == 128 && g.Wi % 16 == 0 && g.Hi % 8 == 0 &&
+    if (env_patch && ntaps == 4 && g.parity && g.N % 64 == 0 && ksplit == 1 && t.bm == 128 && g.Wi % 16 == 0 && g.Hi % 8 == 0 &&
         (g.act == VF_ACT_NONE || g.act == VF_ACT_LRELU || g.act == VF_ACT_RELU) &&
         g.out_elems * 4 < ((int64_t)1 << 31)) {       // (its epilogue addresses the output through 32-bit buffer offsets)
-      const unsigned tiles = (unsigned)(g.M / 128);
-      const int cpb = env_patch == 2 || env_patch == 4 ? env_patch : (tiles >= 512 ? 4 : 2);
+      const unsigned tiles = (unsigned)(g.M / 128), slices = (unsigned)(g.N / 64);
+      const int cpb = env_patch == 2 || env_patch == 4 ? env_patch : (tiles * slices >= 512 ? 4 : 2);
       snprintf(dname, sizeof(dname), "pconv_patch_128x64_t4_c%d", cpb);
-      if (cpb == 4) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_tr<4>, dim3(tiles), dim3(512), g);
-      else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_tr<2>, dim3(2 * tiles), dim3(512), g);
+      const dim3 pgrid(tiles * slices * (cpb == 2 ? 2u : 1u));
+      if (cpb == 4) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_tr<4>, pgrid, dim3(512), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_tr<2>, pgrid, dim3(512), g);
       VF_LAUNCH_CHECK();
       return 0;
     }
