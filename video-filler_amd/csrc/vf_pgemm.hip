@@ -228,7 +228,7 @@ struct PGemm {
   int dact;
   float dslope;
   int dbg;               // timing experiments only (VF_PG_DBG; wrong results): 1 = no operand loads after the first step,
-                         // 2 = no LDS writes after the first step, 4 = no MFMAs
+                         // 2 = no LDS writes after the first step, 4 = no MFMAs, 8 = no output stores (k_pconv_patch_tr)
   VfBnSt st;
 };
 
