@@ -7,10 +7,14 @@ share the CU.  Wait states before or after the instruction do not help; the same
 (`op_sel:[1,0,0]`), or split into two v_fma_f32, never failed (0 of 27 process-runs against 31 of 42).  The compiler picks the form
 by itself (SLP-vectorised fmaf chains with a broadcast operand), so the check runs on the binaries, not the sources.
 
-Flags every packed FP32 arithmetic instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose op_sel selects the high dword
-of src1 or src2 for the low result.  src0 selection ([1,0,0]) is the form the shipped kernels use and is not flagged.
+Which form the compiler emits depends on register allocation (the form came back once from an unrelated refactoring), so since the
+end of round 4 the library is built with `-Xclang -target-feature -Xclang -packed-fp32-ops` (video-filler_amd/build.py) and holds NO
+packed FP32 arithmetic at all.  The check mirrors that intent: by default it flags EVERY v_pk_fma_f32 / v_pk_mul_f32 /
+v_pk_add_f32 — if the feature flag were ever dropped silently, the harmless src0-select form would reappear first and the check
+fails on it — and reports separately (`scan(...)[0]`) the instructions of the dangerous form, the LOW result selecting the HIGH dword
+of src1 or src2.
 
-    python scripts/check_pk_opsel.py [library.so ...]        exit status 1 when anything is flagged
+    python scripts/check_pk_opsel.py [--opsel-only] [library.so ...]        exit status 1 when anything is flagged
 """
 import os
 import re
@@ -22,6 +26,7 @@ import tempfile
 LLVM = os.environ.get("VF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PK = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\b.*?\bop_sel:\[([01](?:,[01])*)\]")
+PK_ANY = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b")
 
 
 def code_objects(so, workdir):
@@ -33,8 +38,9 @@ def code_objects(so, workdir):
     return sorted(os.path.join(workdir, f) for f in os.listdir(workdir) if "amdgcn" in f)
 
 
-def scan(so):
-    """[(kernel symbol, instruction text)] for every flagged instruction; also the number of kernels seen."""
+def scan(so, any_packed=None):
+    """[(kernel symbol, instruction text)] for every instruction of the dangerous form; also the number of kernels seen.  With a
+    list in `any_packed`, every packed FP32 arithmetic instruction (whatever its op_sel) is appended to it as well."""
     flagged, kernels = [], set()
     with tempfile.TemporaryDirectory() as wd:
         for co in code_objects(so, wd):
@@ -48,6 +54,8 @@ def scan(so):
                     if not sym.startswith("L") and "$local" not in sym:
                         kernels.add(sym)
                     continue
+                if any_packed is not None and PK_ANY.search(line):
+                    any_packed.append((sym, line.split("//")[0].strip()))
                 m = PK.search(line)
                 if m:
                     sel = [int(b) for b in m.group(2).split(",")]
@@ -57,11 +65,16 @@ def scan(so):
 
 
 def main(argv):
-    libs = argv or [os.path.join(ROOT, "video-filler_amd", "lib", "libvf_hip.so")]
+    opsel_only = "--opsel-only" in argv
+    libs = [a for a in argv if not a.startswith("--")] or [os.path.join(ROOT, "video-filler_amd", "lib", "libvf_hip.so")]
     bad = 0
     for so in libs:
-        flagged, n = scan(so)
-        print("%s: %d kernels, %d flagged instructions" % (os.path.relpath(so, ROOT), n, len(flagged)))
+        packed = []
+        flagged, n = scan(so, packed)
+        print("%s: %d kernels, %d packed FP32 arithmetic instructions, %d of them with a high-dword src1 / src2 select"
+              % (os.path.relpath(so, ROOT), n, len(packed), len(flagged)))
+        if not opsel_only:
+            flagged = packed
         per = {}
         for sym, ins in flagged:
             per.setdefault(sym, []).append(ins)

@@ -134,14 +134,19 @@ def test_shipped_code_objects_hold_no_packed_fma_with_a_high_dword_src1_select()
     """scripts/check_pk_opsel.py over the built library: `v_pk_fma_f32 ... op_sel:[0,1,0]` (and its mul / add / src2 relatives) gives
     wrong low results in lanes 48-63 on gfx950 when other processes share the CU — the cause of round 3's run-to-run differences
     (DESIGN.md 4.9).  The compiler chooses the form by itself, so the guard is on the binary: a kernel that acquires it after a
-    source change fails HERE, before it reaches a GPU."""
+    source change fails HERE, before it reaches a GPU.  Since the library is built without packed FP32 ops altogether
+    (build.py: -packed-fp32-ops), the guard asserts exactly that: NO v_pk_{fma,mul,add}_f32 of any form — a silently dropped feature
+    flag would bring the harmless src0-select form back first, and must fail here too."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("check_pk_opsel", os.path.join(ROOT, "scripts", "check_pk_opsel.py"))
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
-    flagged, kernels = chk.scan(os.path.join(ROOT, "video-filler_amd", "lib", "libvf_hip.so"))
+    packed = []
+    flagged, kernels = chk.scan(os.path.join(ROOT, "video-filler_amd", "lib", "libvf_hip.so"), packed)
     assert kernels >= 150, "the scan did not find the library's kernels (%d)" % kernels
     assert not flagged, "packed FP32 instructions selecting the high dword of src1/src2: %s" % flagged[:5]
+    assert not packed, "the library is built with -packed-fp32-ops and must hold no packed FP32 arithmetic: %s" % packed[:5]
+    assert chk.PK_ANY.search("v_pk_mul_f32 v[0:1], v[2:3], s[8:9]") and not chk.PK_ANY.search("v_pk_add_f16 v0, v1, v2")
     # the detector itself: the instruction text of the round-3 kernel is flagged, the shipped form is not
     assert chk.PK.search("v_pk_fma_f32 v[12:13], v[22:23], v[18:19], v[12:13] op_sel:[0,1,0]")
     m = chk.PK.search("v_pk_fma_f32 v[4:5], v[26:27], v[6:7], v[4:5] op_sel:[1,0,0]")

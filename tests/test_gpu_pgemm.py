@@ -262,6 +262,51 @@ def test_planes_full_conv_passes_against_the_oracle(Bn, Cin, H, Cout, oracle, hi
     assert _err(gb, ref.gradBias) <= 2e-5
 
 
+#  which kernel a transposed pass lands on is a tiling decision of launch_pconv (vf_pgemm.hip): the patch kernel
+# with four parity classes per block from 512 (row tile x column slice) blocks, with two below.  The ORACLE_CASES above reach only the
+# two-class form and do not say so; here every case names the symbol it is meant for and the launch list is asserted.
+PATCH_ORACLE_CASES = [
+    (64, 64, 64, 64, "pconv_patch_128x64_t4_c4"),      # E2's data-gradient at batchSize 64 (train.lua:92): 512 row tiles x 1 slice
+    (32, 128, 64, 64, "pconv_patch_128x64_t4_c4"),     # into N = 128 channels: 256 row tiles x 2 column slices
+    (16, 64, 64, 64, "pconv_patch_128x64_t4_c2"),      # 128 row tiles: two classes per block
+    (8, 128, 32, 64, "pconv_patch_128x64_t4_c2"),      # N = 128 on a 16 x 16 low-res grid
+]
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout,symbol", PATCH_ORACLE_CASES, ids=lambda v: str(v))
+def test_patch_fed_transposed_passes_against_the_oracle(Bn, Cin, H, Cout, symbol, oracle, hipb):
+    """k_pconv_patch_tr<4> / <2> directly against oracle.SpatialConvolution.updateGradInput (THNN SpatialConvolutionMM's
+    data-gradient, train.lua:92 for the first case) — plain, and with the LeakyReLU derivative mask of the layer below in the
+    epilogue — asserting through vf_prof_begin / _end that the named symbol is what served the pass."""
+    dev = hipb.device
+    rng = np.random.default_rng(Bn * 1000 + Cin + Cout + 7)
+    Hl = H // 2
+    oracle.set_num_threads(16)
+    try:
+        ref = oracle.SpatialConvolution(Cin, Cout, 4, 4, 2, 2, 1, 1)
+        ref.weight[...] = rng.standard_normal(ref.weight.shape).astype(np.float32) * 0.05
+        gy = rng.standard_normal((Bn, Cout, Hl, Hl)).astype(np.float32)
+        x = rng.standard_normal((Bn, Cin, H, H)).astype(np.float32)      # updateGradInput reads it for its shape only (SURVEY A.1)
+        want = ref.updateGradInput(x, gy).copy()
+    finally:
+        oracle.set_num_threads(1)
+    dw, dgy, dx = _to_dev(ref.weight, dev), _to_dev(gy, dev), _to_dev(x, dev)
+    gp = hipb.planes_split(dgy)
+    _, wt = hipb.weight_planes(dw)
+    got = hipb.empty_act(Bn, Cin, H, H)
+    hipb.prof_begin()
+    hipb.pconv_scatter(gp, wt, None, got, Bn, Hl, Hl, Cout, Cin)
+    names = hipb.prof_end()
+    assert symbol in names, (symbol, list(names))
+    assert _err(got, want) <= 2e-5
+    # the derivative mask of the LeakyReLU whose output is this conv's input (conv -> LeakyReLU -> this conv): dx *= (x > 0 ? 1 : 0.2)
+    hipb.prof_begin()
+    hipb.pconv_scatter(gp, wt, None, got, Bn, Hl, Hl, Cout, Cin, dmask=dx, dact="lrelu", dslope=0.2)
+    names = hipb.prof_end()
+    assert symbol in names, (symbol, list(names))
+    assert _err(got, want * np.where(x > 0, 1.0, 0.2)) <= 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ producer-written planes
 def _same_planes(a, b):
     return torch.equal(a.view(torch.int16), b.view(torch.int16))

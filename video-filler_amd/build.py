@@ -10,8 +10,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # dword of src1 for the low result) gives wrong results on gfx950 when other processes share the CU, and which form
 # the compiler picks depends on register allocation (round 4: a refactoring of the fused Adam epilogue brought it back at once).
 # Same-box A/B of the whole library with and without the packed forms: configs[1] +0.3 %, configs[2] / [4] within noise — they issue
-# at half rate on this part and every kernel that used them is memory-bound.  scripts/check_pk_opsel.py stays as the guard on the
-# binary.  (The host half of each compile prints "not a recognized feature for this target": the flag is the device's.)
+# at half rate on this part and every kernel that used them is memory-bound.  scripts/check_pk_opsel.py is the guard on the binary:
+# it fails on ANY packed FP32 arithmetic, so a silently dropped flag cannot pass.  The flag cannot be scoped to the device pass
+# (`-Xarch_device` refuses options that take an argument), so the host half of each compile prints "'-packed-fp32-ops' is not a
+# recognized feature for this target (ignoring feature)"; build() drops those lines from its verbose output.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
@@ -44,7 +46,7 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on " + s)
         if verbose and out:
-            print(out.decode())
+            print("\n".join(ln for ln in out.decode().split("\n") if "-packed-fp32-ops' is not a recognized feature" not in ln))
     so = lib_path()
     if rebuilt or not os.path.exists(so):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs, "-ldl"])

@@ -128,8 +128,14 @@ class CNet(nn.Sequential):
             raise RuntimeError("SyncBN over vf_net needs the C-ABI communicator (backend.comm); without it the trainers keep such "
                                "nets on the module-by-module host (trainers._host_nets)")
         # (keyed by the communicator too: one attached after the first forward must reach the net)
+        # a forced SyncBN at world 1 (tests, `--force-dist`) takes the communicator only when that communicator IS one rank: the library
+        # all-reduces the sums over all of its ranks and divides by npix * world (vf_net_set_sync_bn refuses a mismatch)
+        def _sync_comm(v):
+            if v[0] > 1:
+                return comm
+            return comm if (v[1] and comm is not None and lib.vf_comm_world(comm) == v[0]) else None
         self._push("sync", sync + (getattr(comm, "value", None),),
-                   lambda v: lib.vf_net_set_sync_bn(self._net, comm if (v[0] > 1 or v[1]) else None, v[0], 1 if v[1] else 0))
+                   lambda v: lib.vf_net_set_sync_bn(self._net, _sync_comm(v), v[0], 1 if v[1] else 0))
         hook = nn.Sequential.act_hook
         if (hook is not None) != (self._cb is not None):
             if hook is not None:

@@ -273,12 +273,14 @@ int conv_forward(vf_net* n, Layer& l, const float* x, const void* in_planes, int
   const float* b = n->params + l.b_off;
   const bool full = is_full(l);
   l.out_planes = nullptr;
+  // every branch below rewrites l.y: sign bits a previous forward left (another planes gate, product mode or VF_NO_THIN then) no longer
+  // describe it, whichever branch this forward takes
+  l.bits_live = false;
   const bool simple_act = act == VF_ACT_NONE || relu_like(act);
   if (want_planes && !full && l.C == 3 && simple_act && is_s2(l) && l.Co % 64 == 0 && l.H % 16 == 0 && l.W % 16 == 0) {
     if (int rc = ensure_planes(n, &l.yp, (int64_t)n->B * l.Ho * l.Wo * l.Co)) return rc;
     // the sign bits of the activated output, for the derivative mask of the data-gradient pass above (2 MB read there instead of the
     // 67 MB activation); not under an activation observer, whose edits of y the bits would not follow (tests/helpers.py KinkSync)
-    l.bits_live = false;
     if (relu_like(act) && !n->observer && !g_no_act_bits) {
       if (!l.ybits)
         if (int rc = net_alloc(n->act_owned, (void**)&l.ybits, sizeof(unsigned) * (size_t)n->B * l.Ho * l.Wo * (l.Co / 32))) return rc;
@@ -1058,6 +1060,10 @@ VF_API int vf_net_set_sync_bn(vf_net* n, vf_comm* comm, int world, int force) {
   VF_REQUIRE(n && world >= 1, "vf_net_set_sync_bn: bad arguments");
   // (a world of several ranks without a communicator would silently normalise with rank-local statistics)
   VF_REQUIRE(world == 1 || comm != nullptr, "vf_net_set_sync_bn: world = %d needs a communicator (vf_comm_init)", world);
+  // bn_forward / bn_backward all-reduce the sums over EVERY rank of `comm` and divide by npix * world: the two must be the same number
+  // (a forced world-1 SyncBN over a communicator of N ranks would normalise with N-times-too-large sums: ADVICE r4)
+  VF_REQUIRE(comm == nullptr || vf_comm_world(comm) == world,
+             "vf_net_set_sync_bn: world = %d but the communicator spans %d ranks", world, comm ? vf_comm_world(comm) : 0);
   n->comm = comm;
   n->sync_world = world;
   n->sync_force = force != 0;

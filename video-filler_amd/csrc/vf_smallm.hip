@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void k_smallm_rowdot(const float* __restrict__
   //  `v_pk_fma_f32 acc[r:r+1], w[r:r+1], x.hi ... op_sel:[0,1,0]`, a form that on gfx950 occasionally drops its low result in lanes
   //  48-63 under GPU sharing (checker kernel: the per-lane partials in front of the reduction equal the chain with exactly that
   //  FMA missing; the same instruction with src0/src1 exchanged, or split into two v_fma_f32, never failed).  With this epilogue
-  //  the compiler packs pairs of activation rows instead (`op_sel:[1,0,0]`), which is what the shipped code objects hold —
-  //  scripts/check_pk_opsel.py keeps it that way, in the CPU suite.)
+  //  the compiler packed pairs of activation rows instead (`op_sel:[1,0,0]`); since the end of round 4 the whole library is built
+  //  with -packed-fp32-ops (build.py) and these chains are plain v_fma_f32 — scripts/check_pk_opsel.py asserts, in the CPU suite,
+  //  that the shipped code objects hold no packed FP32 arithmetic at all.)
   __shared__ float red[4][R * MT][65];
   const int wl = threadIdx.x >> 6;
 #pragma unroll
