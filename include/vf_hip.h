@@ -146,6 +146,12 @@ int vf_pconv_supported(int B, int H, int W, int Cin, int Cout, int k, int stride
  * 64-channel K steps, whole 64 x 64 tiles): vf_pconv_supported_in_mode(1, ...); mode 3 = vf_pconv_supported; mode 0: never.
  * Results equal the in-kernel-rounding kernels' (same products, another summation order). */
 int vf_pconv_supported_in_mode(int mfma_mode, int B, int H, int W, int Cin, int Cout, int k, int stride, int pad, int transposed);
+/* Which kernel serves a planes pass is a tiling decision of the library (kernel map).  Two of the choices can be switched
+ * per process, for same-box A/B runs and for the tests that compare the kernels bit for bit: gather_patch (0 / 1: k_pconv_patch_g for
+ * the gather passes on whole 128-row tiles; default 1, env VF_PG_GPATCH) and scatter_patch (0 off, 1 auto, 2 / 4 parity classes per
+ * block of k_pconv_patch_tr; default 1, env VF_PG_PATCH).  A negative value leaves a setting as it is.  Results do not depend on it:
+ * every choice forms the same six-term products in the same K order per output element. */
+int vf_pconv_set_routing(int gather_patch, int scatter_patch);
 int vf_pconv_gather(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,
                     int Cout, int act, float slope);
 int vf_pconv_scatter(vf_ctx* ctx, const void* ap, const void* wp, const float* bias, float* y, int B, int H, int W, int Cin,

@@ -40,7 +40,28 @@ for name, Cin, H, Cout in LAYERS:
     fl = 2.0 * Bn * (H // 2) ** 2 * Cout * Cin * 16
     t_old = timeit(lambda: hb.conv2d_fwd(x, w, None, y, 4, 2, 1))
     t_new = timeit(lambda: hb.pconv_gather(xp, wn, None, y, Bn, H, H, Cin, Cout))
-    print("%-6s gather  B=%3d  old %7.1f us %6.1f TF   planes %7.1f us %6.1f TF   x%.2f" % (name, Bn, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new))
+    hb.pconv_set_routing(gather_patch=0)
+    t_dma = timeit(lambda: hb.pconv_gather(xp, wn, None, y, Bn, H, H, Cin, Cout))
+    hb.pconv_set_routing(gather_patch=1)
+    print("%-6s gather  B=%3d  old %7.1f us %6.1f TF   planes %7.1f us %6.1f TF   x%.2f   (tap-staged k_pconv_dma %7.1f us %6.1f TF)" % (name, Bn, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new, t_dma, fl / t_dma / 1e6))
+    # the gather pass as the iteration runs it: forward with bias + LeakyReLU + BatchNorm forward sums; data-gradient with mask + backward sums
+    smg = hb.zeros(Cout)
+    partg = hb.zeros((max(Bn * (H // 2) ** 2 // 64, 512) + 8) * 2 * Cout, dtype=torch.float64)
+    bias_g = hb.zeros(Cout)
+    def g_fwd():
+        hb.bn_fuse_next_fwd(smg, partg, 1)
+        hb.pconv_gather(xp, wn, bias_g, y, Bn, H, H, Cin, Cout)
+        hb.bn_fuse_result()
+    def g_bwd():
+        hb.bn_fuse_next_bwd(y, y, "relu", 0.0, smg, partg, 1)
+        hb.pconv_gather(xp, wn, None, y, Bn, H, H, Cin, Cout)
+        hb.bn_fuse_result()
+    res = []
+    for route in (1, 0):
+        hb.pconv_set_routing(gather_patch=route)
+        res += [timeit(g_fwd), timeit(g_bwd)]
+    hb.pconv_set_routing(gather_patch=1)
+    print("%-6s gather + forward sums %7.1f us (dma %7.1f)   + mask + backward sums %7.1f us (dma %7.1f)" % (name, res[0], res[2], res[1], res[3]))
     t_old = timeit(lambda: hb.conv2d_bwd_data(y, w, gx, 4, 2, 1))
     t_new = timeit(lambda: hb.pconv_scatter(yp, wt, None, gx, Bn, H // 2, H // 2, Cout, Cin))
     print("%-6s scatter B=%3d  old %7.1f us %6.1f TF   planes %7.1f us %6.1f TF   x%.2f" % (name, Bn, t_old, fl / t_old / 1e6, t_new, fl / t_new / 1e6, t_old / t_new))

@@ -307,6 +307,96 @@ def test_patch_fed_transposed_passes_against_the_oracle(Bn, Cin, H, Cout, symbol
     assert _err(got, want * np.where(x > 0, 1.0, 0.2)) <= 2e-5
 
 
+# ---- the gather passes from a patch (k_pconv_patch_g): against k_pconv_dma BIT FOR BIT (same products, same K order
+# per output element), and against the oracle with the symbol asserted.  Modes: m0 = 8 x 16 tiles of a map at least 8 x 16 (Wo = 16 and
+# Wo = 32 take different tile walks), m1 = whole 8 x 8 maps, m2 = whole 4 x 4 maps; several cases split K over channel chunks.
+GATHER_PATCH_CASES = [
+    (8, 64, 32, 128, "m0"), (4, 64, 64, 64, "m0"), (16, 128, 16, 256, "m1"), (32, 256, 8, 512, "m2"), (64, 64, 32, 128, "m0"),
+    (6, 192, 32, 384, "m0"), (64, 128, 16, 256, "m1"), (64, 256, 8, 512, "m2"), (2, 64, 128, 64, "m0"),
+]
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout,mode", GATHER_PATCH_CASES, ids=lambda v: str(v))
+def test_patch_fed_gather_pass_equals_the_tap_staged_kernel_bit_for_bit(Bn, Cin, H, Cout, mode, hipb):
+    dev = hipb.device
+    x = _act(Bn, Cin, H, 31, dev)
+    w = _rand((Cout, 4, 4, Cin), 32, dev, 0.05).permute(0, 3, 1, 2)
+    bias = _rand((Cout,), 33, dev, 0.1)
+    xp = hipb.planes_split(x)
+    wp, _ = hipb.weight_planes(w, want_transposed=False)
+    outs = {}
+    try:
+        for route in (1, 0):
+            hipb.pconv_set_routing(gather_patch=route)
+            y = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+            y.fill_(float("nan"))
+            hipb.prof_begin()
+            hipb.pconv_gather(xp, wp, bias, y, Bn, H, H, Cin, Cout, "lrelu", 0.2)
+            names = hipb.prof_end()
+            if route:
+                assert "pconv_patchg_128x64_t16_" + mode in names, list(names)
+            else:
+                assert not any(k.startswith("pconv_patchg") for k in names) and any(k.startswith("pconv_dma") for k in names), list(names)
+            # the data-gradient form (nn.SpatialFullConvolution: no bias, the ReLU derivative of the layer below in the epilogue and the
+            # BatchNorm-backward sums of that layer as a by-product)
+            gx = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+            below = _act(Bn, Cout, H // 2, 34, dev)
+            sm = _rand((Cout,), 35, dev, 0.1)
+            rows = max(Bn * (H // 2) ** 2 // 64, 512) + 8
+            part = hipb.zeros(rows * 2 * Cout, dtype=torch.float64)
+            hipb.bn_fuse_next_bwd(below, below, "relu", 0.0, sm, part, 1)
+            hipb.pconv_gather(xp, wp, None, gx, Bn, H, H, Cin, Cout)
+            nrows = hipb.bn_fuse_result()
+            outs[route] = (y, gx, part.view(-1, 2 * Cout)[:max(nrows, 0)].sum(0) if nrows > 0 else None, nrows)
+    finally:
+        hipb.pconv_set_routing(gather_patch=1)
+    (y1, g1, s1, n1), (y0, g0, s0, n0) = outs[1], outs[0]
+    assert torch.equal(y1, y0), float((y1 - y0).abs().max())
+    assert torch.equal(g1, g0), float((g1 - g0).abs().max())
+    assert (n1 > 0) == (n0 > 0)
+    if n1 > 0:            # the partial rows are fp32 sums per row tile (8 x 16 tiles walk a 32-wide map in another order): their totals agree
+        assert float((s1 - s0).abs().max() / (s0.abs().max() + 1e-30)) <= 2e-6
+
+
+GATHER_ORACLE_CASES = [(4, 64, 32, 128, "m0"), (2, 64, 64, 64, "m0"), (4, 128, 16, 256, "m1"), (16, 256, 8, 512, "m2")]
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout,mode", GATHER_ORACLE_CASES, ids=lambda v: str(v))
+def test_patch_fed_gather_passes_against_the_oracle(Bn, Cin, H, Cout, mode, oracle, hipb):
+    """k_pconv_patch_g directly against oracle.SpatialConvolution.updateOutput (+ LeakyReLU, train.lua:89-101) and against
+    oracle.SpatialFullConvolution.updateGradInput over the same pair of maps (train.lua:134-146), the launch name asserted."""
+    dev = hipb.device
+    rng = np.random.default_rng(Bn * 1000 + Cin + Cout + 11)
+    symbol = "pconv_patchg_128x64_t16_" + mode
+    oracle.set_num_threads(16)
+    try:
+        ref = oracle.SpatialConvolution(Cin, Cout, 4, 4, 2, 2, 1, 1)
+        ref.weight[...] = rng.standard_normal(ref.weight.shape).astype(np.float32) * 0.05
+        ref.bias[...] = rng.standard_normal(Cout).astype(np.float32) * 0.1
+        x = rng.standard_normal((Bn, Cin, H, H)).astype(np.float32)
+        y = ref.forward(x).copy()
+        full = oracle.SpatialFullConvolution(Cout, Cin, 4, 4, 2, 2, 1, 1)      # weight [Cout][Cin][4][4]: the same tensor read the other way
+        full.weight[...] = ref.weight
+        lo = rng.standard_normal((Bn, Cout, H // 2, H // 2)).astype(np.float32)
+        want_gx = full.updateGradInput(lo, x).copy()                            # "gradOutput" = x: H x H maps with Cin channels
+    finally:
+        oracle.set_num_threads(1)
+    dx, dw, db = _to_dev(x, dev), _to_dev(ref.weight, dev), _to_dev(ref.bias, dev)
+    xp = hipb.planes_split(dx)
+    wn, _ = hipb.weight_planes(dw, want_transposed=False)
+    got = hipb.empty_act(Bn, Cout, H // 2, H // 2)
+    hipb.prof_begin()
+    hipb.pconv_gather(xp, wn, db, got, Bn, H, H, Cin, Cout, "lrelu", 0.2)
+    names = hipb.prof_end()
+    assert symbol in names, (symbol, list(names))
+    assert _err(got, np.where(y > 0, y, 0.2 * y)) <= 2e-5
+    hipb.prof_begin()
+    hipb.pconv_gather(xp, wn, None, got, Bn, H, H, Cin, Cout)
+    names = hipb.prof_end()
+    assert symbol in names, (symbol, list(names))
+    assert _err(got, want_gx) <= 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ producer-written planes
 def _same_planes(a, b):
     return torch.equal(a.view(torch.int16), b.view(torch.int16))

@@ -43,6 +43,7 @@ SIGNATURES = {
     "vf_weight_planes_multi": (i32, [vp, vp, i32, i32]),
     "vf_pconv_supported": (i32, [i32] * 9),
     "vf_pconv_supported_in_mode": (i32, [i32] * 10),
+    "vf_pconv_set_routing": (i32, [i32, i32]),
     "vf_pconv_gather": (i32, [vp, vp, vp, vp, vp] + [i32] * 5 + [i32, f32]),
     "vf_pconv_scatter": (i32, [vp, vp, vp, vp, vp] + [i32] * 5 + [i32, f32, vp, i32, f32]),
     "vf_bn_stats": (i32, [vp, vp, vp, vp, i64, i32]),

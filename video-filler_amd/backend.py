@@ -547,6 +547,10 @@ class HipBackend:
         plane, whole 64-wide tiles only; 0: never)?"""
         return bool(self.lib.vf_pconv_supported_in_mode(MFMA_MODES[self.mfma_mode], B, H, W, Cin, Cout, k, stride, pad, 1 if transposed else 0))
 
+    def pconv_set_routing(self, gather_patch=-1, scatter_patch=-1):
+        """process-wide: which kernels serve the planes passes (vf_pconv_set_routing; -1 leaves a setting alone)"""
+        _lib.check(self.lib.vf_pconv_set_routing(int(gather_patch), int(scatter_patch)))
+
     def pconv_gather(self, ap, wp, bias, y, B, H, W, Cin, Cout, act="none", slope=0.0):
         self._c("vf_pconv_gather", _ptr(ap), _ptr(wp), _ptr(bias), _ptr(y), B, H, W, Cin, Cout, ACT[act], slope)
 

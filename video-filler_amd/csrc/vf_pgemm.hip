@@ -266,15 +266,17 @@ __device__ __forceinline__ void pg_bn_tile_partials(const VfBnSt& st, float (&s1
 // multiplier, so the 16 * MT * NT element bodies are straight-line code (with the activation as a per-element switch and
 // the statistics mode as per-element branches the epilogue was a quarter of vf_conv.hip's igemm kernels).
 // `red`: LDS the tile loop no longer needs (2 * WAVES_M * BN floats), for the statistics partials.
-// pre_d / pre_x (MT = NT = 1 only; may be NULL): the 16 derivative-mask values / BatchNorm inputs of this lane's accumulator
+// pre_d / pre_x (PRE, MT = 1; [column tile][16]): the 16 derivative-mask values / BatchNorm inputs of this lane's accumulator
 // elements, fetched by the caller BEFORE its K loop — read here, at the end of the tile, they were a serialised memory phase
 // that nothing overlapped (E2's data-gradient: 62 us without the mask, 78 with it)
-template <int MT, int NT, int WAVES_M, int BN, bool PRE = false>
-__device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT], float* red, int m0, int n0, int wm, int wn, int lane,
-                                            int tid, int wave_m, int bx, int ks, int ooy0, int oox0, int ph, int pw, bool tile_ok,
-                                            const float (&pre_d)[16], const float (&pre_x)[16]) {
+// pix_of(row): the output pixel (index into [pixels][N]) of row `row` of the block tile, or -1 for a row past the end of the GEMM —
+// the row -> pixel map is the caller's (k_pconv / k_pconv_dma: GEMM row m0 + row decoded as (b, my, mx); k_pconv_patch_g: an 8 x 16
+// spatial tile), the arithmetic on the element is this function's alone.
+template <int MT, int NT, int WAVES_M, int BN, bool PRE = false, class PixOf>
+__device__ __forceinline__ void pg_epilogue_at(const PGemm& p, f32x16 (&acc)[MT][NT], float* red, int n0, int wm, int wn, int lane,
+                                               int tid, int wave_m, int bx, int ks, int ph, int pw, bool tile_ok,
+                                               const float (&pre_d)[NT][16], const float (&pre_x)[NT][16], PixOf pix_of) {
   const int lr = lane & 31, lh = lane >> 5;
-  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
   float* out = p.ksplit > 1 ? p.slab + (int64_t)ks * p.out_elems : p.Y;
   const bool fin = p.ksplit == 1;
   const int stm = fin ? p.st.mode : 0;
@@ -299,24 +301,22 @@ __device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
-        const int64_t pix = ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
+        const int64_t pix = pix_of(row);
+        if (pix < 0) continue;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int n = n0 + wn + nt * 32 + lr;
           if (n < p.N) {
             float v = acc[mt][nt][r] + bv[nt];
             v = v * (v > 0.f ? 1.f : neg);
-            if constexpr (has_dmask) v = v * ((PRE ? pre_d[r] : p.dmask[pix * p.N + n]) > 0.f ? 1.f : dneg);
+            if constexpr (has_dmask) v = v * ((PRE ? pre_d[nt][r] : p.dmask[pix * p.N + n]) > 0.f ? 1.f : dneg);
             if constexpr (sm == 1) {
               const float d = v - sv[nt];
               st1[nt] += d;
               st2[nt] += d * d;
             } else if constexpr (sm == 2) {
               st1[nt] += v;
-              st2[nt] += v * ((PRE ? pre_x[r] : p.st.x[pix * p.N + n]) - sv[nt]);
+              st2[nt] += v * ((PRE ? pre_x[nt][r] : p.st.x[pix * p.N + n]) - sv[nt]);
             }
             out[pix * p.N + n] = v;
           }
@@ -330,10 +330,8 @@ __device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
-        const int64_t pix = ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
+        const int64_t pix = pix_of(row);
+        if (pix < 0) continue;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int n = n0 + wn + nt * 32 + lr;
@@ -351,6 +349,24 @@ __device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT
   if (stm)
     pg_bn_tile_partials<NT, WAVES_M, BN>(p.st, st1, st2, red, wave_m, wn, lane, tid, n0, tile_ok ? p.N : 0, bx,
                                          p.parity ? ((ph << 1) | pw) : 0);
+}
+
+// the GEMM-row form: row `row` of the tile is GEMM row m0 + row = (b, my, mx) on the Mh x Mw grid, output pixel (my osy + ooy0, mx osx + oox0)
+template <int MT, int NT, int WAVES_M, int BN, bool PRE = false>
+__device__ __forceinline__ void pg_epilogue(const PGemm& p, f32x16 (&acc)[MT][NT], float* red, int m0, int n0, int wm, int wn, int lane,
+                                            int tid, int wave_m, int bx, int ks, int ooy0, int oox0, int ph, int pw, bool tile_ok,
+                                            const float (&pre_d)[16], const float (&pre_x)[16]) {
+  const int Mw = 1 << p.lgMw, Mh = 1 << p.lgMh;
+  static_assert(!PRE || NT == 1, "the prefetched epilogue operands of the GEMM-row form are one column tile's");
+  typedef const float (&pre_t)[NT][16];
+  pg_epilogue_at<MT, NT, WAVES_M, BN, PRE>(p, acc, red, n0, wm, wn, lane, tid, wave_m, bx, ks, ph, pw, tile_ok,
+                                           reinterpret_cast<pre_t>(pre_d), reinterpret_cast<pre_t>(pre_x),
+                                           [&](int row) -> int64_t {
+                                             const int m = m0 + row;
+                                             if (m >= p.M) return -1;
+                                             const int mx = m & (Mw - 1), my = (m >> p.lgMw) & (Mh - 1), b = m >> (p.lgMw + p.lgMh);
+                                             return ((int64_t)b * p.outH + (my * p.osy + ooy0)) * p.outW + (mx * p.osx + oox0);
+                                           });
 }
 
 // BM x BN block tile, 4 waves of WM x WN (32x32 MFMA tiles), one K step = ONE window tap x CH channels, K walked channel
@@ -1030,6 +1046,269 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
   });
 }
 
+// ------------------------------------------------------------------------------------------------ gather passes from a PATCH
+// k_pconv_dma fills its stages tap by tap: per 64-channel K step a 128 x 64 tile moves 48 KB of A and 24 KB of W from L2 into LDS for
+// 0.64 us of matrix-pipe work — 29 TB/s chip-wide at the pipe's rate, against the ~17 TB/s LDS-DMA gathers get out of L2
+// (MI355X_MICROARCH.md "Indexed rows: gather into LDS"): the gather (t16) passes, the family's dominant symbol, are FILL-bound near
+// 0.58 of their pipe bound and ran at 0.31.  A 4x4 stride-2 window reads each INPUT-PARITY class of the input
+// through a 2x2-tap stride-1 window: taps (th, tw) with th = cth + 2a, tw = ctw + 2b read input (2 oy - 1 + th, 2 ox - 1 + tw) =
+// sub-image pixel (oy - 1 + cth + a, ox - 1 + ctw + b) of class (cth, ctw) — the order k_pconv_dma already walks its 16 taps in
+// (class outer, (a, b) inner).  So per (64-channel chunk, class) a block stages the class's sub-image region ONCE as a patch and
+// reads the A fragments of its four taps from it at per-lane slots; only the weights stream, one (tap, 64 ch) stage of 24 KB per
+// step: 14.7 + 24.6 KB per step instead of 72.
+//   MODE 0: an 8 x 16 tile of an output map with Wo % 16 == 0, Ho % 8 == 0: patch = 9 x 17 sub-image pixels (one halo row and column;
+//           pixels outside the image arrive as zeros: out-of-range DMA lanes), slot (r, c) = r * 17 + c.
+//   MODE 1 / 2: whole output maps of 8 x 8 / 4 x 4 (two / eight per 128-row tile): the class's sub-image IS Ho x Wo pixels per map
+//           and every halo pixel is padding: 128 real slots + two all-zero slots that the lanes of padding taps read instead.
+// LDS (147 KB, one block per CU): the patch's hi and mid planes are double-buffered (the next unit's travel beside this unit's four
+// steps); the lo plane — read by ONE of the six product terms — is single: its fragments of a unit's LAST step are read one step
+// early into 16 registers, so the next unit's lo plane can be fetched during that last step.  (All three planes double-buffered
+// are 2.7 KB more than a CU has beside two weight stages.)  16-byte k-octets of a slot are XOR-swizzled by (patch column & 7)
+// (MODE 0) / (slot >> 1) & 7 (MODE 1, 2): every ds_read_b128 lane group covers the 64 banks once for all sixteen (class, tap)
+// windows (checked exhaustively against MI355X_MICROARCH.md's lane groups; padding lanes read the zero slots at the bank position
+// their out-of-image slot would have had).
+// Same six-term products in the same K order per output element as k_pconv_dma: bit-identical results.  N % 64 == 0, C % 64 == 0,
+// split-K over channel chunks as k_pconv_dma.  Semantics: nn.SpatialConvolution forward (train.lua:89-101, 183-193) and
+// nn.SpatialFullConvolution's data-gradient (train.lua:134-146).
+template <int MODE>
+__global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
+  constexpr int PW = 17;
+  constexpr int NSLOT = MODE == 0 ? 9 * PW : 130;           // MODE 1, 2: 128 real slots + the zero slots 128, 129
+  constexpr int NG = (NSLOT + 7) / 8, AGW = (NG + 7) / 8;   // 8-slot DMA groups; groups per wave
+  constexpr int PL = NG * 8 * 128;                          // one plane image, bytes (a multiple of 1 KB)
+  constexpr int W_PL = 64 * 128, WBUF = 3 * W_PL;           // one (tap, 64 ch) weight stage
+  constexpr int OFF_LO = 4 * PL, OFF_W = 5 * PL;            // [hi0 | mid0 | hi1 | mid1 | lo | W0 | W1]
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[5 * PL + 2 * WBUF];
+  float* red = (float*)(smem + OFF_W);                      // (BatchNorm partials of the epilogue: the weight stages are dead by then)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ntiles = p.gm * p.gn * p.gz;
+  const int lid = pg_xcd_remap(blockIdx.x, ntiles);
+  const int bx = lid % p.gm, byz = lid / p.gm;
+  const int n0 = (byz % p.gn) * 64;
+  const int ks = byz / p.gn;
+  const int cps = p.nchunks / p.ksplit;
+  const int ch0 = ks * cps;
+  const int Wo = 1 << p.lgMw, Ho = 1 << p.lgMh;
+
+  // ---- tile geometry
+  int b_img = 0, oy0 = 0, ox0 = 0;                            // MODE 0: image and tile origin on the output map
+  if constexpr (MODE == 0) {
+    const int tiles_x = Wo >> 4, tiles_y = Ho >> 3;
+    const int tx = bx % tiles_x, ty = (bx / tiles_x) % tiles_y;
+    b_img = bx / (tiles_x * tiles_y);
+    oy0 = 8 * ty;
+    ox0 = 16 * tx;
+  }
+  constexpr int HW = MODE == 1 ? 64 : 16, LW = MODE == 1 ? 3 : 2;      // MODE 1, 2: pixels per map, log2 of its width
+
+  // ---- this lane's share of every patch: slot 8 * group + lane / 8, LDS octet lane % 8 = global octet ^ swizzle(slot).
+  //      a_byte: the slot's pixel of class (0, 0); class (cth, ctw) is cls_off(cth, ctw) bytes away; a_ok bit (2 cth + ctw): in the image
+  unsigned a_byte[AGW], a_ok[AGW], a_lds[AGW];
+#pragma unroll
+  for (int i = 0; i < AGW; ++i) {
+    const int grp = wave + 8 * i;
+    const int sl = 8 * grp + (lane >> 3);
+    a_lds[i] = (unsigned)(grp * 8 * 128);
+    if constexpr (MODE == 0) {
+      const int r = sl / PW, c = sl - r * PW;
+      const int y00 = 2 * (oy0 + r) - 1, x00 = 2 * (ox0 + c) - 1;
+      const int oct = (lane & 7) ^ (c & 7);
+      a_byte[i] = 2u * (unsigned)(((b_img * p.Hi + y00) * p.Wi + x00) * p.C + 8 * oct);
+      unsigned ok = 0;
+#pragma unroll
+      for (int cls = 0; cls < 4; ++cls)
+        if ((unsigned)(y00 + (cls >> 1)) < (unsigned)p.Hi && (unsigned)(x00 + (cls & 1)) < (unsigned)p.Wi) ok |= 1u << cls;
+      a_ok[i] = (grp < NG && sl < NSLOT) ? ok : 0u;
+    } else {
+      const int g = sl >> (2 * LW), ii = (sl >> LW) & (Wo - 1), jj = sl & (Wo - 1);
+      const int oct = (lane & 7) ^ ((sl >> 1) & 7);
+      const int img = bx * (128 / HW) + g;
+      // class (cth, ctw) of sub-image pixel (ii, jj) is input pixel (2 ii + 1 - cth, 2 jj + 1 - ctw): always inside the image
+      a_byte[i] = 2u * (unsigned)(((img * p.Hi + 2 * ii + 1) * p.Wi + 2 * jj + 1) * p.C + 8 * oct);
+      a_ok[i] = (grp < NG && sl < 128) ? 15u : 0u;
+    }
+  }
+  // ---- and of every weight stage: row n = 8 * wave + lane / 8 of the 64
+  const int wrow = 8 * wave + (lane >> 3);
+  const unsigned w_byte = 2u * (unsigned)((n0 + wrow) * 16 * p.C + 8 * ((lane & 7) ^ ((wrow >> 1) & 7)));
+  const unsigned w_lds = (unsigned)(wave * 8 * 128);
+  const __amdgpu_buffer_rsrc_t rsA = pg_rsrc(p.A, p.a_bytes), rsW = pg_rsrc(p.W, p.w_bytes);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  unsigned szero;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(szero));
+  int rowA = 2 * p.Wi * p.C, colA = 2 * p.C;                  // one input row / pixel, bytes
+
+  // plane q (0 hi, 1 mid, 2 lo) of unit (chunk ch, class cls) into patch buffer pb
+  auto dma_patch_plane = [&](int ch, int cls, int pb, auto Q, bool live) {
+    constexpr int q = decltype(Q)::value;
+    const int cth = cls >> 1, ctw = cls & 1;
+    const unsigned cb = 128u * (unsigned)ch + (unsigned)(MODE == 0 ? cth * rowA + ctw * colA : -(cth * rowA + ctw * colA));
+    const unsigned dst = lds0 + (unsigned)(q == 2 ? OFF_LO : (2 * pb + q) * PL);
+    if (!live) return;                                        // (wave-uniform: the block's last unit has no successor)
+#pragma unroll
+    for (int i = 0; i < AGW; ++i) {
+      if (wave + 8 * i < NG) {                                // (wave-uniform)
+        const bool ok = (a_ok[i] >> cls) & 1u;
+        pg_dma16(dst + a_lds[i], ok ? a_byte[i] + cb : VF_OOB, rsA, szero + q * p.a_ps);
+      }
+    }
+  };
+  // weight stage of step s_ (tap th = cth + 2a, tw = ctw + 2b: filter tap (th, tw)) of chunk ch
+  auto dma_w = [&](int ch, auto STEP, int buf, bool live) {
+    constexpr int s_ = decltype(STEP)::value;
+    constexpr int th = ((s_ >> 3) & 1) + 2 * ((s_ >> 1) & 1), tw = ((s_ >> 2) & 1) + 2 * (s_ & 1);
+    const unsigned tW = 2u * (unsigned)((th * 4 + tw) * p.C) + 128u * (unsigned)ch;
+    if (!live) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pg_dma16(lds0 + (unsigned)(OFF_W + buf * WBUF + q * W_PL) + w_lds, w_byte, rsW, q * p.w_ps + tW);
+  };
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+  // ---- this lane's A row of the tile and its first slot; B row wn + lr
+  const int arow = wm + lr;
+  int slot_base;                                            // MODE 0: slot of tap (a, b) = (0, 0); MODE 1, 2: slot of sub-image pixel (oy - 1, ox - 1)
+  unsigned tap_ok = 0xffffu;                                // MODE 1, 2: bit s_ = step s_'s tap lies inside the map
+  int a_col = 0;                                            // MODE 0: patch column of tap b = 0
+  if constexpr (MODE == 0) {
+    a_col = arow & 15;
+    slot_base = (arow >> 4) * PW + a_col;
+  } else {
+    const int oy = (arow >> LW) & (Wo - 1), ox = arow & (Wo - 1);
+    slot_base = (arow >> (2 * LW)) * HW + (oy - 1) * Wo + (ox - 1);
+    tap_ok = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      const int di = ((s_ >> 3) & 1) + ((s_ >> 1) & 1) - 1, dj = ((s_ >> 2) & 1) + (s_ & 1) - 1;
+      if ((unsigned)(oy + di) < (unsigned)Ho && (unsigned)(ox + dj) < (unsigned)Wo) tap_ok |= 1u << s_;
+    }
+  }
+  const int brow = wn + lr;
+  unsigned b_off0 = (unsigned)(brow * 128);
+  const unsigned b_sw = (unsigned)((brow >> 1) & 7);
+
+  // A fragment address pieces of step s_: byte offset of the slot inside a plane image, swizzle
+  auto a_addr = [&](auto STEP, unsigned& off, unsigned& sw) {
+    constexpr int s_ = decltype(STEP)::value;
+    constexpr int cth = (s_ >> 3) & 1, ctw = (s_ >> 2) & 1, a = (s_ >> 1) & 1, b = s_ & 1;
+    if constexpr (MODE == 0) {
+      off = (unsigned)((slot_base + a * PW + b) * 128);
+      sw = (unsigned)((a_col + b) & 7);
+    } else {
+      const int raw = slot_base + (cth + a) * Wo + ctw + b;
+      const bool ok = (tap_ok >> s_) & 1u;
+      off = (unsigned)((ok ? raw : (128 | (raw & 1))) * 128);
+      sw = (unsigned)((raw >> 1) & 7);
+    }
+  };
+
+  bf16x8 lo_held[4];                                        // the lo fragments of a unit's last step (read during the step before)
+  auto read_lo_ahead = [&](auto STEP) {
+    unsigned off, sw;
+    a_addr(STEP, off, sw);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) lo_held[g] = *(const bf16x8*)(smem + OFF_LO + off + ((((unsigned)(2 * g + lh)) ^ sw) << 4));
+  };
+  auto compute_step = [&](auto STEP, int pb, int wbuf) {
+    constexpr int s_ = decltype(STEP)::value;
+    constexpr bool held = (s_ & 3) == 3;
+    unsigned a_off, a_sw;
+    a_addr(STEP, a_off, a_sw);
+    const unsigned char* pa = smem + 2 * pb * PL + a_off;
+    const unsigned char* pl = smem + OFF_LO + a_off;
+    const unsigned char* wb = smem + OFF_W + wbuf * WBUF + b_off0;
+    bf16x8 a[2][3], bb[2][3];
+    auto read_frag = [&](int g, int set) {
+      const unsigned o = (unsigned)(2 * g + lh);
+      a[set][0] = *(const bf16x8*)(pa + ((o ^ a_sw) << 4));
+      a[set][1] = *(const bf16x8*)(pa + PL + ((o ^ a_sw) << 4));
+      if constexpr (!held) a[set][2] = *(const bf16x8*)(pl + ((o ^ a_sw) << 4));
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bb[set][q] = *(const bf16x8*)(wb + q * W_PL + ((o ^ b_sw) << 4));
+    };
+    read_frag(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cs = g & 1;
+      if (g + 1 < 4) read_frag(g + 1, cs ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 a2;
+      if constexpr (held) a2 = lo_held[g];
+      else a2 = a[cs][2];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], bb[cs][1], acc[0][0], 0, 0, 0);      // smallest terms first
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], bb[cs][2], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bb[cs][0], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], bb[cs][1], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1], bb[cs][0], acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], bb[cs][0], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- the output pixel of a tile row, and what the epilogue reads besides the accumulators (derivative mask, BatchNorm input):
+  //      fetched now, beside the first stages (k_pconv_dma's pre_d / pre_x)
+  auto pix_of = [&](int row) -> int64_t {
+    if constexpr (MODE == 0) return ((int64_t)b_img * Ho + oy0 + (row >> 4)) * Wo + ox0 + (row & 15);
+    else return (int64_t)bx * 128 + row;
+  };
+  float pre_d[16], pre_x[16];
+  const bool fin_tile = p.ksplit == 1;
+  const bool want_d = fin_tile && p.dmask != nullptr, want_x = fin_tile && p.st.mode == 2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    pre_d[r] = 1.f;
+    pre_x[r] = 0.f;
+  }
+  if (want_d || want_x) {
+    const int n = n0 + wn + lr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t pix = pix_of(wm + (r & 3) + 8 * (r >> 2) + 4 * lh);
+      if (want_d) pre_d[r] = p.dmask[pix * p.N + n];
+      if (want_x) pre_x[r] = p.st.x[pix * p.N + n];
+    }
+  }
+
+  // ---- main loop: unit = (channel chunk, class), four tap steps each; weights one step ahead, the next unit's hi / mid planes during
+  //      steps 0 / 1 into the other patch buffer, its lo plane during step 3 (whose lo fragments were read during step 2)
+  dma_patch_plane(ch0, 0, 0, VfIntC<0>{}, true);
+  dma_patch_plane(ch0, 0, 0, VfIntC<1>{}, true);
+  dma_patch_plane(ch0, 0, 0, VfIntC<2>{}, true);
+  dma_w(ch0, VfIntC<0>{}, 0, true);
+  for (int c = 0; c < cps; ++c) {
+    const int ch = ch0 + c;
+    asm volatile("" : "+v"(slot_base), "+v"(b_off0), "+s"(rowA), "+s"(colA));
+    vf_static_for<16>([&](auto S) {
+      constexpr int s_ = decltype(S)::value, cls = s_ >> 2, t = s_ & 3, wbuf = s_ & 1, pb = cls & 1;      // (4 units per chunk: the buffer parity follows the class)
+      const bool last_unit = (c + 1 == cps) && cls == 3;
+      const int nch = cls == 3 ? ch + 1 : ch, ncls = (cls + 1) & 3;      // the next unit
+      // this wave's DMAs (this step's weights; at a unit's first step its patch) have landed and its LDS reads have returned — the lo
+      // fragments read ahead during step 2 in particular, whose plane the DMAs of step 3 overwrite; after the barrier everybody's have
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 1)) {
+        if constexpr (s_ + 1 < 16) dma_w(ch, VfIntC<s_ + 1>{}, wbuf ^ 1, true);
+        else dma_w(ch + 1, VfIntC<0>{}, wbuf ^ 1, c + 1 < cps);
+        if constexpr (t == 0) dma_patch_plane(nch, ncls, pb ^ 1, VfIntC<0>{}, !last_unit);
+        if constexpr (t == 1) dma_patch_plane(nch, ncls, pb ^ 1, VfIntC<1>{}, !last_unit);
+        if constexpr (t == 3) dma_patch_plane(nch, ncls, pb ^ 1, VfIntC<2>{}, !last_unit);
+      }
+      if constexpr (t == 2) read_lo_ahead(VfIntC<s_ + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(p.dbg & 4)) compute_step(S, pb, wbuf);
+    });
+  }
+  // every DMA has landed and nobody still reads a weight stage when the epilogue's partial sums go there
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  pg_epilogue_at<1, 1, 4, 64, true>(p, acc, red, n0, wm, wn, lane, tid, wave >> 1, bx, ks, 0, 0, true, pre_d, pre_x, pix_of);
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradients from planes
 // dW[n][tap][c] = sum_p U[p][n] * V[p @ tap][c] (VfPWGrad, vf_common.h): a 128 (n) x 128 (tap, c) tile per block, K = pixels in
 // steps of 32.  Both operands are K-MAJOR in memory ([pixel][channel]), which is the layout gfx950's transposing LDS read
@@ -1249,6 +1528,16 @@ int vf_internal_pwgrad_group(vf_ctx* ctx, const VfPWGradGroup& G, int blocks, co
 }
 
 // ================================================================================================ host
+// which kernel serves a planes pass is a tiling decision; the two patch-fed forms can be switched per process (A/B runs, and the tests
+// that compare them with k_pconv_dma bit for bit): defaults from VF_PG_GPATCH / VF_PG_PATCH, vf_pconv_set_routing overrides
+static int g_gather_patch = getenv("VF_PG_GPATCH") ? atoi(getenv("VF_PG_GPATCH")) : 1;     // 0 off, 1 on
+static int g_scatter_patch = getenv("VF_PG_PATCH") ? atoi(getenv("VF_PG_PATCH")) : 1;      // 0 off, 1 auto, 2 / 4 classes per block
+VF_API int vf_pconv_set_routing(int gather_patch, int scatter_patch) {
+  if (gather_patch >= 0) g_gather_patch = gather_patch;
+  if (scatter_patch >= 0) g_scatter_patch = scatter_patch;
+  return 0;
+}
+
 static inline bool pg_aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // shared with vf_conv.hip: the split-K combine (plain and with BatchNorm statistics)
@@ -1375,7 +1664,7 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
     // with one tile per CU the second stage is what is needed instead: E3 gather 29.7 vs 39.8 single-stage)
     // transposed passes on grids of at least 8 x 16: the patch kernel (k_pconv_patch_tr).  VF_PG_PATCH: 0 off, 2 / 4 = that many parity
     // classes per block, 1 (default) = 4 where that still gives two rounds of blocks, else 2
-    static const int env_patch = getenv("VF_PG_PATCH") ? atoi(getenv("VF_PG_PATCH")) : 1;
+    const int env_patch = g_scatter_patch;
     if (env_patch && ntaps == 4 && g.parity && g.N % 64 == 0 && ksplit == 1 && t.bm == 128 && g.Wi % 16 == 0 && g.Hi % 8 == 0 &&
         (g.act == VF_ACT_NONE || g.act == VF_ACT_LRELU || g.act == VF_ACT_RELU) &&
         g.out_elems * 4 < ((int64_t)1 << 31)) {       // (its epilogue addresses the output through 32-bit buffer offsets)
@@ -1387,6 +1676,26 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
       else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_tr<2>, pgrid, dim3(512), g);
       VF_LAUNCH_CHECK();
       return 0;
+    }
+    // gather passes (conv forward, full-conv data-gradient) on whole 128-row tiles: the patch kernel (k_pconv_patch_g).  VF_PG_GPATCH=0
+    // keeps k_pconv_dma's tap-by-tap stages
+    const int env_gpatch = g_gather_patch;
+    if (env_gpatch && ntaps == 16 && !g.parity && g.N % 64 == 0 && t.bm == 128 && g.sy == 2 && g.sx == 2) {
+      const int Ho = 1 << g.lgMh, Wo = 1 << g.lgMw;
+      const int mode = (Wo % 16 == 0 && Ho % 8 == 0) ? 0 : (Ho == 8 && Wo == 8) ? 1 : (Ho == 4 && Wo == 4) ? 2 : -1;
+      if (mode >= 0) {
+        snprintf(dname, sizeof(dname), "pconv_patchg_128x64_t16_m%d", mode);
+        if (mode == 0) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_g<0>, dim3(nt), dim3(512), g);
+        else if (mode == 1) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_g<1>, dim3(nt), dim3(512), g);
+        else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_g<2>, dim3(nt), dim3(512), g);
+        VF_LAUNCH_CHECK();
+        if (ksplit > 1) {
+          VfProf prof(ctx, slab_st ? "slab_reduce_pconv_bnstats" : "slab_reduce_pconv", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+          return vf_internal_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, g.dmask, g.dact, g.dslope,
+                                         slab_st ? &g.st : nullptr, st_groups);
+        }
+        return 0;
+      }
     }
     static const int env_nbuf = getenv("VF_PG_NBUF") ? atoi(getenv("VF_PG_NBUF")) : 0;
     const bool one_stage = env_nbuf ? env_nbuf == 1 : (t.bm == 128 && nt >= 512);
