@@ -1067,6 +1067,15 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
 // (MODE 0) / (slot >> 1) & 7 (MODE 1, 2): every ds_read_b128 lane group covers the 64 banks once for all sixteen (class, tap)
 // windows (checked exhaustively against MI355X_MICROARCH.md's lane groups; padding lanes read the zero slots at the bank position
 // their out-of-image slot would have had).
+// Measured on E3's forward pass (4.3 GFLOP, 256 tiles of 16 steps; scripts/bench_pconv.py, VF_PG_DBG ablations, one box): 30.7 us against
+// 33.2 for k_pconv_dma; an empty launch of the same shape 9.0, MFMAs alone 25.3, DMAs alone 19.4 (k_pconv_dma: 25.2) — the fill
+// stream is 1.6x shorter, the matrix phase (1.0 us per 24-MFMA step and wave pair, 0.7 of it pipe time) now bounds the tile.  Two
+// role splits between a SIMD's two waves were built on this kernel, bit-identical, and dropped (profiles/r05_*gather*): waves 4-7
+// only fetching and waves 0-3 owning 32 x 64 strips with all 48 MFMAs of their SIMD (33.1 us: one wave per SIMD leaves the pipe idle
+// while it issues its own fragment reads, and four waves store the whole tile); both waves computing but issuing their DMAs at
+// opposite ends of the step — waves 0-3 the weights in front of their MFMAs, waves 4-7 the next unit's patch planes behind theirs
+// (33.0 against 31.4 on one box: no better).  v_mfma_f32_16x16x32_bf16 in place of 32x32x16 (the same cycles; the guide's
+// higher-clock shape) moved the tile by 3-5 % in a timing-only build, not enough to give up bit-identity with the other kernels.
 // Same six-term products in the same K order per output element as k_pconv_dma: bit-identical results.  N % 64 == 0, C % 64 == 0,
 // split-K over channel chunks as k_pconv_dma.  Semantics: nn.SpatialConvolution forward (train.lua:89-101, 183-193) and
 // nn.SpatialFullConvolution's data-gradient (train.lua:134-146).
@@ -1306,7 +1315,9 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   }
   // every DMA has landed and nobody still reads a weight stage when the epilogue's partial sums go there
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  pg_epilogue_at<1, 1, 4, 64, true>(p, acc, red, n0, wm, wn, lane, tid, wave >> 1, bx, ks, 0, 0, true, pre_d, pre_x, pix_of);
+  typedef const float (&pre_t)[1][16];
+  pg_epilogue_at<1, 1, 4, 64, true>(p, acc, red, n0, wm, wn, lane, tid, wave >> 1, bx, ks, 0, 0, true, reinterpret_cast<pre_t>(pre_d),
+                                    reinterpret_cast<pre_t>(pre_x), pix_of);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients from planes
