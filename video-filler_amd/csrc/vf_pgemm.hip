@@ -228,7 +228,7 @@ struct PGemm {
   int dact;
   float dslope;
   int dbg;               // timing experiments only (VF_PG_DBG; wrong results): 1 = no operand loads after the first step,
-                         // 2 = no LDS writes after the first step, 4 = no MFMAs, 8 = no output stores (k_pconv_patch_tr)
+                         // 2 = no LDS writes after the first step, 4 = no MFMAs, 8 = no output stores, 32 = no first stage either (k_pconv_patch_g)
   VfBnSt st;
 };
 
@@ -318,7 +318,7 @@ __device__ __forceinline__ void pg_epilogue_at(const PGemm& p, f32x16 (&acc)[MT]
               st1[nt] += v;
               st2[nt] += v * ((PRE ? pre_x[nt][r] : p.st.x[pix * p.N + n]) - sv[nt]);
             }
-            out[pix * p.N + n] = v;
+            if (!(p.dbg & 8)) out[pix * p.N + n] = v;
           }
         }
       }
@@ -1286,10 +1286,10 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
 
   // ---- main loop: unit = (channel chunk, class), four tap steps each; weights one step ahead, the next unit's hi / mid planes during
   //      steps 0 / 1 into the other patch buffer, its lo plane during step 3 (whose lo fragments were read during step 2)
-  dma_patch_plane(ch0, 0, 0, VfIntC<0>{}, true);
-  dma_patch_plane(ch0, 0, 0, VfIntC<1>{}, true);
-  dma_patch_plane(ch0, 0, 0, VfIntC<2>{}, true);
-  dma_w(ch0, VfIntC<0>{}, 0, true);
+  dma_patch_plane(ch0, 0, 0, VfIntC<0>{}, !(p.dbg & 32));
+  dma_patch_plane(ch0, 0, 0, VfIntC<1>{}, !(p.dbg & 32));
+  dma_patch_plane(ch0, 0, 0, VfIntC<2>{}, !(p.dbg & 32));
+  dma_w(ch0, VfIntC<0>{}, 0, !(p.dbg & 32));
   for (int c = 0; c < cps; ++c) {
     const int ch = ch0 + c;
     asm volatile("" : "+v"(slot_base), "+v"(b_off0), "+s"(rowA), "+s"(colA));
