@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--fuse-adam", default="on", choices=["on", "keep", "off"], help="N=1: optim.adam(fGx) applied to the two bottleneck weight "
                     "tensors inside the kernel that forms their gradient (vf_wgrad_adam_outer: 24 B per weight instead of 32). on (default): "
                     "gradParametersG does not receive those two slices; keep: it does (28 B); off: accGradParameters + the plain update")
-    ap.add_argument("--dp-fused", default="gathered", choices=["gathered", "rows", "reduced"], help="N>1: what becomes of the bottleneck "
+    ap.add_argument("--dp-fused", default="rows", choices=["gathered", "rows", "reduced"], help="N>1: what becomes of the bottleneck "
                     "pair's gradient (262 of G's 284 MB): gathered (default) = every rank all-gathers the pair's OPERANDS (6 MB per rank) and "
                     "forms the global-batch gradient of all rows inside the fused update; rows = the same gather, each rank updates its "
                     "1/N of the rows and the updated rows are all-gathered; reduced = the gradients are all-reduced like the rest")

@@ -429,6 +429,9 @@ int vf_comm_allreduce_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t n, 
  * sharded over the ranks: reduce-scatter the gradient (mean), update 1 / world of the parameters, all-gather them */
 int vf_comm_reduce_scatter_avg_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t shard_count, int* ticket);
 int vf_comm_allgather_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t shard_count, int* ticket);
+/* rank `root`'s buf[0..count) to every rank on the exchange stream (ticketed like the collectives above): the row blocks of a tensor
+ * whose rows do not split evenly over the ranks travel as one broadcast per rank (vf_net_fused_adam_row_range) */
+int vf_comm_broadcast_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t count, int root, int* ticket);
 int vf_comm_wait(vf_comm* c, vf_ctx* ctx, int ticket);
 int vf_comm_allreduce_inline(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int op);
 int vf_comm_broadcast(vf_comm* c, vf_ctx* ctx, void* buf, int64_t count, int dtype, int root);
@@ -541,6 +544,15 @@ int vf_net_adam_fused_gathered(vf_net* net, const float* all_segments, int world
  * every fused tensor's rows and updates them (m, v: those rows only); the host then all-gathers the updated rows of each
  * vf_net_fused_adam_range slice (equal, contiguous row blocks).  vf_net_fused_adam_rows_ok: do the row counts split that way? */
 int vf_net_fused_adam_rows_ok(const vf_net* net, int row_world);
+/* The row blocks: rank r of row_world owns rows [r * bs, min(Nu, (r + 1) * bs)), bs = 2 * ceil(Nu / (2 * row_world)) — equal blocks
+ * where the rows split evenly, a shorter last block where they do not (every block at least 64 rows: vf_net_fused_adam_rows_ok).
+ * vf_net_fused_adam_row_range: that block of fused layer i (of vf_net_set_fused_adam's count) as an element range of the flat vectors. */
+int vf_net_fused_adam_row_range(const vf_net* net, int i, int row_rank, int row_world, int64_t* offset, int64_t* length);
+/* Hiding the exchange of the updated rows: the host issues it on the communicator's stream right after the update (vf_comm_allgather_async
+ * / vf_comm_broadcast_async) and hands the tickets to the net; the NEXT vf_net_forward runs the layers in front of the bottleneck conv
+ * (train.lua:89-104; they read none of those weights) beside the transfer and waits for the tickets in front of the first layer the fused
+ * update takes.  One-shot. */
+int vf_net_forward_wait_fused(vf_net* net, vf_comm* comm, int ticket);
 int vf_net_adam_fused_gathered_rows(vf_net* net, const float* all_segments, int world, int64_t seg_stride, float* m, float* v, double beta1,
                                     double beta2, double eps, const int32_t* t_dev, int keep_grad, int row_rank, int row_world);
 /* SyncBN: BatchNorm sums all-reduced over `comm` (world ranks; statistics of the global batch).  force: take that path at world 1

@@ -4,10 +4,10 @@ about the N > 1 iteration.  Every rank runs the train.lua nets through the C-ABI
   * `on`  : the phased step with the bottleneck pair's OPERANDS all-gathered and the global-batch gradient formed inside the fused
             Adam kernel on every rank (trainers._phase_b / _phase_c, vf_net_fused_adam_pack / vf_net_adam_fused_gathered);
   * `off` : the same step with that pair's gradients all-reduced like the rest;
-  * `rows`: `on` with the fused update SHARDED BY WEIGHT ROWS (trainer.dp_fused = "rows": rank r forms and applies rows
-            [r R / N, (r + 1) R / N) of the pair, the updated rows are all-gathered) — must hold the SAME BITS as `on` in every
-            parameter, and in Adam's moments on this rank's rows (where the row counts do not split over the ranks the trainer keeps
-            the gathered form: then everything is identical).
+  * `rows`: `on` with the fused update SHARDED BY WEIGHT ROWS (trainer.dp_fused = "rows", the default: rank r forms and applies its
+            row block of the pair — equal blocks at 2 ranks, 68 / 68 / 64 of the 200 rows at 3 — and the exchange of the updated
+            blocks opens the NEXT iteration, or flush()) — must hold the SAME BITS as `on` in every parameter after flush(), in
+            Adam's moments on this rank's rows before gather_adam_state() and everywhere after it.
 
 Checked on every rank: the two walk the same trajectory to fp32 rounding (gradients of everything that is still exchanged,
 parameters where the gradient is significant), the fused slices were really left out of the exchange, and the replicas hold the
@@ -35,7 +35,7 @@ B = get_backend()
 b = int(os.environ.get("VF_REHEARSAL_BATCH", "4"))
 # (smooth nets — every (Leaky)ReLU replaced by LeakyReLU(1.0), same graph and kernels: two trajectories that differ by fp32
 #  rounding must not be told apart by an activation that sits at its kink, tests/test_gpu_trainers.py)
-opt = dict(nBottleneck=128, wtl2=0.999, overlapPred=4, nef=32, ngf=32, ndf=32, batchSize=b, smooth=True)
+opt = dict(nBottleneck=200, wtl2=0.999, overlapPred=4, nef=32, ngf=32, ndf=32, batchSize=b, smooth=True)
 gen = torch.Generator().manual_seed(7)
 full = torch.rand((world * b, 3, 128, 128), generator=gen) * 2 - 1          # the same draw on every rank; rank r takes shard r
 shard = full[rank * b:(rank + 1) * b].contiguous()
@@ -49,6 +49,7 @@ def make(mode):
 
 
 on, off, rows = make("on"), make("off"), make("on")
+on.dp_fused = "gathered"
 rows.dp_fused = "rows"
 assert torch.equal(on.parametersG, off.parametersG)
 for _ in range(3):
@@ -81,17 +82,24 @@ def bits(t):
     return int(t.view(torch.int32).to(torch.int64).sum().item())
 
 
-# the row-sharded form against the gathered one: same bits in every parameter; Adam's moments on this rank's rows of the pair and
-# everywhere outside it
-rows_active = rows._dp_rows()
-rows_ok = torch.equal(rows.parametersG, on.parametersG) and torch.equal(rows.parametersD, on.parametersD)
-for key in ("m", "v"):
+# the row-sharded form against the gathered one: before flush() the other ranks' rows of the last update are still owed ...
+rows_active = rows._rows_stale and rows._row_ranges is not None
+own = torch.zeros(n, dtype=torch.bool, device=on.parametersG.device)          # this rank's row blocks of the pair
+for per_rank in (rows._row_ranges or []):
+    own[per_rank[rank][0]:per_rank[rank][1]] = True
+stale_before = bool((rows.parametersG != on.parametersG)[mask & ~own].any()) if rows_active else False
+rows.flush()                                                                     # ... and after it every parameter holds the same bits
+rows_ok = torch.equal(rows.parametersG, on.parametersG) and torch.equal(rows.parametersD, on.parametersD) and not rows._rows_stale
+rows_ok = rows_ok and (stale_before or not rows_active or world == 1)
+blocks = [[hi - lo for lo, hi in per_rank] for per_rank in (rows._row_ranges or [])]
+for key in ("m", "v"):                                                           # Adam's moments: this rank's rows, and everything outside the pair
     a, c = rows.optimStateG[key], on.optimStateG[key]
-    rows_ok = rows_ok and torch.equal(a[~mask], c[~mask])
-    for lo, hi in ranges:
-        per = (hi - lo) // world if rows_active else hi - lo
-        r0 = lo + (rank * per if rows_active else 0)
-        rows_ok = rows_ok and torch.equal(a[r0:r0 + per], c[r0:r0 + per])
+    rows_ok = rows_ok and torch.equal(a[~mask], c[~mask]) and torch.equal(a[own], c[own])
+assert (rows.optimStateG.get("row_shard") == (rank, world)) == rows_active
+rows.gather_adam_state()                                                         # whole again on every rank
+for key in ("m", "v"):
+    rows_ok = rows_ok and torch.equal(rows.optimStateG[key], on.optimStateG[key])
+rows_ok = rows_ok and "row_shard" not in rows.optimStateG
 
 
 sig = torch.tensor([bits(on.parametersG), bits(on.optimStateG["m"]), bits(on.optimStateG["v"]), bits(on.parametersD)], dtype=torch.int64)
@@ -99,8 +107,9 @@ every = [torch.zeros_like(sig) for _ in range(world)]
 dist.all_gather(every, sig)
 same = all(torch.equal(e, every[0]) for e in every)
 line = ("rank %d/%d  batch %d/rank  fused slices %s  gather buffer %d floats  |  on vs off: grad(exchanged part) %.2e  param %.3f lr  "
-        "adam m %.2e  netD %.3f lr  |  replicas bit-identical: %s  |  row-sharded update (%s) == gathered, bit for bit: %s"
-        % (rank, world, b, ranges, on._opbuf.numel(), err_g, err_p, err_m, err_d, same, "active" if rows_active else "rows do not split: gathered", rows_ok))
+        "adam m %.2e  netD %.3f lr  |  replicas bit-identical: %s  |  row-sharded update (%s; row blocks %s) == gathered, bit for bit: %s"
+        % (rank, world, b, ranges, on._opbuf.numel(), err_g, err_p, err_m, err_d, same, "active" if rows_active else "rows do not split: gathered",
+           blocks, rows_ok))
 print(line, flush=True)
 ok = err_g < 1e-4 and err_p < 0.05 and err_m < 1e-3 and same and rows_ok
 if not ok:

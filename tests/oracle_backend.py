@@ -89,11 +89,12 @@ class OracleBackend:
         self.scale_shift(t, 1.0 / world, 0.0)
         return t[rank * n:(rank + 1) * n]
 
-    def all_gather_shards(self, t, world, rank, group=None):
+    def all_gather_shards(self, t, world, rank, group=None, async_op=False):
         import torch.distributed as dist
         n = t.numel() // world
         parts = [t[r * n:(r + 1) * n] for r in range(world)]
         dist.all_gather(parts, parts[rank].clone(), group=group)
+        return None
 
     def copy(self, dst, src):
         dst.copy_(src)
@@ -324,9 +325,130 @@ class OracleBackend:
         c.setMask(np.ascontiguousarray(mask_u8.contiguous().numpy()))
         _put(gx, c.backward(_np(x), _np(xhat)))
 
+    # the two halves of adam_step, as the HIP backend splits them (optim.adam_update_fused / adam_update_split)
+    def adam_prep(self, lr, beta1, beta2, t_dev):
+        t_dev[0] += 1
+        self._adam_lr = float(lr)
+
+    def adam_apply(self, x, g, m, v, beta1, beta2, eps, t_dev):
+        xa, ga, ma, va = x.numpy(), np.ascontiguousarray(g.numpy()), m.numpy(), v.numpy()
+        assert xa.flags["C_CONTIGUOUS"] and ma.flags["C_CONTIGUOUS"] and va.flags["C_CONTIGUOUS"]
+        self.lib.vfo_adam_step(O._p(xa), O._p(ga), O._p(ma), O._p(va), None, C.c_size_t(xa.size), C.c_double(self._adam_lr),
+                               C.c_double(beta1), C.c_double(beta2), C.c_double(eps), int(t_dev[0]))
+
+    def all_gather_ranges(self, t, ranges, rank, group=None, async_op=False):
+        """HipBackend.all_gather_ranges over a process group: equal adjacent blocks as one all-gather, a ragged split as one broadcast
+        per rank; async_op returns the handles still in flight"""
+        import torch.distributed as dist
+        world = len(ranges)
+        lens = [hi - lo for lo, hi in ranges]
+        if len(set(lens)) == 1 and all(ranges[r + 1][0] == ranges[r][1] for r in range(world - 1)):
+            self.all_gather_shards(t[ranges[0][0]:ranges[-1][1]], world, rank, group)
+            return []
+        hs = [dist.broadcast(t[lo:hi], src=r, group=group, async_op=True) for r, (lo, hi) in enumerate(ranges) if hi > lo]
+        if async_op:
+            return hs
+        for h in hs:
+            h.wait()
+        return []
+
     # adam: element-wise, so the physical order of x does not matter
     def adam_step(self, x, g, m, v, lr, beta1, beta2, eps, t_dev):
         t_dev[0] += 1
         xa, ga, ma, va = x.numpy(), g.numpy(), m.numpy(), v.numpy()
         self.lib.vfo_adam_step(O._p(xa), O._p(ga), O._p(ma), O._p(va), None, C.c_size_t(xa.size), C.c_double(lr),
                                C.c_double(beta1), C.c_double(beta2), C.c_double(eps), int(t_dev[0]))
+
+
+# ------------------------------------------------------------------------------------------------ fused-Adam protocol, test double
+def install_fused_adam_emulation(min_rows=2):
+    """A TEST DOUBLE of cnet.CNet's fused-Adam protocol (set_fused_adam / fused_adam_pack / adam_fused[_gathered] / row ranges) on the
+    module-by-module host, so that the trainers' data-parallel HOST LOGIC for it — which slices stay out of the gradient exchange, what
+    is gathered instead, the row blocks of the sharded update (ragged ones included), the deferred exchange of the updated rows, the
+    marks on the optimiser state — runs under gloo on the CPU.  What travels in a rank's segment here is its LOCAL weight gradient of
+    the two bottleneck tensors (the mean over the segments is the global-batch gradient, as the mean of the ranks' operand products is);
+    the kernel that forms that gradient from the gathered operands is covered on the GPU (tests/test_gpu_fused_adam.py,
+    tests/test_gpu_dp_rehearsal.py).  min_rows: the library deals row blocks of at least 64; the CPU suite's nets have 32 rows."""
+    from video_filler_amd import nn
+    from video_filler_amd.backend import get_backend
+    S = nn.Sequential
+    pad4 = lambda n: (n + 3) & ~3
+
+    def _layers(self):
+        out = []
+        for m, name, gname, o, n in self._flat[2]:
+            if name == "weight" and isinstance(m, nn.SpatialConvolution) and m.kH == 4 and m.dH == 1 and m.padH == 0:
+                out.append((o, n, m.nInputPlane if m._is_full else m.nOutputPlane))
+        return out
+
+    def set_fused_adam(self, on=True):
+        self._fa_layers = _layers(self) if on else []
+        self._fused_ranges = [(o, o + n) for o, n, _ in self._fa_layers]
+        return list(self._fused_ranges)
+
+    def fused_adam_ranges(self):
+        return list(getattr(self, "_fused_ranges", []))
+
+    def fused_adam_pack_size(self):
+        return sum(pad4(n) for _, n, _ in self._fa_layers)
+
+    def fused_adam_pack(self, segment):
+        g, pos = self._flat[1], 0
+        for o, n, _ in self._fa_layers:
+            segment[pos:pos + n].copy_(g[o:o + n])
+            g[o:o + n].zero_()              # (the real kernel never writes these slices)
+            pos += pad4(n)
+
+    def _block(Nu, r, world):
+        bs = 2 * ((Nu + 2 * world - 1) // (2 * world))
+        r0 = min(Nu, r * bs)
+        return r0, min(Nu, r0 + bs) - r0
+
+    def fused_adam_rows_ok(self, ranks):
+        ls = _layers(self)
+        return bool(ls) and all(_block(Nu, ranks - 1, ranks)[1] >= min_rows for _, _, Nu in ls)
+
+    def fused_adam_row_ranges(self, ranks):
+        out = []
+        for o, n, Nu in self._fa_layers:
+            nc = n // Nu
+            out.append([(o + _block(Nu, r, ranks)[0] * nc, o + (_block(Nu, r, ranks)[0] + _block(Nu, r, ranks)[1]) * nc) for r in range(ranks)])
+        return out
+
+    def _apply(self, grads, m, v, b1, b2, eps, t_dev, keep, rows):
+        B = get_backend()
+        x, gflat = self._flat[0], self._flat[1]
+        for (o, n, Nu), g in zip(self._fa_layers, grads):
+            lo, hi = o, o + n
+            if rows is not None:
+                r0, nr = _block(Nu, rows[0], rows[1])
+                nc = n // Nu
+                lo, hi = o + r0 * nc, o + (r0 + nr) * nc
+            B.adam_apply(x[lo:hi], g[lo - o:hi - o], m[lo:hi], v[lo:hi], b1, b2, eps, t_dev)
+            if keep:
+                gflat[lo:hi].copy_(g[lo - o:hi - o])
+
+    def adam_fused(self, m, v, b1, b2, eps, t_dev, keep_grad=False):
+        g = self._flat[1]
+        grads = [g[o:o + n].clone() for o, n, _ in self._fa_layers]
+        if not keep_grad:
+            for o, n, _ in self._fa_layers:
+                g[o:o + n].zero_()
+        _apply(self, grads, m, v, b1, b2, eps, t_dev, keep_grad, None)
+
+    def adam_fused_gathered(self, all_segments, world, m, v, b1, b2, eps, t_dev, keep_grad=False, rows=None):
+        seg = all_segments.numel() // world
+        grads, pos = [], 0
+        for o, n, _ in self._fa_layers:
+            acc = all_segments[pos:pos + n].clone()
+            for r in range(1, world):
+                acc += all_segments[r * seg + pos:r * seg + pos + n]
+            grads.append(acc * (1.0 / world))
+            pos += pad4(n)
+        _apply(self, grads, m, v, b1, b2, eps, t_dev, keep_grad, rows)
+
+    for name, fn in dict(set_fused_adam=set_fused_adam, fused_adam_ranges=fused_adam_ranges, fused_adam_pack_size=fused_adam_pack_size,
+                         fused_adam_pack=fused_adam_pack, fused_adam_rows_ok=fused_adam_rows_ok, fused_adam_row_ranges=fused_adam_row_ranges,
+                         adam_fused=adam_fused, adam_fused_gathered=adam_fused_gathered).items():
+        setattr(S, name, fn)
+    S.fused_adam_emulated = True

@@ -166,3 +166,51 @@ def test_torch_distributed_fallback_collectives_stay_on_the_device(hipb):
         B.comm = saved
         if own:
             dist.destroy_process_group()
+
+
+
+def test_row_exchange_waits_in_front_of_the_bottleneck_conv(hipb):
+    """the rows another rank updated arrive by a collective on the exchange stream, and the generator's next forward
+    waits for it in front of its bottleneck conv only (vf_net_forward_wait_fused; train.lua:89-104: E1 ... E5 read none of those rows).
+    One rank: an all-gather of one block and a broadcast (the ragged form) of the two fused slices are the identity — the forward with
+    the tickets armed must equal the plain one, consume the tickets, and be capturable in one graph with the collectives it waits for."""
+    from video_filler_amd.cnet import adopt_if_chain
+    from video_filler_amd.trainers import build_netG, weights_init
+    B = attach_world1_comm(hipb)
+    net = build_netG(3, 3, 16, 16, 96, False)
+    weights_init(net, torch.Generator().manual_seed(5))
+    net = adopt_if_chain(net)
+    assert type(net).__name__ == "CNet"
+    flat, _ = net.getParameters()
+    net.evaluate()       # (training-mode forwards shift their BatchNorm sums by the running mean, which moves: not bit-repeatable)
+    x = torch.rand((4, 3, 128, 128), generator=torch.Generator().manual_seed(6)).to(B.device).contiguous(memory_format=torch.channels_last) * 2 - 1
+    want = net.forward(x).clone()
+    slices = net.set_fused_adam(True)
+    assert len(slices) == 2 and net.fused_adam_rows_ok(1)
+    ranges = net.fused_adam_row_ranges(1)
+    assert [r[0] for r in ranges] == slices                      # one rank owns every row
+    net.set_fused_adam(False)
+
+    def exchange_and_forward():
+        hs = []
+        hs += B.all_gather_ranges(flat, [ranges[0][0]], 0, async_op=True)                       # equal blocks: an all-gather
+        t = C.c_int32(-1)
+        lo, hi = ranges[1][0]                                                                   # ragged blocks: one broadcast per rank
+        assert B.lib.vf_comm_broadcast_async(B.comm, B.ctx, C.c_void_p(flat[lo:hi].data_ptr()), hi - lo, 0, C.byref(t)) == 0
+        tickets = [h.ticket for h in hs] + [t.value]
+        net.forward_wait_fused(B.comm, tickets)
+        return net.forward(x)
+    got = exchange_and_forward().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(net.forward(x), want)                     # (the tickets were one-shot)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        B.use_current_stream()
+        out = exchange_and_forward()
+    B.use_current_stream()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert B.lib.vf_net_forward_wait_fused(net._net, None, 0) != 0 and b"bad argument" in B.lib.vf_last_error()

@@ -34,9 +34,11 @@ def test_gathered_operand_exchange_with_real_ranks(world):
     # (every rank exits non-zero on a failed check and torchrun passes that on; the ranks' lines may interleave on the shared stdout)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-6000:])
     assert r.stdout.count("replicas bit-identical: True") == world, r.stdout[-2000:]
-    # the update sharded by weight rows (2 ranks: active; 3 ranks: 128 rows do not split, the trainer keeps the gathered form)
+    # the update sharded by weight rows: active at both world sizes — 200 rows are 100 / 100 at 2 ranks and a ragged 68 / 68 / 64 at 3
     assert r.stdout.count("== gathered, bit for bit: True") == world, r.stdout[-2000:]
-    assert ("row-sharded update (active)" in r.stdout) == (world == 2), r.stdout[-2000:]
+    assert r.stdout.count("row-sharded update (active") == world, r.stdout[-2000:]
+    # (blocks in elements of the flat vector: 4096 columns per row at ngf = 32)
+    assert ("[409600, 409600]" in r.stdout) == (world == 2) and ("[278528, 278528, 262144]" in r.stdout) == (world == 3), r.stdout[-2000:]
     lines = [r.stdout]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "dp_rehearsal_%d.log" % world), "w") as fh:

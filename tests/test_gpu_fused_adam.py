@@ -91,7 +91,8 @@ def test_gathered_operands_give_the_mean_gradient_of_the_ranks(world, K, Nu, Nco
     assert torch.equal(x1, x2) and torch.equal(m1, m2) and torch.equal(v1, v2)
 
 
-@pytest.mark.parametrize("world,K,Nu,Ncols", [(2, 4, 256, 128), (4, 16, 512, 256), (8, 8, 4000, 1024)])
+@pytest.mark.parametrize("world,K,Nu,Ncols", [(2, 4, 256, 128), (4, 16, 512, 256), (8, 8, 4000, 1024),
+                                              (3, 4, 200, 128), (3, 8, 4000, 256), (6, 4, 4000, 128), (7, 4, 1000, 128)])      # ragged row blocks
 def test_update_sharded_by_weight_rows_equals_the_whole_tensor_update(world, K, Nu, Ncols, hipb):
     """data parallel without redoing the work N times: rank r forms the global-batch gradient of rows
     [r Nu / N, (r + 1) Nu / N) only and updates them; the row blocks of all ranks together are, BIT FOR BIT, the whole-tensor
@@ -110,15 +111,22 @@ def test_update_sharded_by_weight_rows_equals_the_whole_tensor_update(world, K, 
     x2, m2, v2, t2 = _state(hipb, n, 9)
     g2 = torch.zeros(n, device=hipb.device)
     hipb.adam_prep(lr, b1, b2, t2)
-    rows = Nu // world
+    # the library's row blocks (vf_net_fused_adam_row_range): even blocks of 2 * ceil(Nu / (2 world)) rows, a shorter last one where
+    # the rows do not split (200 rows over 3 ranks: 68, 68, 64; 4000 over 3: 1334, 1334, 1332)
+    bs = 2 * ((Nu + 2 * world - 1) // (2 * world))
     x0 = x2.clone()
+    covered = 0
     for r in range(world):       # every virtual rank updates its row block of the shared tensors
-        hipb.wgrad_adam_outer_rows(buf, u_off, v_off, world, K, seg, Nu, Ncols, r * rows, rows, x2, m2, v2, g2, b1, b2, eps, t2)
-        lo, hi = r * rows * Ncols, (r + 1) * rows * Ncols
-        assert torch.equal(x2[hi:], x0[hi:]), "rank %d wrote past its rows" % r
+        r0 = min(Nu, r * bs)
+        rows = min(Nu, r0 + bs) - r0
+        assert rows >= 64 and r0 == covered
+        hipb.wgrad_adam_outer_rows(buf, u_off, v_off, world, K, seg, Nu, Ncols, r0, rows, x2, m2, v2, g2, b1, b2, eps, t2)
+        covered = r0 + rows
+        assert torch.equal(x2[covered * Ncols:], x0[covered * Ncols:]), "rank %d wrote past its rows" % r
+    assert covered == Nu
     assert torch.equal(x1, x2) and torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(g1, g2)
     with pytest.raises(Exception, match="rows"):
-        hipb.wgrad_adam_outer_rows(buf, u_off, v_off, world, K, seg, Nu, Ncols, 1, rows, x2, m2, v2, None, b1, b2, eps, t2)
+        hipb.wgrad_adam_outer_rows(buf, u_off, v_off, world, K, seg, Nu, Ncols, 1, bs, x2, m2, v2, None, b1, b2, eps, t2)
 
 
 def test_adam_over_several_ranges_in_one_launch(hipb):

@@ -111,6 +111,7 @@ SIGNATURES = {
     "vf_comm_allreduce_avg_async": (i32, [vp, vp, vp, i64, C.POINTER(i32)]),
     "vf_comm_reduce_scatter_avg_async": (i32, [vp, vp, vp, i64, C.POINTER(i32)]),
     "vf_comm_allgather_async": (i32, [vp, vp, vp, i64, C.POINTER(i32)]),
+    "vf_comm_broadcast_async": (i32, [vp, vp, vp, i64, i32, C.POINTER(i32)]),
     "vf_comm_wait": (i32, [vp, vp, i32]),
     "vf_comm_allreduce_inline": (i32, [vp, vp, vp, i64, i32, i32]),
     "vf_comm_broadcast": (i32, [vp, vp, vp, i64, i32, i32]),
@@ -150,6 +151,8 @@ SIGNATURES = {
     "vf_net_fused_adam_pack": (i32, [vp, vp]),
     "vf_net_adam_fused_gathered": (i32, [vp, vp, i32, i64, vp, vp, f64, f64, f64, vp, i32]),
     "vf_net_fused_adam_rows_ok": (i32, [vp, i32]),
+    "vf_net_fused_adam_row_range": (i32, [vp, i32, i32, i32, C.POINTER(i64), C.POINTER(i64)]),
+    "vf_net_forward_wait_fused": (i32, [vp, vp, i32]),
     "vf_net_adam_fused_gathered_rows": (i32, [vp, vp, i32, i64, vp, vp, f64, f64, f64, vp, i32, i32, i32]),
     "vf_net_set_sync_bn": (i32, [vp, vp, i32, i32]),
     "vf_net_set_weight_planes_managed": (i32, [vp, i32]),

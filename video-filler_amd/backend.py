@@ -396,6 +396,38 @@ class HipBackend:
         dist.all_gather(parts, parts[rank].clone(), group=group)
         return None
 
+    def all_gather_ranges(self, t, ranges, rank, group=None, async_op=False):
+        """rank r's block t[ranges[r][0] : ranges[r][1]] of the flat fp32 tensor t to every rank, in place — the row blocks of a weight
+        tensor after an update sharded by rows (vf_net_fused_adam_row_range).  Equal, adjacent blocks travel as ONE all-gather; a ragged
+        split (4000 rows over 3 ranks) as one broadcast per rank.  -> handles in flight (async_op; wait() orders this backend's stream
+        behind them), [] when done."""
+        world = len(ranges)
+        lens = [hi - lo for lo, hi in ranges]
+        if len(set(lens)) == 1 and all(ranges[r + 1][0] == ranges[r][1] for r in range(world - 1)):
+            h = self.all_gather_shards(t[ranges[0][0]:ranges[-1][1]], world, rank, group, async_op=async_op)
+            return [h] if h is not None else []
+        hs = []
+        for r, (lo, hi) in enumerate(ranges):
+            if hi <= lo:
+                continue
+            blk = t[lo:hi]
+            assert blk.is_contiguous() and blk.dtype == torch.float32
+            if self.comm is not None:
+                ticket = C.c_int32(-1)
+                _lib.check(self.lib.vf_comm_broadcast_async(self.comm, self.ctx, _ptr(blk), hi - lo, r, C.byref(ticket)))
+                hs.append(_CommHandle(self, ticket.value))
+            else:
+                import torch.distributed as dist
+                src = r if group is None else dist.get_global_rank(group, r)
+                h = dist.broadcast(blk, src=src, group=group, async_op=async_op)
+                if async_op and h is not None:
+                    hs.append(h)
+        if not async_op:
+            for h in hs:
+                h.wait()
+            return []
+        return hs
+
     def _c(self, name, *args):
         _lib.check(getattr(self.lib, name)(self.ctx, *args))
 

@@ -261,8 +261,29 @@ class CNet(nn.Sequential):
             _lib.check(_lib.load().vf_net_adam_fused_gathered_rows(*args, int(rows[0]), int(rows[1])))
 
     def fused_adam_rows_ok(self, ranks):
-        """do the fused tensors' row counts split evenly (and in even numbers) over `ranks`?"""
+        """can the fused tensors' rows be dealt to `ranks` ranks in blocks of at least 64 (even blocks; a shorter last one where the
+        row count does not split)?"""
         return self._net is not None and bool(_lib.load().vf_net_fused_adam_rows_ok(self._net, int(ranks)))
+
+    def fused_adam_row_ranges(self, ranks):
+        """per marked layer (set_fused_adam(True) first): [(lo, hi)] of the flat vectors, rank by rank — the row block each rank updates
+        under adam_fused_gathered(rows=...) and everybody gathers afterwards"""
+        lib = _lib.load()
+        out = []
+        for i in range(len(self.fused_adam_ranges())):
+            per = []
+            for r in range(ranks):
+                o, n = C.c_int64(), C.c_int64()
+                _lib.check(lib.vf_net_fused_adam_row_range(self._net, i, r, int(ranks), C.byref(o), C.byref(n)))
+                per.append((o.value, o.value + n.value))
+            out.append(per)
+        return out
+
+    def forward_wait_fused(self, comm, tickets):
+        """the next forward waits for these collectives of `comm` (vf_comm_* tickets) in front of its bottleneck conv instead of at its
+        start: the layers before it read none of the rows the collectives deliver"""
+        for t in tickets:
+            _lib.check(_lib.load().vf_net_forward_wait_fused(self._net, comm, int(t)))
 
     def backward_finish(self):
         if self._net is not None:

@@ -222,6 +222,22 @@ VF_API int vf_comm_allgather_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t 
   return 0;
 }
 
+// rank `root`'s buf[0..count) to every rank, on the exchange stream (same discipline as vf_comm_allgather_async).  The row blocks of a
+// tensor whose rows do NOT split evenly over the ranks (vf_net_fused_adam_row_range) travel as one such broadcast per rank, where
+// equal blocks travel as one all-gather.
+VF_API int vf_comm_broadcast_async(vf_comm* c, vf_ctx* ctx, float* buf, int64_t count, int root, int* ticket) {
+  VF_REQUIRE(c != nullptr && ctx != nullptr && ticket != nullptr, "vf_comm_broadcast_async: NULL argument");
+  VF_REQUIRE(root >= 0 && root < c->world && count >= 0 && (count == 0 || buf != nullptr), "vf_comm_broadcast_async: root %d of %d, %lld floats",
+             root, c->world, (long long)count);
+  VF_CHECK_HIP(hipEventRecord(c->ready, ctx->stream));
+  VF_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+  if (count > 0) VF_CHECK_RCCL(g_rccl.Broadcast(buf, buf, (size_t)count, ncclFloat32, root, c->comm, c->stream));
+  const int t = (int)(c->issued++ % RING);
+  VF_CHECK_HIP(hipEventRecord(c->done[t], c->stream));
+  *ticket = t;
+  return 0;
+}
+
 // the context's stream waits (on the device; the host does not block) for collective `ticket` — and, the exchange stream
 // being in order, for every collective issued before it
 VF_API int vf_comm_wait(vf_comm* c, vf_ctx* ctx, int ticket) {

@@ -162,6 +162,8 @@ struct vf_net {
   std::map<const vf_net*, BothTable> both_tables;
   bool fused_adam = false;         // vf_net_set_fused_adam
   std::vector<int> fa_layers;
+  vf_comm* fwd_wait_comm = nullptr;     // vf_net_forward_wait_fused: collectives the next forward waits for in front of its first
+  std::vector<int> fwd_wait_tickets;    // bottleneck layer (one-shot)
   bool split_pending = false;      // vf_net_backward_split ran: the gradients of the entries below the cut are still recorded
   std::string pending_bias;        // (their deferred bias gradients, as a byte image of Deferred[])
   std::vector<void*> owned;        // parameter-lifetime allocations
@@ -1100,6 +1102,7 @@ VF_API int vf_net_bucket_split(const vf_net* n, double frac, int* plan_index, in
   return 0;
 }
 
+static bool fused_adam_shape(const Layer& l);
 VF_API int vf_net_forward(vf_net* n, const float* x, const float** y) {
   VF_REQUIRE(n && x, "vf_net_forward: NULL argument");
   vf_ctx* ctx = n->ctx;
@@ -1114,6 +1117,13 @@ VF_API int vf_net_forward(vf_net* n, const float* x, const float** y) {
     Layer& l = n->L[e.main];
     Layer* nxt = idx + 1 < np ? &n->L[n->plan[idx + 1].main] : nullptr;
     int rc = 0;
+    if (!n->fwd_wait_tickets.empty() && (fused_adam_shape(l) || idx + 1 == np)) {
+      // vf_net_forward_wait_fused: the parameter rows other ranks updated must have arrived before the first layer that reads them
+      for (int t : n->fwd_wait_tickets)
+        if ((rc = vf_comm_wait(n->fwd_wait_comm, ctx, t))) return rc;
+      n->fwd_wait_tickets.clear();
+      n->fwd_wait_comm = nullptr;
+    }
     if (is_conv(l)) {
       if (l.fused_act == VF_ACT_NONE && nxt && nxt->d.kind == VF_L_BN && bn_fusable(n, *nxt) && nxt->d.nout == l.Co) {
         // the BatchNorm behind this convolution gets its statistics from the convolution's own epilogue
@@ -1210,6 +1220,15 @@ VF_API int vf_net_fused_adam_range(const vf_net* n, int i, int64_t* offset, int6
   return 0;
 }
 static int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+// the update sharded by weight rows: rank r of `world` owns rows [r * bs, min(Nu, (r + 1) * bs)), bs = 2 * ceil(Nu / (2 * world)) — even
+// blocks (the fused kernel's lanes own row pairs), equal wherever Nu splits, a shorter last block where it does not (4000 rows over
+// 3 ranks: 1334, 1334, 1332)
+static void fused_row_block(int Nu, int rank, int world, int* row0, int* nrows) {
+  const int bs = 2 * ((Nu + 2 * world - 1) / (2 * world));
+  const int r0 = std::min(Nu, rank * bs), r1 = std::min(Nu, r0 + bs);
+  *row0 = r0;
+  *nrows = r1 - r0;
+}
 // row_world > 1: this rank forms and applies rows [row_rank * Nu / row_world, (row_rank + 1) * Nu / row_world) of every fused tensor only
 static int fused_layers_launch(vf_net* n, const float* all, int world, int64_t seg_stride, float* m, float* v, double beta1, double beta2,
                                double eps, const int32_t* t_dev, int keep_grad, int row_rank = 0, int row_world = 1) {
@@ -1246,11 +1265,13 @@ static int fused_layers_launch(vf_net* n, const float* all, int world, int64_t s
     L.kps = l.fa_k; L.seg = all ? seg_stride : 0; L.gscale = 1.f / (float)world;
     L.row0 = 0; L.ldu = 0;
     if (row_world > 1) {
-      VF_REQUIRE(Nu % (2 * row_world) == 0 && Nu / row_world >= 64, "vf_net_adam_fused_gathered_rows: %d rows do not split over %d ranks", Nu,
-                 row_world);
+      int r0, nr;
+      fused_row_block(Nu, row_rank, row_world, &r0, &nr);
+      VF_REQUIRE(nr >= 64, "vf_net_adam_fused_gathered_rows: %d rows do not split over %d ranks (rank %d would hold %d; at least 64)", Nu,
+                 row_world, row_rank, nr);
       L.ldu = Nu;
-      L.Nu = Nu / row_world;
-      L.row0 = row_rank * L.Nu;
+      L.Nu = nr;
+      L.row0 = r0;
     }
     l.fa_k = 0;
   }
@@ -1307,10 +1328,35 @@ VF_API int vf_net_fused_adam_rows_ok(const vf_net* n, int row_world) {
   for (const Layer& l : n->L) {       // (the layers vf_net_set_fused_adam would mark, whether or not they are marked right now)
     if (!fused_adam_shape(l)) continue;
     const int Nu = is_full(l) ? l.C : l.Co;
-    if (Nu % (2 * row_world) != 0 || Nu / row_world < 64) return 0;
+    int r0, nr;
+    fused_row_block(Nu, row_world - 1, row_world, &r0, &nr);      // (the last rank's block is the shortest)
+    if (nr < 64) return 0;
     ++cnt;
   }
   return cnt > 0;
+}
+// rank `row_rank`'s row block of fused layer i as an element range of the flat vectors (what the host all-gathers after the update)
+VF_API int vf_net_fused_adam_row_range(const vf_net* n, int i, int row_rank, int row_world, int64_t* offset, int64_t* length) {
+  VF_REQUIRE(n && offset && length && i >= 0 && i < (int)n->fa_layers.size() && row_world >= 1 && row_rank >= 0 && row_rank < row_world,
+             "vf_net_fused_adam_row_range: bad argument");
+  const Layer& l = n->L[n->fa_layers[i]];
+  const bool full = is_full(l);
+  const int Nu = full ? l.C : l.Co, Cv = full ? l.Co : l.C;
+  int r0, nr;
+  fused_row_block(Nu, row_rank, row_world, &r0, &nr);
+  *offset = l.w_off + (int64_t)r0 * 16 * Cv;
+  *length = (int64_t)nr * 16 * Cv;
+  return 0;
+}
+// The rows another rank updated arrive by a collective the host issued on the communicator's stream (vf_comm_allgather_async /
+// vf_comm_broadcast_async tickets).  Nothing in front of the bottleneck conv reads them (train.lua:89-104: E1 ... E5), so the next
+// vf_net_forward runs up to there beside the transfer and waits for the tickets in front of the first layer the fused update takes.
+VF_API int vf_net_forward_wait_fused(vf_net* n, vf_comm* comm, int ticket) {
+  VF_REQUIRE(n && comm && ticket >= 0, "vf_net_forward_wait_fused: bad argument");
+  VF_REQUIRE(n->fwd_wait_comm == nullptr || n->fwd_wait_comm == comm, "vf_net_forward_wait_fused: tickets of two communicators");
+  n->fwd_wait_comm = comm;
+  n->fwd_wait_tickets.push_back(ticket);
+  return 0;
 }
 VF_API int vf_net_adam_fused_gathered_rows(vf_net* n, const float* all, int world, int64_t seg_stride, float* m, float* v, double beta1,
                                            double beta2, double eps, const int32_t* t_dev, int keep_grad, int row_rank, int row_world) {

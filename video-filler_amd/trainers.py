@@ -18,7 +18,7 @@ import os
 import torch
 
 from . import data, nn, optim
-from .backend import get_backend, to_nhwc
+from .backend import bump_param_version, get_backend, to_nhwc
 
 DEFAULT_OPT_TRAIN = dict(batchSize=64, fineSize=128, nBottleneck=100, nef=64, ngf=64, ndf=64, nc=3, wtl2=0.0,
                          overlapPred=0, lr=0.0002, beta1=0.5, nz=100, conditionAdv=False, noiseGen=False,
@@ -275,10 +275,15 @@ class _TrainerBase:
         #   "rows"                the same gather, but rank r forms and applies rows [r R / N, (r + 1) R / N) only (2 B flops per weight
         #                         again, Adam traffic / N), then the updated rows are all-gathered (131 MB per tensor)
         #   "reduced"             the pair's gradients are all-reduced like everything else (fuse_adam off under data parallelism)
-        self.dp_fused = os.environ.get("VF_DP_FUSED", "gathered")
+        #   Default since round 5: "rows" — it does strictly less work than "gathered", and its row exchange is issued at the top of the NEXT
+        #   iteration, on the communicator's stream, with the wait in front of the generator's bottleneck conv (E1 ... E5 read none of
+        #   those rows); where a tensor's rows cannot be dealt in blocks of >= 64 the trainer keeps the gathered form for that step.
+        self.dp_fused = os.environ.get("VF_DP_FUSED", "rows")
         assert self.dp_fused in ("gathered", "rows", "reduced"), "VF_DP_FUSED: gathered | rows | reduced"
         self._dpf = []               # phased data-parallel step: the fused slices of this iteration (set in phase B)
         self._opbuf = None           # ... and the gather buffer of their operands: world segments
+        self._row_ranges = None      # rows mode: per fused slice, the (lo, hi) block of every rank (cnet.fused_adam_row_ranges)
+        self._rows_stale = False     # rows mode: phase C updated this rank's rows only and the exchange of the row blocks is still owed
         self.defer_adam_g = False
         self.adam_overlap = False    # enable_adam_overlap(): Adam(G)'s two big weight tensors beside the next encoder forward
         self.side_a = None
@@ -440,15 +445,57 @@ class _TrainerBase:
         from .cnet import CNet
         if dp is None:
             dp = self._comm_on()
-        ok = (self.fuse_adam != "off" and isinstance(self.netG, CNet) and self.netG._net is not None and not self.shard_adam
-              and not self.defer_adam_g and not self.adam_overlap)
+        # (the library's net object; `fused_adam_emulated`: a test double of the same protocol on a host without the kernel — tests/)
+        hosted = (isinstance(self.netG, CNet) and self.netG._net is not None) or getattr(self.netG, "fused_adam_emulated", False)
+        ok = (self.fuse_adam != "off" and hosted and not self.shard_adam and not self.defer_adam_g and not self.adam_overlap)
         if dp and self.dp_fused == "reduced":
             return False
         return ok and (self._comm_on() and not self._pipelined if dp else not self._comm_on())
 
     def _dp_rows(self):
-        """the row-sharded form of the data-parallel fused update: asked for, and the tensors' rows split evenly over the ranks"""
-        return self.dp_fused == "rows" and self.world > 1 and bool(self._dpf) and self.netG.fused_adam_rows_ok(self.world)
+        """the row-sharded form of the data-parallel fused update: asked for, and every rank can be dealt a block of >= 64 rows of each
+        fused tensor.  Adam's m and v of the fused slices are then current in this rank's rows ONLY, which optimStateG records
+        (`row_shard` = (rank, world)): continuing in another mode or world size on such a state would silently use stale moments for
+        (N - 1) / N of 92 % of the generator's weights — refused until gather_adam_state() has made them whole."""
+        rows = self.dp_fused == "rows" and self.world > 1 and bool(self._dpf) and self.netG.fused_adam_rows_ok(self.world)
+        mark = self.optimStateG.get("row_shard")
+        if mark is not None and (not rows or tuple(mark) != (self.rank, self.world)) and bool(self._dpf):
+            raise RuntimeError("optimStateG holds Adam moments sharded by weight rows for rank %d of %d; this step would run as %s on rank "
+                               "%d of %d: call gather_adam_state() first" % (mark[0], mark[1], "rows" if rows else self.dp_fused, self.rank, self.world))
+        return rows
+
+    def _exchange_rows(self, defer):
+        """rows mode: every rank's updated row block of the fused slices to everybody.  defer: issued on the exchange stream, the
+        generator's next forward waits for it in front of its bottleneck conv (vf_net_forward_wait_fused) — its first five convolutions
+        run beside the transfer; a host without that hook (the module-by-module mirror, a process group instead of vf_comm_*) waits
+        here.  Captured phase graphs cannot wait for an event recorded outside their capture: they wait here too."""
+        B = get_backend()
+        hs = []
+        for per_rank in self._row_ranges or []:
+            hs += B.all_gather_ranges(self.parametersG, per_rank, self.rank, self.group, async_op=True)
+        self._rows_stale = False
+        comm = getattr(B, "comm", None)
+        tickets = [h.ticket for h in hs if hasattr(h, "ticket")]
+        hook = defer and comm is not None and self._graphs is None and hasattr(self.netG, "forward_wait_fused") and len(tickets) == len(hs)
+        if hook:
+            self.netG.forward_wait_fused(comm, tickets)
+        else:
+            for h in hs:
+                h.wait()
+        if hs or self._row_ranges:
+            bump_param_version(self.parametersG)
+        return hook
+
+    def gather_adam_state(self):
+        """after steps in rows mode Adam's m and v of the fused slices are current in each rank's own rows only; this makes them whole
+        on every rank (2 x 262 MB on the wire for train.lua's generator: for checkpoints of the optimiser and mode changes, not per step)"""
+        if self.optimStateG.get("row_shard") is None:
+            return
+        B = get_backend()
+        for key in ("m", "v"):
+            for per_rank in self._row_ranges or []:
+                B.all_gather_ranges(self.optimStateG[key], per_rank, self.rank, self.group)
+        del self.optimStateG["row_shard"]
 
     def _fuse_adam_ranges(self):
         """marks netG's bottleneck pair for the fused update when step() may use it; the slices it covers (empty: plain update)"""
@@ -524,7 +571,10 @@ class _TrainerBase:
 
     def flush(self):
         """Apply a deferred Adam(G).  A captured graph always begins with that update, so after a flush the graph
-        must not be replayed again (capture anew instead)."""
+        must not be replayed again (capture anew instead).  Rows mode: the exchange of the last iteration's row blocks, which the next
+        iteration would have started with (replays after it are fine: they begin with an exchange of identical rows)."""
+        if self._rows_stale:
+            self._exchange_rows(defer=False)
         if self._pending_g:
             assert not self.shard_adam, "shard_adam has no deferred full-vector update to flush"
             self._wait_inflight()
@@ -599,6 +649,8 @@ class _TrainerBase:
             self._refresh_planes_written_outside_the_graph()
         _, off = self.netG.bucket_split()
         gG = self.gradParametersG
+        if self._rows_stale:                 # the row blocks the last phase C updated: on the wire beside this iteration's first layers
+            self._exchange_rows(defer=True)
         pa()
         B.all_reduce_avg(self.gradParametersD, self.world, self.group)
         pb()
@@ -618,10 +670,12 @@ class _TrainerBase:
             if h is not None:
                 h.wait()
         rows = self._dp_rows()               # (asked before phase C clears the marks)
-        slices = list(self._dpf) if rows else []
+        if rows and self._row_ranges is None:
+            self._row_ranges = self.netG.fused_adam_row_ranges(self.world)
         pc()
-        for lo, hi in slices:                # every rank updated ITS rows of the pair: the updated row blocks to everybody
-            B.all_gather_shards(self.parametersG[lo:hi], self.world, self.rank, self.group)
+        if rows:                             # every rank updated ITS rows of the pair: the exchange opens the next iteration (or flush())
+            self._rows_stale = True
+            self.optimStateG["row_shard"] = (self.rank, self.world)
 
     # -- pipelined data-parallel iteration: G's exchange and Adam move into the NEXT iteration, behind netD's real pass
     #    A1: netD real pass | wait G buckets (i-1) | A2: Adam(G) (i-1), netG forward, netD fake pass | all-reduce D |
