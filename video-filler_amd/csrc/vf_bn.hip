@@ -165,15 +165,32 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
   auto column_total = [&](const double* pbase) {      // valid in the threads with ry == 0
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     if (ok) {
+      // 512 partial rows per pass: the lane's 32 loads are ALL in flight before the first sum (the GEMM epilogues leave 512-1024 rows in
+      // another XCD's L2 or in memory: with four loads per loop iteration the walk was eight dependent round trips, 5-7 us for a launch
+      // that moves 64 KB).  Same four running sums, fed in the same order as the streaming loop it replaces: bit-identical totals.
       const double* p = pbase + col;
-      int k = ry;
-      for (; k + 48 < nslab; k += 64) {
-        s0 += p[(int64_t)k * ncol];
-        s1 += p[(int64_t)(k + 16) * ncol];
-        s2 += p[(int64_t)(k + 32) * ncol];
-        s3 += p[(int64_t)(k + 48) * ncol];
+      for (int base = 0; base < nslab; base += 512) {
+        double v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int k = base + ry + 16 * i;
+          v[i] = k < nslab ? p[(int64_t)k * ncol] : 0.0;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const int k0 = base + ry + 64 * g;
+          if (k0 + 48 < nslab) {
+            s0 += v[4 * g];
+            s1 += v[4 * g + 1];
+            s2 += v[4 * g + 2];
+            s3 += v[4 * g + 3];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (k0 + 16 * j < nslab) s0 += v[4 * g + j];
+          }
+        }
       }
-      for (; k < nslab; k += 16) s0 += p[(int64_t)k * ncol];
     }
     __syncthreads();                                   // (the previous group's totals have been read)
     red[ry][cx] = (s0 + s1) + (s2 + s3);

@@ -227,6 +227,7 @@ struct PGemm {
   const unsigned* dbits;   // the same mask as sign bits (vf_common.h act_bits_out layout), or NULL: read by the epilogue prefetch
   int dact;
   float dslope;
+  long long* stamps;     // timing experiments only (VF_PG_STAMPS=<file>, k_pconv_patch_g<., true>): shader-clock stamps per wave and step
   int dbg;               // timing experiments only (VF_PG_DBG; wrong results): 1 = no operand loads after the first step,
                          // 2 = no LDS writes after the first step, 4 = no MFMAs, 8 = no output stores, 32 = no first stage either (k_pconv_patch_g)
   VfBnSt st;
@@ -1076,10 +1077,24 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
 // opposite ends of the step — waves 0-3 the weights in front of their MFMAs, waves 4-7 the next unit's patch planes behind theirs
 // (33.0 against 31.4 on one box: no better).  v_mfma_f32_16x16x32_bf16 in place of 32x32x16 (the same cycles; the guide's
 // higher-clock shape) moved the tile by 3-5 % in a timing-only build, not enough to give up bit-identity with the other kernels.
+// What the step is made of (in-kernel stamps, diagnostic build; profiles/r05_g_gather_patch_stamps_and_fetch_waves.txt): ~180 cycles
+// from the barrier to the first MFMA (fragment reads), ~1 530 in which the SIMD's 48 MFMAs (1 536 cycles of pipe time) are issued —
+// the older wave of a pair finishes its 24 after ~1 140 and then waits ~1 000 at the barrier for the younger, which gets the pipe's
+// leftover slots — ~130 in s_waitcnt, ~270 in the barrier for the wave that arrives last: ~2 360 per step, the pipe 65 % busy.  Built on
+// that reading and measured without gain (all bit-identical; the same file): FOUR DEDICATED FETCH WAVES (blocks of 12 waves: waves 8-11
+// issue every DMA, the computing waves no vector-memory instruction) — the stamped step is then the same 2 364 cycles with the DMAs as
+// without them, i.e. the fill stream costs the computing waves no cycle any more, and the launch takes the same 28.7 us (28.5 without
+// fetch waves): what the DMAs cost is CLOCK, not cycles (same cycle count, 47.5 against 41.5 us in the stamped build); fragment reads
+// two k-groups ahead; the next group's reads interleaved one by one with the MFMAs (sched_group_barrier: 31.7 against 29.0 us);
+// s_setprio for the SIMD's younger wave.  Every variant lands within 3 % of 29 us on E3 — the kernel sits at what the chip's clock
+// management gives a loop of this switching activity, and what did move it is what removed bytes (the fill: 72 -> 39 KB per step).
 // Same six-term products in the same K order per output element as k_pconv_dma: bit-identical results.  N % 64 == 0, C % 64 == 0,
 // split-K over channel chunks as k_pconv_dma.  Semantics: nn.SpatialConvolution forward (train.lua:89-101, 183-193) and
 // nn.SpatialFullConvolution's data-gradient (train.lua:134-146).
-template <int MODE>
+// ST: diagnostic build (VF_PG_STAMPS): lane 0 of every wave of the first 64 blocks stamps the shader clock at four points of each of its
+// first 16 steps — after the barrier, after its DMA issue, after its last MFMA, after its s_waitcnt — into p.stamps
+// (scripts/probe/pg_stamp_report.py)
+template <int MODE, bool ST = false>
 __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   constexpr int PW = 17;
   constexpr int NSLOT = MODE == 0 ? 9 * PW : 130;           // MODE 1, 2: 128 real slots + the zero slots 128, 129
@@ -1297,9 +1312,25 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
       constexpr int s_ = decltype(S)::value, cls = s_ >> 2, t = s_ & 3, wbuf = s_ & 1, pb = cls & 1;      // (4 units per chunk: the buffer parity follows the class)
       const bool last_unit = (c + 1 == cps) && cls == 3;
       const int nch = cls == 3 ? ch + 1 : ch, ncls = (cls + 1) & 3;      // the next unit
-      // this wave's DMAs (this step's weights; at a unit's first step its patch) have landed and its LDS reads have returned — the lo
-      // fragments read ahead during step 2 in particular, whose plane the DMAs of step 3 overwrite; after the barrier everybody's have
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      auto stamp = [&](int slot) {
+        if constexpr (ST) {
+          if (c == 0 && lane == 0 && blockIdx.x < 64) p.stamps[(((int)blockIdx.x * 8 + wave) * 16 + s_) * 4 + slot] = (long long)__builtin_amdgcn_s_memtime();
+        }
+      };
+      // this wave's DMAs of THIS step's weights have landed — and, at a unit's first step, of its patch — and its LDS reads have
+      // returned (the lo fragments read ahead during step 2 in particular, whose plane the DMAs of step 3 overwrite); after the barrier
+      // everybody's have.  The hi / mid planes of the NEXT unit, issued behind the weights of steps 0 / 1, are not needed before that
+      // unit begins: steps 1 and 2 leave the (at least two) DMAs of the plane issued one step earlier in flight — vmcnt counts in
+      // issue order, so the weights in front of them have landed — instead of waiting the whole fill stream out at every step
+      if constexpr (t == 1 || t == 2) {
+        if (last_unit) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (no next unit: nothing but weights in flight)
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      stamp(3);          // (of the step that just ended: its slot 3 is written here, one step late — see the dump's reader)
+      asm volatile("s_barrier" ::: "memory");
+      stamp(0);
       __builtin_amdgcn_sched_barrier(0);
       if (!(p.dbg & 1)) {
         if constexpr (s_ + 1 < 16) dma_w(ch, VfIntC<s_ + 1>{}, wbuf ^ 1, true);
@@ -1310,7 +1341,9 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
       }
       if constexpr (t == 2) read_lo_ahead(VfIntC<s_ + 1>{});
       __builtin_amdgcn_sched_barrier(0);
+      stamp(1);
       if (!(p.dbg & 4)) compute_step(S, pb, wbuf);
+      stamp(2);
     });
   }
   // every DMA has landed and nobody still reads a weight stage when the epilogue's partial sums go there
@@ -1696,6 +1729,32 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
       const int mode = (Wo % 16 == 0 && Ho % 8 == 0) ? 0 : (Ho == 8 && Wo == 8) ? 1 : (Ho == 4 && Wo == 4) ? 2 : -1;
       if (mode >= 0) {
         snprintf(dname, sizeof(dname), "pconv_patchg_128x64_t16_m%d", mode);
+        // timing experiments only (VF_PG_STAMPS=<file>): the stamped build of the 8 x 16-tile form; every 16th launch is synchronised and dumped
+        static const char* stamp_file = getenv("VF_PG_STAMPS");
+        if (stamp_file && mode == 0 && ksplit == 1) {
+          static long long* stamp_buf = nullptr;
+          static unsigned stamp_count = 0;
+          constexpr size_t NST = (size_t)64 * 8 * 16 * 4;
+          if (!stamp_buf) VF_CHECK_HIP(hipHostMalloc((void**)&stamp_buf, NST * sizeof(long long), hipHostMallocDefault));
+          g.stamps = stamp_buf;
+          const bool dump = (++stamp_count % 16) == 0;
+          if (dump) {
+            VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            memset(stamp_buf, 0, NST * sizeof(long long));
+          }
+          hipLaunchKernelGGL((k_pconv_patch_g<0, true>), dim3(nt), dim3(512), 0, ctx->stream, g);
+          VF_LAUNCH_CHECK();
+          if (dump) {
+            VF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            if (FILE* f = fopen(stamp_file, "ab")) {
+              const int hdr[4] = {(int)nt, g.M, g.N, g.C};
+              fwrite(hdr, sizeof(hdr), 1, f);
+              fwrite(stamp_buf, sizeof(long long), NST, f);
+              fclose(f);
+            }
+          }
+          return 0;
+        }
         if (mode == 0) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_g<0>, dim3(nt), dim3(512), g);
         else if (mode == 1) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_g<1>, dim3(nt), dim3(512), g);
         else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, k_pconv_patch_g<2>, dim3(nt), dim3(512), g);
