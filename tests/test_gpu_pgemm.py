@@ -373,6 +373,61 @@ def test_patch_fed_gather_pass_equals_the_tap_staged_kernel_bit_for_bit(Bn, Cin,
                 assert torch.equal(a, b), route
 
 
+# ... and the transposed passes whose low-resolution grid is a whole 8 x 8 / 4 x 4 map (k_pconv_patch_g<., ., TR>: E4 / E5 and netD's deeper
+# data-gradients, D2 / D3 forward), against k_pconv_dma<., ., 4> bit for bit; (Bn, Cin, H, Cout) as the scatter tests above: the low-res
+# operand has Cout channels on an H/2 grid
+TR_PATCH_CASES = [(16, 128, 16, 256, "m1"), (32, 256, 8, 512, "m2"), (64, 128, 16, 256, "m1"), (64, 256, 8, 512, "m2"), (128, 256, 8, 512, "m2")]
+
+
+@pytest.mark.parametrize("Bn,Cin,H,Cout,mode", TR_PATCH_CASES, ids=lambda v: str(v))
+def test_patch_fed_transposed_whole_map_pass_equals_the_tap_staged_kernel_bit_for_bit(Bn, Cin, H, Cout, mode, hipb):
+    dev = hipb.device
+    Hl = H // 2
+    gy = _act(Bn, Cout, Hl, 41, dev)
+    w = _rand((Cout, 4, 4, Cin), 42, dev, 0.05).permute(0, 3, 1, 2)
+    gp = hipb.planes_split(gy)
+    _, wt = hipb.weight_planes(w)
+    bias = _rand((Cin,), 43, dev, 0.1)
+    below = _act(Bn, Cin, H, 44, dev)
+    sm = _rand((Cin,), 45, dev, 0.1)
+    rows = max(Bn * H * H // 64, 512) + 8
+    outs = {}
+    try:
+        for route in (1, 0):
+            hipb.pconv_set_routing(scatter_patch=route)
+            res = []
+            # conv data-gradient, plain; with the LeakyReLU derivative mask; with mask + BatchNorm-backward sums; full-conv forward with
+            # bias + ReLU + BatchNorm forward sums
+            for kind in ("plain", "mask", "bwd_sums", "fwd_sums"):
+                out = hipb.empty_act(Bn, Cin, H, H)
+                out.fill_(float("nan"))
+                part = hipb.zeros(rows * 2 * Cin, dtype=torch.float64)
+                hipb.prof_begin()
+                if kind == "plain":
+                    hipb.pconv_scatter(gp, wt, None, out, Bn, Hl, Hl, Cout, Cin)
+                elif kind == "mask":
+                    hipb.pconv_scatter(gp, wt, None, out, Bn, Hl, Hl, Cout, Cin, dmask=below, dact="lrelu", dslope=0.2)
+                elif kind == "bwd_sums":
+                    hipb.bn_fuse_next_bwd(below, below, "lrelu", 0.2, sm, part, 1)
+                    hipb.pconv_scatter(gp, wt, None, out, Bn, Hl, Hl, Cout, Cin)
+                else:
+                    hipb.bn_fuse_next_fwd(sm, part, 1)
+                    hipb.pconv_scatter(gp, wt, bias, out, Bn, Hl, Hl, Cout, Cin, "relu", 0.0)
+                nrows = hipb.bn_fuse_result() if kind.endswith("sums") else 0
+                names = hipb.prof_end()
+                if route:
+                    assert "pconv_patchg_128x64_t4_" + mode in names, (kind, list(names))
+                else:
+                    assert not any(k.startswith("pconv_patch") for k in names), (kind, list(names))
+                res.append((out, part.view(-1, 2 * Cin)[:max(nrows, 0)].clone(), nrows))
+            outs[route] = res
+    finally:
+        hipb.pconv_set_routing(scatter_patch=1)
+    for (o1, p1, n1), (o0, p0, n0) in zip(outs[1], outs[0]):
+        assert torch.equal(o1, o0), float((o1 - o0).abs().max())
+        assert n1 == n0 and torch.equal(p1, p0)
+
+
 GATHER_ORACLE_CASES = [(4, 64, 32, 128, "m0"), (2, 64, 64, 64, "m0"), (4, 128, 16, 256, "m1"), (16, 256, 8, 512, "m2")]
 
 

@@ -1094,8 +1094,17 @@ __global__ __launch_bounds__(512) void k_pconv_patch_tr(const PGemm p) {
 // ST: diagnostic build (VF_PG_STAMPS): lane 0 of every wave of the first 64 blocks stamps the shader clock at four points of each of its
 // first 16 steps — after the barrier, after its DMA issue, after its last MFMA, after its s_waitcnt — into p.stamps
 // (scripts/probe/pg_stamp_report.py)
-template <int MODE, bool ST = false>
+// TR (MODE 1, 2): the TRANSPOSED passes (conv data-gradient, full-conv forward) whose low-resolution grid is a whole 8 x 8 / 4 x 4 map —
+// the ones k_pconv_patch_tr's 8 x 16 regions do not cover (E4 / E5 and netD's deeper data-gradients, D2 / D3 forward: 8 launches of
+// configs[1]).  A block serves ONE output-parity class (ph, pw) of its 128 low-resolution rows, as k_pconv_dma does (the grid keeps
+// its four blocks per row tile); the patch is the low-resolution map itself (128 pixels + the zero slots for the padding taps), staged
+// once per 64-channel chunk and read by the class's four taps (th, tw) at (my + ph - 1 + th, mx + pw - 1 + tw): a unit is a chunk,
+// four steps each — 12 + 24.6 KB of fill per step instead of 72.  Same planes schedule, same products, same K order as k_pconv_dma
+// <., ., 4>: bit-identical results.
+template <int MODE, bool ST = false, bool TR = false>
 __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
+  static_assert(!TR || MODE != 0, "the transposed form serves whole-map tiles (8 x 16 regions of larger maps: k_pconv_patch_tr)");
+  constexpr int NS = TR ? 4 : 16;                           // steps per channel chunk
   constexpr int PW = 17;
   constexpr int NSLOT = MODE == 0 ? 9 * PW : 130;           // MODE 1, 2: 128 real slots + the zero slots 128, 129
   constexpr int NG = (NSLOT + 7) / 8, AGW = (NG + 7) / 8;   // 8-slot DMA groups; groups per wave
@@ -1110,7 +1119,13 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int lr = lane & 31, lh = lane >> 5;
   const int ntiles = p.gm * p.gn * p.gz;
-  const int lid = pg_xcd_remap(blockIdx.x, ntiles);
+  int lid = pg_xcd_remap(blockIdx.x, ntiles);
+  int ph = 0, pw = 0;                                       // TR: this block's output-parity class
+  if constexpr (TR) {
+    ph = (lid >> 1) & 1;
+    pw = lid & 1;
+    lid >>= 2;
+  }
   const int bx = lid % p.gm, byz = lid / p.gm;
   const int n0 = (byz % p.gn) * 64;
   const int ks = byz / p.gn;
@@ -1151,8 +1166,10 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
       const int g = sl >> (2 * LW), ii = (sl >> LW) & (Wo - 1), jj = sl & (Wo - 1);
       const int oct = (lane & 7) ^ ((sl >> 1) & 7);
       const int img = bx * (128 / HW) + g;
-      // class (cth, ctw) of sub-image pixel (ii, jj) is input pixel (2 ii + 1 - cth, 2 jj + 1 - ctw): always inside the image
-      a_byte[i] = 2u * (unsigned)(((img * p.Hi + 2 * ii + 1) * p.Wi + 2 * jj + 1) * p.C + 8 * oct);
+      // class (cth, ctw) of sub-image pixel (ii, jj) is input pixel (2 ii + 1 - cth, 2 jj + 1 - ctw): always inside the image;
+      // TR: the low-resolution pixel (ii, jj) itself
+      if constexpr (TR) a_byte[i] = 2u * (unsigned)(((img * p.Hi + ii) * p.Wi + jj) * p.C + 8 * oct);
+      else a_byte[i] = 2u * (unsigned)(((img * p.Hi + 2 * ii + 1) * p.Wi + 2 * jj + 1) * p.C + 8 * oct);
       a_ok[i] = (grp < NG && sl < 128) ? 15u : 0u;
     }
   }
@@ -1170,7 +1187,7 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   auto dma_patch_plane = [&](int ch, int cls, int pb, auto Q, bool live) {
     constexpr int q = decltype(Q)::value;
     const int cth = cls >> 1, ctw = cls & 1;
-    const unsigned cb = 128u * (unsigned)ch + (unsigned)(MODE == 0 ? cth * rowA + ctw * colA : -(cth * rowA + ctw * colA));
+    const unsigned cb = 128u * (unsigned)ch + (TR ? 0u : (unsigned)(MODE == 0 ? cth * rowA + ctw * colA : -(cth * rowA + ctw * colA)));
     const unsigned dst = lds0 + (unsigned)(q == 2 ? OFF_LO : (2 * pb + q) * PL);
     if (!live) return;                                        // (wave-uniform: the block's last unit has no successor)
 #pragma unroll
@@ -1185,7 +1202,9 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   auto dma_w = [&](int ch, auto STEP, int buf, bool live) {
     constexpr int s_ = decltype(STEP)::value;
     constexpr int th = ((s_ >> 3) & 1) + 2 * ((s_ >> 1) & 1), tw = ((s_ >> 2) & 1) + 2 * (s_ & 1);
-    const unsigned tW = 2u * (unsigned)((th * 4 + tw) * p.C) + 128u * (unsigned)ch;
+    // TR: window tap (th, tw) = (s_ >> 1, s_ & 1) of class (ph, pw) meets filter tap (3 - ph - 2 th, 3 - pw - 2 tw)
+    const int ftap = TR ? (3 - ph - 2 * (s_ >> 1)) * 4 + 3 - pw - 2 * (s_ & 1) : th * 4 + tw;
+    const unsigned tW = 2u * (unsigned)(ftap * p.C) + 128u * (unsigned)ch;
     if (!live) return;
 #pragma unroll
     for (int q = 0; q < 3; ++q) pg_dma16(lds0 + (unsigned)(OFF_W + buf * WBUF + q * W_PL) + w_lds, w_byte, rsW, q * p.w_ps + tW);
@@ -1205,11 +1224,11 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
     slot_base = (arow >> 4) * PW + a_col;
   } else {
     const int oy = (arow >> LW) & (Wo - 1), ox = arow & (Wo - 1);
-    slot_base = (arow >> (2 * LW)) * HW + (oy - 1) * Wo + (ox - 1);
+    slot_base = (arow >> (2 * LW)) * HW + (oy - 1 + ph) * Wo + (ox - 1 + pw);      // (ph = pw = 0 unless TR)
     tap_ok = 0;
 #pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) {
-      const int di = ((s_ >> 3) & 1) + ((s_ >> 1) & 1) - 1, dj = ((s_ >> 2) & 1) + (s_ & 1) - 1;
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int di = (TR ? ph : ((s_ >> 3) & 1)) + ((s_ >> 1) & 1) - 1, dj = (TR ? pw : ((s_ >> 2) & 1)) + (s_ & 1) - 1;
       if ((unsigned)(oy + di) < (unsigned)Ho && (unsigned)(ox + dj) < (unsigned)Wo) tap_ok |= 1u << s_;
     }
   }
@@ -1220,7 +1239,7 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   // A fragment address pieces of step s_: byte offset of the slot inside a plane image, swizzle
   auto a_addr = [&](auto STEP, unsigned& off, unsigned& sw) {
     constexpr int s_ = decltype(STEP)::value;
-    constexpr int cth = (s_ >> 3) & 1, ctw = (s_ >> 2) & 1, a = (s_ >> 1) & 1, b = s_ & 1;
+    constexpr int cth = TR ? 0 : (s_ >> 3) & 1, ctw = TR ? 0 : (s_ >> 2) & 1, a = (s_ >> 1) & 1, b = s_ & 1;
     if constexpr (MODE == 0) {
       off = (unsigned)((slot_base + a * PW + b) * 128);
       sw = (unsigned)((a_col + b) & 7);
@@ -1279,7 +1298,11 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   //      fetched now, beside the first stages (k_pconv_dma's pre_d / pre_x)
   auto pix_of = [&](int row) -> int64_t {
     if constexpr (MODE == 0) return ((int64_t)b_img * Ho + oy0 + (row >> 4)) * Wo + ox0 + (row & 15);
-    else return (int64_t)bx * 128 + row;
+    else if constexpr (!TR) return (int64_t)bx * 128 + row;
+    else {      // low-resolution pixel (my, mx) of map bx * (128 / HW) + row / HW -> output pixel (2 my + ph, 2 mx + pw)
+      const int img = bx * (128 / HW) + (row >> (2 * LW)), my = (row >> LW) & (Wo - 1), mx = row & (Wo - 1);
+      return ((int64_t)img * (2 * Ho) + 2 * my + ph) * (2 * Wo) + 2 * mx + pw;
+    }
   };
   float pre_d[16], pre_x[16];
   const bool fin_tile = p.ksplit == 1;
@@ -1291,10 +1314,13 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   }
   if (want_d || want_x) {
     const int n = n0 + wn + lr;
+    // (sign bits instead of the fp32 activation where the producer left them — k_pconv_dma's layout: word 2 * (n / 64) + (n & 1) of
+    //  the pixel, bit (n / 2) % 32)
+    const int bw = 2 * (n >> 6) + (n & 1), bb = (n >> 1) & 31, wpp = p.N >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t pix = pix_of(wm + (r & 3) + 8 * (r >> 2) + 4 * lh);
-      if (want_d) pre_d[r] = p.dmask[pix * p.N + n];
+      if (want_d) pre_d[r] = p.dbits ? (float)((p.dbits[pix * wpp + bw] >> bb) & 1u) : p.dmask[pix * p.N + n];
       if (want_x) pre_x[r] = p.st.x[pix * p.N + n];
     }
   }
@@ -1308,10 +1334,12 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   for (int c = 0; c < cps; ++c) {
     const int ch = ch0 + c;
     asm volatile("" : "+v"(slot_base), "+v"(b_off0), "+s"(rowA), "+s"(colA));
-    vf_static_for<16>([&](auto S) {
-      constexpr int s_ = decltype(S)::value, cls = s_ >> 2, t = s_ & 3, wbuf = s_ & 1, pb = cls & 1;      // (4 units per chunk: the buffer parity follows the class)
-      const bool last_unit = (c + 1 == cps) && cls == 3;
-      const int nch = cls == 3 ? ch + 1 : ch, ncls = (cls + 1) & 3;      // the next unit
+    vf_static_for<NS>([&](auto S) {
+      // gather: 4 units (classes) per chunk, the patch buffer's parity follows the class; TR: ONE unit per chunk, it follows the chunk
+      constexpr int s_ = decltype(S)::value, cls = s_ >> 2, t = s_ & 3, wbuf = s_ & 1;
+      const int pb = TR ? (c & 1) : (cls & 1);
+      const bool last_unit = (c + 1 == cps) && (TR || cls == 3);
+      const int nch = (TR || cls == 3) ? ch + 1 : ch, ncls = TR ? 0 : ((cls + 1) & 3);      // the next unit
       auto stamp = [&](int slot) {
         if constexpr (ST) {
           if (c == 0 && lane == 0 && blockIdx.x < 64) p.stamps[(((int)blockIdx.x * 8 + wave) * 16 + s_) * 4 + slot] = (long long)__builtin_amdgcn_s_memtime();
@@ -1333,7 +1361,7 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
       stamp(0);
       __builtin_amdgcn_sched_barrier(0);
       if (!(p.dbg & 1)) {
-        if constexpr (s_ + 1 < 16) dma_w(ch, VfIntC<s_ + 1>{}, wbuf ^ 1, true);
+        if constexpr (s_ + 1 < NS) dma_w(ch, VfIntC<s_ + 1>{}, wbuf ^ 1, true);
         else dma_w(ch + 1, VfIntC<0>{}, wbuf ^ 1, c + 1 < cps);
         if constexpr (t == 0) dma_patch_plane(nch, ncls, pb ^ 1, VfIntC<0>{}, !last_unit);
         if constexpr (t == 1) dma_patch_plane(nch, ncls, pb ^ 1, VfIntC<1>{}, !last_unit);
@@ -1349,7 +1377,7 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
   // every DMA has landed and nobody still reads a weight stage when the epilogue's partial sums go there
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   typedef const float (&pre_t)[1][16];
-  pg_epilogue_at<1, 1, 4, 64, true>(p, acc, red, n0, wm, wn, lane, tid, wave >> 1, bx, ks, 0, 0, true, reinterpret_cast<pre_t>(pre_d),
+  pg_epilogue_at<1, 1, 4, 64, true>(p, acc, red, n0, wm, wn, lane, tid, wave >> 1, bx, ks, ph, pw, true, reinterpret_cast<pre_t>(pre_d),
                                     reinterpret_cast<pre_t>(pre_x), pix_of);
 }
 
@@ -1766,6 +1794,24 @@ static int launch_pconv(vf_ctx* ctx, PGemm& g, int ntaps, const char* what) {
         }
         return 0;
       }
+    }
+    // transposed passes whose low-resolution grid is a whole 8 x 8 / 4 x 4 map (what k_pconv_patch_tr's 8 x 16 regions do not cover): the
+    // patch kernel's TR form, one output-parity class per block as here
+    // (grids of one tile per CU only: from two rounds of blocks the single-stage k_pconv_dma, two blocks per CU, is faster —
+    //  netD's third conv at 2B, 512 blocks: 45.6 us against 46.5, with its derivative mask 51.9 against 59.7)
+    if (env_patch && ntaps == 4 && g.parity && g.N % 64 == 0 && t.bm == 128 && nt < 512 &&
+        ((g.Hi == 8 && g.Wi == 8) || (g.Hi == 4 && g.Wi == 4))) {
+      const int mode = g.Hi == 8 ? 1 : 2;
+      snprintf(dname, sizeof(dname), "pconv_patchg_128x64_t4_m%d", mode);
+      if (mode == 1) VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_patch_g<1, false, true>), dim3(nt), dim3(512), g);
+      else VF_LAUNCH_TIMED(ctx, dname, dfl, dby, (k_pconv_patch_g<2, false, true>), dim3(nt), dim3(512), g);
+      VF_LAUNCH_CHECK();
+      if (ksplit > 1) {
+        VfProf prof(ctx, slab_st ? "slab_reduce_pconv_bnstats" : "slab_reduce_pconv", 0.0, 4.0 * (double)g.out_elems * (ksplit + 1));
+        return vf_internal_slab_reduce(ctx, g.slab, g.Y, g.bias, g.out_elems, g.N, ksplit, g.act, g.slope, g.dmask, g.dact, g.dslope,
+                                       slab_st ? &g.st : nullptr, st_groups);
+      }
+      return 0;
     }
     static const int env_nbuf = getenv("VF_PG_NBUF") ? atoi(getenv("VF_PG_NBUF")) : 0;
     const bool one_stage = env_nbuf ? env_nbuf == 1 : (t.bm == 128 && nt >= 512);
