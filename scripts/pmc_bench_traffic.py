@@ -34,6 +34,11 @@ def bench_name(k):
     m = re.search(r"k_pconv_patch_tr<(\d)>", k)                                   # <parity classes per block>
     if m:
         return "pconv_patch_128x64_t4_c" + m.group(1)
+    m = re.search(r"k_pconv_patch_g<(\d), \w+, (\w+)>", k)                       # <MODE, stamps, TR>
+    if m:
+        return "pconv_patchg_128x64_%s_m%s" % ("t4" if m.group(2) == "true" else "t16", m.group(1))
+    if "k_pconv_patch_h" in k:
+        return "pconv_patchh_128x64_t16"
     if "k_adam_fused_multi" in k:      # the bottleneck pair's update as one launch (vf_internal_adam_fused_multi)
         return "adam_fused_wgrad"
     if "k_conv_thin_in" in k:          # (the nets' thin-input layers feed planes consumers: bench.py's name carries the suffix)
