@@ -6,8 +6,9 @@ import os
 import re
 import sys
 
-src, dst = sys.argv[1], sys.argv[2]
-# rocprof kernel name -> the name bench.py's kernel table uses
+
+
+# rocprof kernel name -> the name bench.py's kernel table uses (tests/test_host_logic.py pins the ones a bench line can choose)
 def bench_name(k):
     suf = {"0": "", "1": "_bf16", "3": "_bf16x3"}
     m = re.match(r"void k_wgrad_group<(\d+), \w+, \w+, (\d)>", k)
@@ -56,33 +57,38 @@ def bench_name(k):
     m = re.match(r"(?:void )?k_([a-z0-9_]+)", k)      # k_adam -> adam, k_bn_stats -> bn_stats ...
     return m.group(1) if m else k
 
-acc = {}
-for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = sorted(glob.glob(os.path.join(src, counter, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
-    if not files:
-        raise SystemExit("no counter_collection.csv under %s/%s" % (src, counter))
-    with open(files[-1]) as fh:
-        for row in csv.DictReader(fh):
-            if row.get("Counter_Name") != counter:
-                continue
-            name = bench_name(row["Kernel_Name"])
-            e = acc.setdefault(name, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
-            e[counter][0] += float(row["Counter_Value"])
-            e[counter][1] += 1
-out = {}
-for name, e in sorted(acc.items()):
-    nf, nw = e["FETCH_SIZE"][1], e["WRITE_SIZE"][1]
-    if not nf or not nw:
-        continue
-    fetch_kib, write_kib = e["FETCH_SIZE"][0] / nf, e["WRITE_SIZE"][0] / nw
-    out[name] = dict(launches_counted=nf, FETCH_SIZE_KiB_per_launch=round(fetch_kib, 1), WRITE_SIZE_KiB_per_launch=round(write_kib, 1),
-                     hbm_read_MB_per_launch_x2=round(2 * fetch_kib * 1024 / 1e6, 2), hbm_write_MB_per_launch=round(write_kib * 1024 / 1e6, 2),
-                     hbm_MB_per_launch=round((2 * fetch_kib + write_kib) * 1024 / 1e6, 2))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import csrc_digest  # noqa: E402
-head = os.environ.get("VF_GIT_HEAD", "")
-json.dump(dict(csrc_sha256=csrc_digest(), git_head=head, workload=os.environ.get("VF_PMC_WORKLOAD", "center"), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graph --no-overlap --steps 2 "
-                    "--warmup 1`; averages over every launch of the kernel in that run; FETCH_SIZE x2 (gfx950 correction, "
-                    "MI355X_MICROARCH.md); kernels keyed as in bench.py's kernel table",
-               kernels=out), open(dst, "w"), indent=1)
-print(json.dumps({k: v["hbm_MB_per_launch"] for k, v in out.items()}, indent=1))
+def main(src, dst):
+    acc = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = sorted(glob.glob(os.path.join(src, counter, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        if not files:
+            raise SystemExit("no counter_collection.csv under %s/%s" % (src, counter))
+        with open(files[-1]) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = bench_name(row["Kernel_Name"])
+                e = acc.setdefault(name, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+                e[counter][0] += float(row["Counter_Value"])
+                e[counter][1] += 1
+    out = {}
+    for name, e in sorted(acc.items()):
+        nf, nw = e["FETCH_SIZE"][1], e["WRITE_SIZE"][1]
+        if not nf or not nw:
+            continue
+        fetch_kib, write_kib = e["FETCH_SIZE"][0] / nf, e["WRITE_SIZE"][0] / nw
+        out[name] = dict(launches_counted=nf, FETCH_SIZE_KiB_per_launch=round(fetch_kib, 1), WRITE_SIZE_KiB_per_launch=round(write_kib, 1),
+                         hbm_read_MB_per_launch_x2=round(2 * fetch_kib * 1024 / 1e6, 2), hbm_write_MB_per_launch=round(write_kib * 1024 / 1e6, 2),
+                         hbm_MB_per_launch=round((2 * fetch_kib + write_kib) * 1024 / 1e6, 2))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_digest  # noqa: E402
+    head = os.environ.get("VF_GIT_HEAD", "")
+    json.dump(dict(csrc_sha256=csrc_digest(), git_head=head, workload=os.environ.get("VF_PMC_WORKLOAD", "center"), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graph --no-overlap --steps 2 "
+                        "--warmup 1`; averages over every launch of the kernel in that run; FETCH_SIZE x2 (gfx950 correction, "
+                        "MI355X_MICROARCH.md); kernels keyed as in bench.py's kernel table",
+                   kernels=out), open(dst, "w"), indent=1)
+    print(json.dumps({k: v["hbm_MB_per_launch"] for k, v in out.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
