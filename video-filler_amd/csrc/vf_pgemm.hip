@@ -1392,6 +1392,8 @@ __global__ __launch_bounds__(512) void k_pconv_patch_g(const PGemm p) {
 // NST = 1 (default): ONE stage in LDS (48 KB, three blocks per CU): issue the stage's DMAs, wait, barrier, MFMAs, barrier — a
 // block does not overlap its own loads and MFMAs, its CU-mates do; these grids are heavily split (tiles of 8-16 K steps, ten
 // rounds of blocks), and what bounds them is the start-up and drain of each tile, which co-resident blocks cover.
+// FS = 1 (default since round 5): ONE fragment set per wave — 73 registers instead of 124, so that three blocks per CU fit the register
+// file as well as LDS (with two sets it held two: the occupancy this form was built around was never reached); -0.8 % on the iteration.
 // NST = 3: three stages (144 KB, one block per CU), DMAs of stage k+2 issued before the MFMAs of stage k, `s_waitcnt vmcnt(6)`
 // lets the newest stage stay in flight, one barrier per step: 20 % slower here (VF_PWG_STAGES=3).
 // Layers WITHOUT planes (Up == NULL: the bottleneck pair, plain [K][Nu] x [K][16 Cv] fp32 matrices) are staged by the block
@@ -1410,8 +1412,8 @@ __device__ __forceinline__ bf16x8 pg_tr_frag(const __bf16* tile, int col0, int k
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int NST, int NPL = 3>
-__global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
+template <int NST, int NPL = 3, int FS = 1>
+__global__ __launch_bounds__(512, (NST == 1 && FS == 1) ? 6 : 1) void k_pwgrad_group(const VfPWGradGroup G) {
   int l = 0;
   while (l + 1 < G.n && (int)blockIdx.x >= G.blk_off[l + 1]) ++l;
   const VfPWGrad& p = G.d[l];
@@ -1501,6 +1503,33 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
   auto compute_stage = [&](int st) {
     const __bf16* base = smem + st * ST_SZ;
+    if constexpr (FS == 1) {
+      // ONE fragment set: a k-group's fragments are read, then multiplied — 73 registers instead of 124, so that the three blocks per CU
+      // the 48 KB stage was sized for really are resident (six waves per SIMD; with two sets the register file held two blocks).  The wave
+      // no longer reads group g + 1 under the MFMAs of group g: the other five waves of its SIMD are what covers that now.  Same MFMAs in
+      // the same order: bit-identical.  Same-box A/B of the iteration, eight interleaved runs each: 2.7013 -> 2.6795 ms (median, -0.8 %)
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {
+        bf16x8 a1[NPL], b1[NPL][2];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+          a1[q] = pg_tr_frag(base + q * PL_SZ, wm, 16 * g, lane);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) b1[q][nt] = pg_tr_frag(base + q * PL_SZ + TILE, wn + 32 * nt, 16 * g, lane);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {      // smallest terms first (the order of vf_conv.hip's mode 3)
+          if constexpr (NPL == 3) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[1][nt], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[2][nt], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[2], b1[0][nt], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[1][nt], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[0][nt], acc[nt], 0, 0, 0);
+          }
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[0][nt], acc[nt], 0, 0, 0);
+        }
+      }
+    } else {
     bf16x8 a[2][NPL], b[2][NPL][2];
     auto read_frag = [&](int g, int set) {
 #pragma unroll
@@ -1528,6 +1557,7 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0], b[cs][0][nt], acc[nt], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
   };
 
@@ -1588,13 +1618,15 @@ __global__ __launch_bounds__(512) void k_pwgrad_group(const VfPWGradGroup G) {
 
 int vf_internal_pwgrad_group(vf_ctx* ctx, const VfPWGradGroup& G, int blocks, const char* name, double flops) {
   static const int env_nst = getenv("VF_PWG_STAGES") ? atoi(getenv("VF_PWG_STAGES")) : 1;   // 1: 48 KB, three blocks per CU (measured 34.7 vs 42.9 us per 4.3 GFLOP layer)
+  static const int env_fs = getenv("VF_PWG_FS") ? atoi(getenv("VF_PWG_FS")) : 1;            // fragment sets per wave: 1 (three blocks per CU fit the register file too), 2 (round 2-4)
   if (ctx->mfma_bf16 == 1) {      // one rounded plane per operand: 16 KB stages
-    VF_LAUNCH_TIMED(ctx, "pwgrad_group_128x128x32_bf16", flops, 0.0, (k_pwgrad_group<1, 1>), dim3((unsigned)blocks), dim3(512), G);
+    VF_LAUNCH_TIMED(ctx, "pwgrad_group_128x128x32_bf16", flops, 0.0, (k_pwgrad_group<1, 1, 2>), dim3((unsigned)blocks), dim3(512), G);
     VF_LAUNCH_CHECK();
     return 0;
   }
-  if (env_nst == 1) VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group<1>, dim3((unsigned)blocks), dim3(512), G);
-  else VF_LAUNCH_TIMED(ctx, name, flops, 0.0, k_pwgrad_group<3>, dim3((unsigned)blocks), dim3(512), G);
+  if (env_nst == 1 && env_fs != 2) VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_pwgrad_group<1, 3, 1>), dim3((unsigned)blocks), dim3(512), G);
+  else if (env_nst == 1) VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_pwgrad_group<1, 3, 2>), dim3((unsigned)blocks), dim3(512), G);
+  else VF_LAUNCH_TIMED(ctx, name, flops, 0.0, (k_pwgrad_group<3, 3, 2>), dim3((unsigned)blocks), dim3(512), G);
   VF_LAUNCH_CHECK();
   return 0;
 }
