@@ -3,8 +3,9 @@ optim.adam_update_fused): train.lua:104 (conv nef*8 -> nBottleneck on a 4x4 map)
 THNN accGradParameters with K = batch, followed by optim/adam.lua's element update.
 
 What is held to what:
-  * the gradient the kernel forms (stored on request) against numpy in double: 2e-6 of its max-norm (fp32 products,
-    fp32 accumulation in batch order);
+  * the gradient the kernel forms (stored on request) against numpy in double: 2e-6 of its max-norm (K < 64: fp32 products on the
+    fp32 matrix pipe, fp32 accumulation in batch order; K >= 64 in the three-plane mode: operands pre-split into bf16 planes in
+    fragment order by k_fused_planes_prep, six product terms on the bf16 pipe — the launch list says which);
   * x, m, v after the fused update against vf_adam_apply fed with that same gradient: BIT FOR BIT (one definition of the
     element update, vf_common.h vf_adam_upd);
   * not storing the gradient changes nothing else: bit for bit;
@@ -30,9 +31,19 @@ def _state(hipb, n, seed):
     return x, m, v, t_dev
 
 
-@pytest.mark.parametrize("K,Nu,Ncols", [(4, 64, 128), (3, 66, 256), (16, 200, 1024), (64, 192, 2048), (8, 4000, 8192), (33, 70, 384)])
+@pytest.mark.parametrize("K,Nu,Ncols", [(4, 64, 128), (3, 66, 256), (16, 200, 1024), (64, 192, 2048), (8, 4000, 8192), (33, 70, 384),
+                                        (80, 70, 384), (128, 200, 1024), (72, 64, 128)])
 def test_fused_kernel_is_accgrad_then_adam(K, Nu, Ncols, hipb):
     assert hipb.lib.vf_wgrad_adam_outer_supported(K, Nu, Ncols) == 1
+    # which pipe forms the gradient: the operand-planes pre-pass runs for K >= 64, K % 16 == 0 (five k-groups at K = 80: an odd count;
+    # a ragged last row tile at Nu = 70 / 200), never below and never for a K that is no multiple of 16
+    x0, m0, v0, t0 = _state(hipb, Nu * Ncols, 7)
+    U0, V0 = hipb.zeros(K, Nu), hipb.zeros(K, Ncols)
+    hipb.adam_prep(2e-4, 0.5, 0.999, t0)
+    hipb.prof_begin()
+    hipb.wgrad_adam_outer(U0, V0, x0, m0, v0, None, 0.5, 0.999, 1e-8, t0)
+    names = hipb.prof_end()
+    assert ("adam_fused_operand_planes" in names) == (K >= 64 and K % 16 == 0), names.keys()
     gen = torch.Generator().manual_seed(K * 1000 + Nu)
     U = torch.randn(K, Nu, generator=gen).to(hipb.device)
     V = torch.randn(K, Ncols, generator=gen).to(hipb.device)

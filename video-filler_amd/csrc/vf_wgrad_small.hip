@@ -15,6 +15,10 @@
 // 32-column blocks), which makes every output store a float2 of adjacent columns: 32 lanes x 8 B = one 256-byte run.
 // A wave owns 64 x 64 outputs (4 accumulator tiles, three waves per SIMD), four independent waves per block.  fp32 products, fp32 accumulation in
 // batch order — the arithmetic of matrix-core mode 0, at least as accurate as the three-plane mode it stands in for.
+// Round 5: from K = 64 (the batch of configs[1]; world x 64 under data parallelism) the FUSED form takes its products from the bf16 pipe
+// like every other mode-3 kernel: k_fused_planes_prep splits both operands exactly into three bf16 planes in the fragment order of
+// v_mfma_f32_32x32x16_bf16, and the K loop is 6 x (K / 16) MFMAs of 32 cycles per accumulator tile where the fp32 pipe needs K / 2 of 64
+// (K = 64, 4000 x 8192: 188 -> 180 us with the pre-pass; K = 512, eight ranks' operands: 430 -> 355; the iteration -0.35 %).
 #include <algorithm>
 #include <cstdlib>
 
@@ -23,6 +27,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -41,6 +46,11 @@ struct VfAdamFuse {
   int kps, kshift;            // kshift: log2(kps) when it is a power of two, else -1
   int64_t seg;
   float gscale;
+  // K >= 64 in the three-plane mode: the operands pre-split into bf16 planes in FRAGMENT order by k_fused_planes_prep (NULL: the fp32
+  // matrix-core path below); kg = K / 16 k-groups
+  const bf16x8* uf;
+  const bf16x8* vf;
+  int kg;
 };
 __device__ __forceinline__ float ws_rne(float f) {
   const unsigned u = __float_as_uint(f);
@@ -124,6 +134,55 @@ __device__ __forceinline__ void wgrad_smallk_body(const float* __restrict__ U, c
   };
   Bat pre;
   if constexpr (FUSE && PF) bat_load(0, 0, pre);
+  bool planes_done = false;
+  if constexpr (FUSE && NJ == 2) {
+    if (A.uf != nullptr) {      // (wave-uniform)
+      // ---- the three-plane form: 16 batch rows per MFMA on the bf16 pipe, six product terms (smallest first: the order of every
+      // mode-3 kernel of the library); the operands arrive pre-split in fragment order — one coalesced 1 KB load per (row block, plane,
+      // k-group) — so the K = 64 gradient costs 96 MFMAs of 32 cycles where the fp32 pipe needs 128 of 64
+      const bf16x8* ua = A.uf + ((int64_t)(tr * 2) * A.kg * 3) * 64 + lane;       // [row tile][i][k-group][plane][lane]
+      const bf16x8* vb = A.vf + ((int64_t)(tc * 2) * A.kg * 3) * 64 + lane;       // [column tile][j][k-group][plane][lane]
+      const int gstride = 3 * 64, istride = A.kg * 3 * 64;
+      // (U fragments two sets deep, V fragments one: 144 registers beside the epilogue's batch — both two deep spilled)
+      bf16x8 fa[2][2][3], fb[2][3];                                               // [set][i][plane], [j][plane]
+      auto lda = [&](int g, int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fa[set][i][q] = ua[(int64_t)i * istride + g * gstride + q * 64];
+      };
+      auto ldb = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fb[j][q] = vb[(int64_t)j * istride + g * gstride + q * 64];
+      };
+      lda(0, 0);
+      for (int g = 0; g < A.kg; g += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (g + h >= A.kg) break;
+          ldb(g + h);
+          if (g + h + 1 < A.kg) lda(g + h + 1, h ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][i][1], fb[j][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][i][0], fb[j][2], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][i][2], fb[j][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][i][0], fb[j][1], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][i][1], fb[j][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][i][0], fb[j][0], acc[i][j], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      planes_done = true;
+    }
+  }
+  if (!planes_done) {
   Pair p0, p1, p2;
   ld(0, p0);
   ld(2, p1);
@@ -140,6 +199,7 @@ __device__ __forceinline__ void wgrad_smallk_body(const float* __restrict__ U, c
     __builtin_amdgcn_sched_barrier(0);
     mm(p2);
     __builtin_amdgcn_sched_barrier(0);
+  }
   }
   // D layout: column block index lane & 31, row index (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   auto store_all = [&](auto ACCUM) {
@@ -221,6 +281,65 @@ struct VfFusedTable {
   const float* V[VF_FUSED_MAX];
   VfAdamFuse A[VF_FUSED_MAX];
 };
+// Operands of the fused update as bf16 planes in FRAGMENT order (the three-plane form above): entry (tile t, half h, k-group g, plane q,
+// lane l) = the eight k values 16 g + 8 (l / 32) .. + 7 of operand row / column 64 t + 2 (l % 32) + h, exact three-way split (hi + mid + lo
+// == x bit for bit: vf_pgemm.hip pg_split4's arithmetic), zeros past the matrix edge.  One thread per (operand, t, h, g, l): eight strided
+// fp32 loads (32 lanes cover one 256-byte run between them and their h-partner), three 16-byte stores.  1.5 + 3.1 MB per layer at K = 64.
+struct VfPrepTable {
+  int nl;
+  int blk_off[VF_FUSED_MAX + 1];
+  int ut[VF_FUSED_MAX], vt[VF_FUSED_MAX];      // U row tiles, V column tiles (64 wide; the V entries follow the U entries)
+  bf16x8* uf[VF_FUSED_MAX];
+  bf16x8* vf[VF_FUSED_MAX];
+};
+__global__ __launch_bounds__(256) void k_fused_planes_prep(const VfFusedTable T, const VfPrepTable P) {
+  int l = 0;
+  while (l + 1 < P.nl && (int)blockIdx.x >= P.blk_off[l + 1]) ++l;
+  const VfAdamFuse& A = T.A[l];
+  const int kg = A.kg;
+  const int64_t e = ((int64_t)((int)blockIdx.x - P.blk_off[l]) * 256 + threadIdx.x);      // entry (t, h, g, lane) with lane fastest
+  const int lane = (int)(e & 63);
+  const int64_t r = e >> 6;
+  const int g = (int)(r % kg);
+  const int64_t th = r / kg;                    // 2 t + h
+  const bool is_v = th >= 2 * (int64_t)P.ut[l];
+  const int64_t th2 = is_v ? th - 2 * (int64_t)P.ut[l] : th;
+  const int t = (int)(th2 >> 1), h = (int)(th2 & 1);
+  const int ncols = is_v ? T.Ncols[l] : T.Nu[l];
+  if (th >= 2 * (int64_t)(P.ut[l] + P.vt[l])) return;      // (padding threads of the layer's last block)
+  const int col = t * 64 + 2 * (lane & 31) + h;
+  const float* base = is_v ? T.V[l] : T.U[l];
+  const int ld = is_v ? T.Ncols[l] : T.ldu[l];
+  float x[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = 16 * g + 8 * (lane >> 5) + q;
+    float v = 0.f;
+    if (k < T.K[l] && col < ncols) {
+      if (A.seg != 0) {
+        const int sg = A.kshift >= 0 ? k >> A.kshift : k / A.kps, kr = k - sg * A.kps;
+        v = base[sg * A.seg + (int64_t)kr * ld + col];
+      } else {
+        v = base[(int64_t)k * ld + col];
+      }
+    }
+    x[q] = v;
+  }
+  bf16x8* dst = (is_v ? P.vf[l] : P.uf[l]) + (((int64_t)(t * 2 + h) * kg + g) * 3) * 64 + lane;
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+    u16x8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned u = __float_as_uint(x[q]);
+      o[q] = (unsigned short)(u >> 16);
+      x[q] -= __uint_as_float(u & 0xffff0000u);
+    }
+    *(u16x8*)(dst + p * 64) = o;
+  }
+}
+
 template <int RB, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_adam_fused_multi(const VfFusedTable T) {
   int l = 0;
@@ -309,9 +428,43 @@ int vf_internal_adam_fused_multi(vf_ctx* ctx, const VfFusedLayer* layers, int nl
     flops += 2.0 * L.K * n;
     bytes += (L.g_out ? 28.0 : 24.0) * n + 4.0 * L.K * ((double)L.Nu + L.Ncols);
   }
+  // ---- three-plane mode, K >= 64: the gradient on the bf16 pipe from operands pre-split in fragment order (k_fused_planes_prep into the
+  // context's workspace; the fp32 pipe's 128 MFMAs of 64 cycles per 64 x 64 tile become 96 of 32).  VF_ADAM_PLANES=0 keeps the fp32 form.
+  {
+    static const int env_pl = getenv("VF_ADAM_PLANES") ? atoi(getenv("VF_ADAM_PLANES")) : 1;
+    bool ok = env_pl && ctx->mfma_bf16 == 3;
+    size_t need = 0;
+    for (int i = 0; i < nl && ok; ++i) {
+      ok = T.K[i] >= 64 && T.K[i] % 16 == 0;
+      need += (size_t)(vf_cdiv(T.Nu[i], 64) + T.Ncols[i] / 64) * 2 * (T.K[i] / 16) * 3 * 64 * 16;
+    }
+    if (ok && need <= vf_ws_avail(ctx)) {
+      VfPrepTable P;
+      memset(&P, 0, sizeof(P));
+      P.nl = nl;
+      bf16x8* w = (bf16x8*)vf_ws_ptr(ctx);
+      for (int i = 0; i < nl; ++i) {
+        const int kg = T.K[i] / 16;
+        P.ut[i] = (int)vf_cdiv(T.Nu[i], 64);
+        P.vt[i] = T.Ncols[i] / 64;
+        P.uf[i] = w;
+        w += (size_t)P.ut[i] * 2 * kg * 3 * 64;
+        P.vf[i] = w;
+        w += (size_t)P.vt[i] * 2 * kg * 3 * 64;
+        T.A[i].uf = P.uf[i];
+        T.A[i].vf = P.vf[i];
+        T.A[i].kg = kg;
+        P.blk_off[i + 1] = P.blk_off[i] + (int)vf_cdiv((int64_t)(P.ut[i] + P.vt[i]) * 2 * kg * 64, 256);
+      }
+      VfProf prof(ctx, "adam_fused_operand_planes", 0.0, (double)need * (1.0 + 4.0 / 6.0));
+      hipLaunchKernelGGL(k_fused_planes_prep, dim3((unsigned)P.blk_off[nl]), dim3(256), 0, ctx->stream, T, P);
+      VF_LAUNCH_CHECK();
+    }
+  }
   // measured (scripts/bench_fused_adam.py; K = 64, 4000 x 8192): RB 4 / three waves per SIMD 180 us; RB 8 / two waves 181; RB 16 / two
   // waves 233 (spills); first batch loaded ahead of the K loop 174-180.  Round 4: all layers in ONE launch (a table in the
   // kernel arguments) — the tail of one tensor's update overlaps the start of the next.
+  // (the first epilogue batch loaded ahead of the now shorter K loop: 168 registers and 164 bytes of scratch — not instantiated)
   VF_LAUNCH_TIMED(ctx, "adam_fused_wgrad", flops, bytes, (k_adam_fused_multi<4, 3>), dim3((unsigned)T.blk_off[nl]), dim3(256), T);
   VF_LAUNCH_CHECK();
   return 0;
