@@ -23,7 +23,7 @@ def bench_name(k):
         return "igemm_%sx%s_%s_v%s%s%s" % (m.group(1), m.group(2), "kmajorB" if m.group(3) == "true" else "rowB", m.group(4),
                                           suf.get(m.group(5) or "0", ""), "_db" if m.group(7) == "true" else "")
     # k_pconv_dma<BM, BN, NTAPS> / k_pconv<BM, BN, WM, WN, NTAPS, CH, PAIR>
-    m = re.match(r"void k_pwgrad_group<(\d+)(?:, (\d+))?>", k)                      # <stages, planes per operand>
+    m = re.match(r"void k_pwgrad_group<(\d+)(?:, (\d+))?(?:, (\d+))?>", k)          # <stages, planes per operand, fragment sets>
     if m:
         return "pwgrad_group_128x128x32" + ("_bf16" if m.group(2) == "1" else "")
     # k_pconv_dma<BM, BN, NTAPS, LDS stages (1: the two-blocks-per-CU form), planes per operand (1: the bf16-operand mode)>

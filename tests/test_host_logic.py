@@ -746,6 +746,8 @@ def test_counter_summary_keys_kernels_the_way_the_bench_line_names_them():
         "void k_igemm<64, 64, 32, 32, true, 2, 3, false, true>(IGemm)": "igemm_64x64_kmajorB_v2_bf16x3_db",
         "void k_igemm<64, 64, 32, 32, false, 2, 3, false, true>(IGemm)": "igemm_64x64_rowB_v2_bf16x3_db",
         "void k_pwgrad_group<1, 3>(VfPWGradGroup)": "pwgrad_group_128x128x32",
+        "void k_pwgrad_group<1, 3, 1>(VfPWGradGroup)": "pwgrad_group_128x128x32",
+        "void k_pwgrad_group<1, 1, 2>(VfPWGradGroup)": "pwgrad_group_128x128x32_bf16",
         "void (anonymous namespace)::k_adam_fused_multi<4, 3>((anonymous namespace)::VfFusedTable)": "adam_fused_wgrad",
         "void (anonymous namespace)::k_conv_thin_in<3>(float const*, float const*)": "conv_thin_in_planes",
     }
@@ -761,4 +763,4 @@ def test_counter_summary_keys_kernels_the_way_the_bench_line_names_them():
     import json
     for f in glob.glob(os.path.join(root, "profiles", "r05_pmc_bench_traffic*.json")):
         keys = json.load(open(f))["kernels"].keys()
-        assert not any(re.fullmatch(r"pconv_patch_(g|h|tr)", k) for k in keys), (f, sorted(keys))
+        assert not any(re.fullmatch(r"pconv_patch_(g|h|tr)|pwgrad_group", k) for k in keys), (f, sorted(keys))
